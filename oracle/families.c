@@ -1,0 +1,209 @@
+/*
+ * oracle/families.c -- TEST INFRASTRUCTURE ONLY (CPU oracle, see oracle.h).
+ *
+ * Host callbacks (reference callback ABI, ntg.h:81-83,90-92) for the problem
+ * families the MI355X kernels provide as device functors, plus the batched CPU
+ * driver used by tests and by bench.py's cpu_baseline leg.
+ *   family 0  kincar     running cost  sum_o (z_o'')^2            (examples/kincar.c:105-117,
+ *                        generalised from 2 outputs to nout outputs = nout/2 cars stacked)
+ *   family 1  vanderpol  running cost  (z^2 + z'^2 + u^2)/2,  u = z'' + z - (1-z^2) z'
+ *                        (examples/vanderpol.c:206-241, examples/vanderpol.txt)
+ *   family 2  testfam    synthetic: every callback slot (initial/trajectory/final cost and
+ *                        nonlinear constraints) populated with smooth nonlinear functions,
+ *                        used only to exercise constraints.c/cost.c row orders.
+ * All families assume maxderiv == 3 for every output (flat index iz[o] = 3*o).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "oracle.h"
+
+static __thread int fam_nout = 2;
+void orc_family_set_nout(int nout) { fam_nout = nout; }
+
+/* ---- family 0 ---- */
+static void kincar_ucf(int *mode, int *nstate, int *i, double *f, double *df, double **zp)
+{
+	int o; (void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) { double s = 0.0; for (o = 0; o < fam_nout; o++) s += zp[o][2] * zp[o][2]; *f = s; }
+	if (*mode == 1 || *mode == 2)
+		for (o = 0; o < fam_nout; o++) { df[3 * o] = 0; df[3 * o + 1] = 0; df[3 * o + 2] = 2 * zp[o][2]; }
+}
+/* ---- family 1 ---- */
+static void vdp_ucf(int *mode, int *nstate, int *i, double *f, double *df, double **zp)
+{
+	double z = zp[0][0], zd = zp[0][1], zdd = zp[0][2], t1 = z * z, u = zdd + z - (1.0 - t1) * zd;
+	(void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) *f = t1 / 2.0 + zd * zd / 2.0 + u * u / 2.0;
+	if (*mode == 1 || *mode == 2) { df[0] = z + u * (1.0 + 2.0 * z * zd); df[1] = zd - u * (1.0 - t1); df[2] = u; }
+}
+/* ---- family 2 ---- */
+static void tf_icf(int *mode, int *nstate, double *f, double *df, double **zp)
+{
+	int o, L = fam_nout - 1; (void)nstate;
+	if (*mode == 0 || *mode == 2) { double s = 0; for (o = 0; o < fam_nout; o++) s += (zp[o][0] - 1.0) * (zp[o][0] - 1.0) + 0.5 * zp[o][1] * zp[o][1]; *f = s + 0.25 * zp[0][0] * zp[L][1]; }
+	if (*mode == 1 || *mode == 2) {
+		for (o = 0; o < fam_nout; o++) { df[3 * o] = 2.0 * (zp[o][0] - 1.0); df[3 * o + 1] = zp[o][1]; df[3 * o + 2] = 0; }
+		df[0] += 0.25 * zp[L][1]; df[3 * L + 1] += 0.25 * zp[0][0];
+	}
+}
+static void tf_ucf(int *mode, int *nstate, int *i, double *f, double *df, double **zp)
+{
+	int o, L = fam_nout - 1; double sn = sin(zp[0][0]), cs = cos(zp[0][0]); (void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) { double s = 0; for (o = 0; o < fam_nout; o++) s += zp[o][0] * zp[o][0] + 0.1 * zp[o][1] * zp[o][1] + zp[o][2] * zp[o][2]; *f = s + 0.3 * sn * zp[L][1]; }
+	if (*mode == 1 || *mode == 2) {
+		for (o = 0; o < fam_nout; o++) { df[3 * o] = 2.0 * zp[o][0]; df[3 * o + 1] = 0.2 * zp[o][1]; df[3 * o + 2] = 2.0 * zp[o][2]; }
+		df[0] += 0.3 * cs * zp[L][1]; df[3 * L + 1] += 0.3 * sn;
+	}
+}
+static void tf_fcf(int *mode, int *nstate, double *f, double *df, double **zp)
+{
+	int o; (void)nstate;
+	if (*mode == 0 || *mode == 2) { double s = 0; for (o = 0; o < fam_nout; o++) s += zp[o][0] * zp[o][1] + 0.5 * zp[o][2] * zp[o][2]; *f = s; }
+	if (*mode == 1 || *mode == 2) for (o = 0; o < fam_nout; o++) { df[3 * o] = zp[o][1]; df[3 * o + 1] = zp[o][0]; df[3 * o + 2] = zp[o][2]; }
+}
+/* nnlic = 1 */
+static void tf_nlicf(int *mode, int *nstate, double *c, double **dc, double **zp)
+{
+	int L = fam_nout - 1, v; (void)nstate;
+	if (*mode == 0 || *mode == 2) c[0] = zp[0][0] * zp[0][0] + zp[L][1];
+	if (*mode == 1 || *mode == 2) { for (v = 0; v < 3 * fam_nout; v++) dc[0][v] = 0; dc[0][0] += 2.0 * zp[0][0]; dc[0][3 * L + 1] += 1.0; }
+}
+/* nnltc = 2 */
+static void tf_nltcf(int *mode, int *nstate, int *i, double *c, double **dc, double **zp)
+{
+	int L = fam_nout - 1, v; (void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) {
+		c[0] = zp[0][0] * zp[0][0] + zp[L][0] * zp[L][0];
+		c[1] = zp[0][1] * zp[L][2] - cos(zp[0][0]);
+	}
+	if (*mode == 1 || *mode == 2) {
+		for (v = 0; v < 3 * fam_nout; v++) { dc[0][v] = 0; dc[1][v] = 0; }
+		dc[0][0] += 2.0 * zp[0][0]; dc[0][3 * L] += 2.0 * zp[L][0];
+		dc[1][1] += zp[L][2]; dc[1][3 * L + 2] += zp[0][1]; dc[1][0] += sin(zp[0][0]);
+	}
+}
+/* nnlfc = 1 */
+static void tf_nlfcf(int *mode, int *nstate, double *c, double **dc, double **zp)
+{
+	int L = fam_nout - 1, v; (void)nstate;
+	if (*mode == 0 || *mode == 2) c[0] = zp[0][2] * zp[0][0] + zp[L][1] * zp[L][1];
+	if (*mode == 1 || *mode == 2) { for (v = 0; v < 3 * fam_nout; v++) dc[0][v] = 0; dc[0][2] += zp[0][0]; dc[0][0] += zp[0][2]; dc[0][3 * L + 1] += 2.0 * zp[L][1]; }
+}
+
+orc_ucf_t orc_family_ucf(int fam) { return fam == 0 ? kincar_ucf : fam == 1 ? vdp_ucf : fam == 2 ? tf_ucf : NULL; }
+orc_icf_t orc_family_icf(int fam) { return fam == 2 ? tf_icf : NULL; }
+orc_icf_t orc_family_fcf(int fam) { return fam == 2 ? tf_fcf : NULL; }
+orc_nlic_t orc_family_nlicf(int fam) { return fam == 2 ? tf_nlicf : NULL; }
+orc_nltc_t orc_family_nltcf(int fam) { return fam == 2 ? tf_nltcf : NULL; }
+orc_nlic_t orc_family_nlfcf(int fam) { return fam == 2 ? tf_nlfcf : NULL; }
+
+/* ---------------- batched CPU driver ---------------- */
+static double **rows_view(const double *flat, int nrows, int ncols)
+{
+	double **r; int i;
+	if (nrows == 0) return NULL;
+	r = malloc(nrows * sizeof(double *));
+	for (i = 0; i < nrows; i++) r[i] = (double *)flat + (size_t)i * ncols;
+	return r;
+}
+static orc_problem *make_from_spec(const orc_batch_spec *s, const double *lowerb, const double *upperb)
+{
+	int nz = 0, o; double **lic, **ltc, **lfc; orc_problem *p;
+	for (o = 0; o < s->nout; o++) nz += s->maxderiv[o];
+	lic = rows_view(s->lic, s->nlic, nz); ltc = rows_view(s->ltc, s->nltc, nz); lfc = rows_view(s->lfc, s->nlfc, nz);
+	p = orc_problem_make(s->nout, (double *)s->bps, s->nbps, (int *)s->kninterv, (double **)s->knots,
+		(int *)s->order, (int *)s->mult, (int *)s->maxderiv,
+		s->nlic, lic, s->nltc, ltc, s->nlfc, lfc,
+		s->nnlic, orc_family_nlicf(s->family), s->nnltc, orc_family_nltcf(s->family), s->nnlfc, orc_family_nlfcf(s->family),
+		s->nicav, (orc_AV *)s->icav, s->ntcav, (orc_AV *)s->tcav, s->nfcav, (orc_AV *)s->fcav,
+		(double *)lowerb, (double *)upperb,
+		s->nicf, orc_family_icf(s->family), s->nucf, orc_family_ucf(s->family), s->nfcf, orc_family_fcf(s->family),
+		s->nicostav, (orc_AV *)s->icostav, s->ntcostav, (orc_AV *)s->tcostav, s->nfcostav, (orc_AV *)s->fcostav);
+	free(lic); free(ltc); free(lfc);
+	return p;
+}
+static int spec_nb(const orc_batch_spec *s) { return s->nlic + s->nltc + s->nlfc + s->nnlic + s->nnltc + s->nnlfc; }
+
+int orc_solve_batch(const orc_batch_spec *s, int batch, const double *lowerb, const double *upperb,
+                    double *x, const orc_sqp_opts *o, double *objective, int *inform, int *iters,
+                    int *nfev, int nthreads)
+{
+	int b, nb = spec_nb(s);
+	if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+	for (b = 0; b < batch; b++) {
+		orc_problem *p; orc_sqp_result res;
+		orc_family_set_nout(s->nout);
+		p = make_from_spec(s, lowerb + (size_t)b * nb, upperb + (size_t)b * nb);
+		orc_sqp_solve(p, x + (size_t)b * p->cc->nC, o, &res, NULL, NULL, NULL, NULL, 0);
+		if (objective) objective[b] = res.objective;
+		if (inform) inform[b] = res.inform;
+		if (iters) iters[b] = res.iters;
+		if (nfev) nfev[b] = res.nfev;
+		orc_problem_free(p);
+	}
+	return 0;
+}
+
+/* f[batch], g[batch][nC], c[batch][ncnln], cJac[batch][ncnln*nC] (column-major per problem) */
+int orc_eval_batch(const orc_batch_spec *s, int batch, const double *x, int mode,
+                   double *f, double *g, double *c, double *cJac, int nthreads)
+{
+	int b, nb = spec_nb(s);
+	double *zero = calloc(nb + 1, sizeof(double));
+	if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+	for (b = 0; b < batch; b++) {
+		orc_problem *p; int md = mode, ns = 1, n, nc;
+		orc_family_set_nout(s->nout);
+		p = make_from_spec(s, zero, zero);
+		n = p->cc->nC; nc = p->ncnln;
+		if (f || g) orc_funobj(p, &md, x + (size_t)b * n, f ? f + b : NULL, g ? g + (size_t)b * n : NULL, &ns);
+		md = mode;
+		if (nc > 0 && (c || cJac)) {
+			orc_funcon(p, &md, x + (size_t)b * n, c ? c + (size_t)b * nc : NULL, NULL, &ns);
+			if (cJac) memcpy(cJac + (size_t)b * nc * n, p->cJac, (size_t)nc * n * sizeof(double));
+		}
+		orc_problem_free(p);
+	}
+	free(zero);
+	return 0;
+}
+
+/* export of the setup-time tables in the flat layout the tests compare against:
+ * blk: outputs concatenated, per output [bp][q][r] (P*k_o*d_o doubles); off: [nout][P];
+ * A column-major nclin x nC; bl/bu: nC+nclin+ncnln.  Any pointer may be NULL. */
+int orc_spec_export(const orc_batch_spec *s, const double *lowerb, const double *upperb,
+                    double *blk, int *off, double *A, double *bl, double *bu)
+{
+	orc_problem *p; int o, nb = spec_nb(s), ntot; size_t pos = 0;
+	double *zero = calloc(nb + 1, sizeof(double));
+	orc_family_set_nout(s->nout);
+	p = make_from_spec(s, lowerb ? lowerb : zero, upperb ? upperb : zero);
+	for (o = 0; o < s->nout; o++) {
+		size_t cnt = (size_t)s->nbps * p->cc->order[o] * p->cc->maxderiv[o];
+		if (blk) memcpy(blk + pos, p->cc->blk[o], cnt * sizeof(double));
+		if (off) memcpy(off + (size_t)o * s->nbps, p->cc->off[o], s->nbps * sizeof(int));
+		pos += cnt;
+	}
+	ntot = p->cc->nC + p->nclin + p->ncnln;
+	if (A && p->nclin) memcpy(A, p->A, (size_t)p->nclin * p->cc->nC * sizeof(double));
+	if (bl) memcpy(bl, p->bl, ntot * sizeof(double));
+	if (bu) memcpy(bu, p->bu, ntot * sizeof(double));
+	orc_problem_free(p); free(zero);
+	return 0;
+}
+
+/* single-problem solve with trace (tests) */
+int orc_solve_one(const orc_batch_spec *s, const double *lowerb, const double *upperb, double *x,
+                  const orc_sqp_opts *o, orc_sqp_result *res, double *clambda, int *istate,
+                  double *R, double *trace, int trace_cap)
+{
+	orc_problem *p;
+	orc_family_set_nout(s->nout);
+	p = make_from_spec(s, lowerb, upperb);
+	orc_sqp_solve(p, x, o, res, clambda, istate, R, trace, trace_cap);
+	orc_problem_free(p);
+	return 0;
+}

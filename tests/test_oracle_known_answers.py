@@ -1,0 +1,116 @@
+"""Pins for the oracle's SQP (NPSOL replacement) at the optimum: closed-form KKT solutions for
+the kincar QPs and an independent scipy solve for vanderpol (BASELINE.md §2 tolerances:
+|dF| <= 1e-9, |dC|inf <= 1e-6, constraint violation <= 1e-8)."""
+import numpy as np
+import pytest
+import scipy.optimize as so
+
+import orc
+from ntg_amd import configs as cf
+
+
+def kkt_kincar(spec, b):
+    """min C'HC/2 s.t. AC=b with H = 2 D2' diag(w) D2 built from the oracle's tables."""
+    tab = orc.export_tables(spec, b, b)
+    n, P = spec.nC, spec.nbps
+    w = np.zeros(P); dt = np.diff(spec.bps); w[:-1] += dt / 2; w[1:] += dt / 2
+    H = np.zeros((n, n)); pos = 0; base = 0
+    for o in range(spec.nout):
+        k, d, no = spec.order[o], spec.maxderiv[o], spec.ncoef[o]
+        blk = tab["blk"][pos:pos + P * k * d].reshape(P, k, d); pos += P * k * d
+        D2 = np.zeros((P, no))
+        for i in range(P):
+            D2[i, tab["off"][o, i]:tab["off"][o, i] + k] = blk[i, :, 2]
+        H[base:base + no, base:base + no] = 2 * D2.T @ (w[:, None] * D2); base += no
+    A = tab["A"]; m = A.shape[0]
+    K = np.block([[H, A.T], [A, np.zeros((m, m))]])
+    sol = np.linalg.solve(K, np.concatenate([np.zeros(n), b]))
+    x = sol[:n]
+    return x, 0.5 * x @ H @ x
+
+
+def test_kincar_shipped_known_answer():
+    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
+    xs, fs = kkt_kincar(spec, lo)
+    assert abs(fs - 2.457581141950512) < 1e-10
+    np.testing.assert_allclose(xs, [0, 5, 10, 20, 30, 35, 40, -2, -2, -2, 0, 2, 2, 2], atol=1e-9)
+    for h in (0, 1):
+        r = orc.solve_one(spec, lo, up, np.ones(spec.nC), orc.default_opts(hessian=h))
+        assert r["inform"] == 0
+        assert abs(r["objective"] - fs) <= 1e-9
+        assert np.abs(r["x"] - xs).max() <= 1e-6
+        assert r["feas"] <= 1e-8
+        assert list(r["istate"][spec.nC:]) == [3] * spec.nclin
+
+
+def vdp_objective(spec):
+    tab = orc.export_tables(spec)
+    P, k, d = spec.nbps, spec.order[0], 3
+    blk = tab["blk"].reshape(P, k, d)
+    M = np.zeros((d, P, spec.nC))
+    for i in range(P):
+        M[:, i, tab["off"][0, i]:tab["off"][0, i] + k] = blk[i].T
+
+    def F(c):
+        z, zd, zdd = M[0] @ c, M[1] @ c, M[2] @ c
+        u = zdd + z - (1 - z * z) * zd
+        f = 0.5 * (z * z + zd * zd + u * u)
+        return float(np.sum(np.diff(spec.bps) * (f[1:] + f[:-1]) / 2))
+    return F, tab["A"]
+
+
+def test_vanderpol_known_answer():
+    spec = cf.config_A(); lo, up = cf.bounds_A()
+    F, A = vdp_objective(spec)
+    res = so.minimize(F, np.ones(spec.nC), method="SLSQP", constraints=[{"type": "eq", "fun": lambda c: A @ c - lo}],
+                      options=dict(ftol=1e-15, maxiter=500))
+    assert abs(res.fun - 1.7022142628309958) < 1e-9
+    cstar = [1, 1, 0.3937399093, -0.0369580060, -0.4395320819, -0.7168653229, -0.2449741945]
+    for h in (0, 1):
+        r = orc.solve_one(spec, lo, up, np.ones(spec.nC), orc.default_opts(hessian=h))
+        assert r["inform"] == 0
+        assert abs(r["objective"] - 1.7022142628309958) <= 1e-9
+        assert np.abs(r["x"] - cstar).max() <= 1e-6
+        assert r["feas"] <= 1e-8
+
+
+@pytest.mark.parametrize("cfg,ncars", [(cf.config_B, 1), (cf.config_M, 3)])
+def test_config_B_M_optimum_matches_kkt(cfg, ncars):
+    spec = cfg(); lo, up = cf.kincar_random_bounds(ncars, 2)
+    for p in range(2):
+        xs, fs = kkt_kincar(spec, lo[p])
+        for h in (0, 1):
+            r = orc.solve_one(spec, lo[p], up[p], np.ones(spec.nC), orc.default_opts(hessian=h))
+            assert r["inform"] == 0
+            assert abs(r["objective"] - fs) <= 1e-9 * max(1.0, abs(fs))
+            assert np.abs(r["x"] - xs).max() <= 1e-6 * max(1.0, np.abs(xs).max())
+            assert r["feas"] <= 1e-8
+        assert r["iters"] <= 5            # preconditioned: the QP is solved in a few majors
+
+
+def test_fixed_iteration_mode_and_limits():
+    spec = cf.config_B(); lo, up = cf.kincar_random_bounds(1, 1)
+    r = orc.solve_one(spec, lo[0], up[0], np.ones(spec.nC), orc.default_opts(itlim=50, fixed_iters=1), trace_cap=64)
+    assert r["inform"] == 4 and r["iters"] == 50
+    assert np.all(np.diff(r["trace"][:, 0]) < 0)          # monotone decrease of F
+    r2 = orc.solve_one(spec, lo[0], up[0], np.ones(spec.nC), orc.default_opts(itlim=5))
+    assert r2["inform"] == 4 and r2["iters"] == 5
+
+
+def test_unsupported_inputs_are_loud():
+    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
+    up2 = up.copy(); up2[0] += 1.0                         # a linear inequality: not in v1 scope
+    r = orc.solve_one(spec, lo, up2, np.ones(spec.nC))
+    assert r["inform"] == 9
+    T = cf.config_T()
+    r = orc.solve_one(T, np.zeros(T.nbounds), np.zeros(T.nbounds), np.ones(T.nC))
+    assert r["inform"] == 9                                # nonlinear constraints: next round
+
+
+def test_R_factor_is_cholesky_of_hessian_estimate():
+    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
+    r = orc.solve_one(spec, lo, up, np.ones(spec.nC), want_R=True)
+    R = r["R"]
+    assert np.allclose(R, np.triu(R))
+    H = R.T @ R
+    assert np.all(np.linalg.eigvalsh(H) > 0)
