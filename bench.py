@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- trajectories/sec of the batched SQP hot path on MI355X.
+
+Workload (BASELINE.json metric): 4096 kincar problems per GPU, 6 flat outputs, order-6 splines,
+20 intervals, 101 breakpoints (config M of SURVEY.md §8), random initial/final states
+(numpy PCG64 seed 20261003), start C = 1, exactly 50 SQP major iterations per problem in the
+NPSOL-equivalent mode (identity cold start, no convergence exit) -- one "step" = one batch solve.
+Inputs are resident in HBM when the timed region starts.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Besides the contract keys it carries
+  roofline      dominant kernel (sqp_kernel) against the HBM roof, algorithmic bytes =
+                SURVEY §8d per-evaluation bytes x evaluations actually performed in the launch
+  cpu_baseline  the CPU oracle (oracle/, kind "port") solving a bounded sample of the same
+                workload on the host cores of this box (rank 0, N=1 only)
+  to_convergence  the product's default mode (collocation preconditioner, convergence exit)
+  eval_kernel   the standalone colloc+assembly kernel (npsolCostFunction batched) streamed over
+                a large batch -- the HBM-bound view of the colloc+Jacobian assembly path
+"""
+from __future__ import annotations
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
+    ap.add_argument("--config", default="M", choices=["M", "B"])
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--cpu-sample", type=int, default=512)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from ntg_amd import api, configs as cf
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    spec = cf.config_M() if args.config == "M" else cf.config_B()
+    ncars = spec.nout // 2
+    B = args.batch
+    # weak scaling: every rank owns its own B problems, drawn from one global stream
+    lo_all, up_all = cf.kincar_random_bounds(ncars, B * world)
+    lo = torch.tensor(lo_all[rank * B:(rank + 1) * B], device=dev)
+    up = torch.tensor(up_all[rank * B:(rank + 1) * B], device=dev)
+    x0 = torch.ones((B, spec.nC), dtype=torch.float64, device=dev)
+    x = x0.clone()
+
+    plan = api.Plan(spec, local)
+    opts = api.default_opts(itlim=args.iters, fixed_iters=1, hessian=0)
+    work = torch.empty(plan.workspace_bytes(B, opts), dtype=torch.uint8, device=dev)
+    out = dict(objective=torch.empty(B, dtype=torch.float64, device=dev),
+               inform=torch.empty(B, dtype=torch.int32, device=dev),
+               iters=torch.empty(B, dtype=torch.int32, device=dev),
+               nfev=torch.empty(B, dtype=torch.int32, device=dev))
+    if world > 1:
+        gath_x = torch.empty((world * B, spec.nC), dtype=torch.float64, device=dev)
+        gath_o = torch.empty(world * B, dtype=torch.float64, device=dev)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        x.copy_(x0)
+        if i is not None:
+            ev[i][0].record()
+        plan.solve(lo, up, x, opts, work=work, out=out)
+        if i is not None:
+            ev[i][1].record()
+        if world > 1:  # the only collective: final gather of the results (RCCL over xGMI)
+            dist.all_gather_into_tensor(gath_x, x)
+            dist.all_gather_into_tensor(gath_o, out["objective"])
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    nfev_total = int(out["nfev"].sum().item())
+    iters_np = out["iters"].cpu().numpy()
+    inform_np = out["inform"].cpu().numpy()
+    value = world * B * args.steps / dt
+
+    res = {
+        "metric": "trajectories/sec (batched SQP, 50 major iterations, kincar 6-output order-6/20-interval)",
+        "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{spec.name}: {B} problems/GPU x {args.iters} SQP majors (identity cold start, fixed work)",
+                   "batch_per_gpu": B, "nout": spec.nout, "order": spec.order[0], "ninterv": spec.kninterv[0],
+                   "nbps": spec.nbps, "nC": spec.nC, "nclin": spec.nclin, "sqp_iters": args.iters,
+                   "parallelism": f"problems sharded over {world} GPU(s), final all_gather only"},
+        "solve_check": {"iters_min": int(iters_np.min()), "iters_max": int(iters_np.max()),
+                        "inform_counts": {str(k): int((inform_np == k).sum()) for k in np.unique(inform_np)},
+                        "nfev_per_problem": nfev_total / B},
+    }
+    alg_bytes = nfev_total * spec.eval_bytes()
+    ach = alg_bytes / (kern_ms * 1e-3) / 1e9
+    res["roofline"] = {"bound": "hbm", "kernel": "sqp_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                       "alg_bytes_per_launch": alg_bytes,
+                       "alg_bytes_def": f"{spec.eval_bytes()} B per funobj evaluation (SURVEY 8d) x {nfev_total} evaluations"}
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- product default mode: preconditioned, to convergence ----
+        oc = api.default_opts(hessian=1, itlim=args.iters)
+        wc = torch.empty(plan.workspace_bytes(B, oc), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            x.copy_(x0); oo = plan.solve(lo, up, x, oc, work=wc)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        nrep = 5
+        for _ in range(nrep):
+            x.copy_(x0); oo = plan.solve(lo, up, x, oc, work=wc)
+        torch.cuda.synchronize()
+        dtc = (time.perf_counter() - t1) / nrep
+        res["to_convergence"] = {"value": B / dtc, "unit": "trajectories/s", "ms_per_batch": 1e3 * dtc,
+                                 "mode": "collocation-preconditioned BFGS, KKT exit (NPSOL tolerances)",
+                                 "converged_frac": float((oo["inform"] == 0).float().mean().item()),
+                                 "iters_mean": float(oo["iters"].float().mean().item()),
+                                 "iters_max": int(oo["iters"].max().item())}
+        del wc
+        # ---- standalone evaluation kernel streamed over a large batch ----
+        nb = 1 << 18
+        xe = torch.randn((nb, spec.nC), dtype=torch.float64, device=dev)
+        for _ in range(2):
+            plan.eval(xe, 2)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        nrep = 10
+        e0.record()
+        for _ in range(nrep):
+            plan.eval(xe, 2)
+        e1.record(); torch.cuda.synchronize()
+        ems = e0.elapsed_time(e1) / nrep
+        eb = nb * spec.eval_bytes()
+        res["eval_kernel"] = {"kernel": "eval_kernel", "batch": nb, "ms": ems, "achieved": eb / (ems * 1e-3) / 1e9,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eb / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "evals_per_s": nb / (ems * 1e-3)}
+        del xe
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orc
+        ncore = os.cpu_count() or 1
+        ns = min(args.cpu_sample, B)
+        oo = orc.default_opts(itlim=args.iters, fixed_iters=1, hessian=0)
+        t1 = time.perf_counter()
+        r = orc.solve_batch(spec, lo_all[:ns], up_all[:ns], np.ones((ns, spec.nC)), oo, nthreads=ncore)
+        dtc = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": ns / dtc, "unit": "trajectories/s", "cores": ncore, "kind": "port",
+                               "sample": f"first {ns} problems of the same batch, same 50 fixed majors, oracle/sqp.c with "
+                                         f"reference-faithful dense assembly, OpenMP one problem per thread, {dtc:.2f} s wall"}
+        # same inputs -> same answers (oracle is the checker here, never the thing shipped)
+        gobj = out["objective"][:ns].cpu().numpy()
+        res["cpu_baseline"]["max_rel_objective_diff_vs_gpu"] = float(np.max(np.abs(gobj - r["objective"]) / np.abs(r["objective"])))
+
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,141 @@
+/*
+ * include/ntg_amd.h -- C ABI of the MI355X-native batched NTG engine (libntg_amd.so).
+ *
+ * Plain pointers and sizes only.  Pointers named d_* are DEVICE pointers (HBM of the GPU the
+ * plan was created on); everything else is host memory.  `stream` is a hipStream_t passed as
+ * void* (NULL = default stream).  All entry points return 0 on success, a negative NTG_E_*
+ * code otherwise; ntg_last_error() returns a message.  Nothing here falls back to the CPU:
+ * without a usable gfx950 device every call fails with NTG_E_NODEVICE.
+ *
+ * Which reference interface each entry point replaces (files under /root/reference/src):
+ *   ntg_plan_create      ntg.c:114-229   ConcatCollocMatrix + LinearConstraintsMatrix + the
+ *                                        argument stash into file-scope globals (ntg.c:119-152)
+ *                        colloc.c:57-117 CollocMatrix: knots_/interv_/bsplvd_ at every breakpoint
+ *   ntg_plan_tables      colloc.h:42-71  read-back of Block.matrix / Block.offset / A
+ *   ntg_basis_batch      colloc.c:92-111 the same basis evaluation for many grids at once
+ *   ntg_batch_eval       ntg.c:274-371   NPfunobj + NPfuncon (cost.c, constraints.c, integrator.c)
+ *   ntg_batch_bounds     constraints.c:5-33 bounds()
+ *   ntg_batch_solve      ntg.c:237-253   the npsol_() call, for `batch` problems at once
+ *   npsolCostFunction / npsolConstraintFunction
+ *                        ntg.c:274-280 / ntg.c:337-346  (static NPfunobj / NPfuncon; exported
+ *                        under the names BASELINE.json uses, same Fortran-style signature)
+ *   ntg(), npsoloption(), linspace(), SplineInterp(), matrix helpers: see include/ntg.h
+ */
+#ifndef NTG_AMD_H
+#define NTG_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTG_MAX_OUT 16     /* outputs per problem */
+#define NTG_MAX_ORDER 10   /* spline order k */
+#define NTG_MAX_NZ 64      /* sum of maxderiv (active-variable masks are 64-bit) */
+
+#define NTG_E_NODEVICE (-1)
+#define NTG_E_BADARG   (-2)
+#define NTG_E_HIP      (-3)
+#define NTG_E_UNSUPPORTED (-4)
+
+/* problem families = device functors for the user callbacks of ntg.h:81-83,90-92 */
+#define NTG_FAM_KINCAR 0     /* examples/kincar.c:105-117 generalised to nout outputs */
+#define NTG_FAM_VANDERPOL 1  /* examples/vanderpol.c:206-241 */
+#define NTG_FAM_TESTFAM 2    /* synthetic, all six callback slots */
+#define NTG_FAM_HOST (-1)    /* host function pointers (ntg() drop-in path only) */
+
+typedef struct { int output; int deriv; } ntg_av; /* == AV of av.h:22-26 */
+
+/* Everything ntg() takes that is common to a batch (ntg.h:72-99). lic/ltc/lfc are row-major
+ * [n][nz] with nz = sum(maxderiv) (the examples' DoubleMatrix layout). */
+typedef struct {
+	int nout, nbps;
+	const double *bps;
+	const int *kninterv;
+	const double *const *knots;
+	const int *order, *mult, *maxderiv;
+	int family;
+	int nlic, nltc, nlfc;
+	const double *lic, *ltc, *lfc;
+	int nnlic, nnltc, nnlfc;
+	int nicav, ntcav, nfcav;
+	const ntg_av *icav, *tcav, *fcav;
+	int nicf, nucf, nfcf;
+	int nicostav, ntcostav, nfcostav;
+	const ntg_av *icostav, *tcostav, *fcostav;
+} ntg_spec;
+
+typedef struct {
+	int itlim;          /* major iteration limit; <=0: max(50, 3(n+nclin)+10 ncnln) (NPSOL default) */
+	double opttol;      /* optimality tolerance r; <=0: eps^0.8 */
+	double steplimit;   /* NPSOL "step limit", 2.0 */
+	double ls_mu, ls_eta; /* 1e-4, 0.9 (NPSOL "line search tolerance") */
+	int ls_maxfev;      /* 20 */
+	int hessian;        /* 0 identity cold start (NPSOL), 1 collocation preconditioner */
+	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
+	int block_threads;  /* 0 = auto (64/128/256) */
+} ntg_solve_opts;
+
+typedef struct ntg_plan ntg_plan;
+
+int ntg_device_count(void);
+const char *ntg_last_error(void);
+void ntg_default_opts(ntg_solve_opts *o);
+
+/* Build the device-resident, batch-shared part of a problem: basis blocks and offsets (HIP
+ * basis kernel), banded linear-constraint rows A, (A A')^-1, optional preconditioner. */
+int ntg_plan_create(const ntg_spec *spec, int device, ntg_plan **out);
+void ntg_plan_destroy(ntg_plan *p);
+
+/* sizes: nC, nz, nclin, ncnln, nbounds, sumk, njrows (banded Jacobian rows), nblk (doubles in blk) */
+int ntg_plan_dims(const ntg_plan *p, int *nC, int *nz, int *nclin, int *ncnln, int *nbounds,
+                  int *sumk, int *nblk);
+/* read the setup tables back to the host (any pointer may be NULL):
+ *   blk  outputs concatenated, per output [bp][q][r]         (reference block[bp].matrix->elements[q][r])
+ *   off  [nout][nbps]                                         (reference block[bp].offset)
+ *   A    dense column-major nclin x nC, ld = nclin            (what ntg.c:206 hands to NPSOL) */
+int ntg_plan_tables(const ntg_plan *p, double *blk, int *off, double *A);
+/* workspace (bytes) ntg_batch_solve needs for `batch` problems with these options */
+long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, const ntg_solve_opts *o);
+
+/* bounds(): d_lower/d_upper [batch][nbounds] -> d_bl/d_bu [batch][nC+nclin+ncnln] */
+int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
+                     double *d_bl, double *d_bu, void *stream);
+
+/* funobj+funcon for `batch` coefficient vectors d_x [batch][nC], mode as in NPSOL (0 values,
+ * 1 gradients, 2 both).  Outputs (any may be NULL): d_f [batch], d_g [batch][nC],
+ * d_c [batch][ncnln] (rows: initial; trajectory constraint-major x breakpoint; final),
+ * d_jband [batch][ncnln][sumk] banded Jacobian rows (for output o the entries
+ * koff[o]..koff[o]+k_o-1 sit in columns iC[o]+off[o][bp(row)]+q),
+ * d_cjac [batch][nC][ncnln] = dense column-major (ld = ncnln) Jacobian as NPSOL sees it. */
+int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, int mode,
+                   double *d_f, double *d_g, double *d_c, double *d_jband, double *d_cjac,
+                   void *stream);
+
+/* Solve `batch` problems: d_x [batch][nC] in/out (initial guess -> solution, ntg.c:109),
+ * d_lower/d_upper [batch][nbounds].  Outputs (may be NULL): d_objective, d_inform, d_iters,
+ * d_nfev [batch]; d_clambda [batch][nC+nclin+ncnln].  d_work: ntg_batch_workspace_bytes(). */
+int ntg_batch_solve(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
+                    double *d_x, const ntg_solve_opts *o,
+                    double *d_objective, int *d_inform, int *d_iters, int *d_nfev,
+                    double *d_clambda, void *d_work, long long work_bytes, void *stream);
+/* name and average-per-launch facts of the solve kernel, for bench/roofline bookkeeping */
+const char *ntg_solve_kernel_name(void);
+
+/* bsplvd at every collocation point for `ngrids` different grids of one spline spec
+ * (per-problem horizons): d_knots [ngrids][ninterv+1], d_bps [ngrids][nbps] ->
+ * d_blk [ngrids][nbps][order][maxderiv], d_off [ngrids][nbps]. */
+int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, int nbps,
+                    const double *d_knots, const double *d_bps, double *d_blk, int *d_off,
+                    void *stream);
+
+/* NPSOL-facing callbacks of the single-problem drop-in (valid while ntg() is running, or
+ * after ntg_set_current_plan()).  Host pointers, Fortran conventions (scalars by pointer),
+ * cJac column-major ldJ x n. */
+void npsolCostFunction(int *mode, int *n, double *x, double *f, double *g, int *nstate);
+void npsolConstraintFunction(int *mode, int *ncnln, int *n, int *ldJ, int *needc, double *x,
+                             double *c, double *cJac, int *nstate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,226 @@
+"""ctypes binding of libntg_amd.so (include/ntg_amd.h).  Host plumbing only: it marshals a Spec
+into the C ABI and passes torch device pointers; all numerics run in the library's HIP kernels.
+There is no fallback: if the library is missing or no GPU is visible, calls raise."""
+from __future__ import annotations
+import ctypes as C
+import os
+from typing import Optional
+import numpy as np
+
+from .spec import Spec
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntg_amd.so")
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+class NtgError(RuntimeError):
+    pass
+
+
+class _AV(C.Structure):
+    _fields_ = [("output", C.c_int), ("deriv", C.c_int)]
+
+
+class _Spec(C.Structure):
+    _fields_ = [("nout", C.c_int), ("nbps", C.c_int), ("bps", dp), ("kninterv", ip),
+                ("knots", C.POINTER(dp)), ("order", ip), ("mult", ip), ("maxderiv", ip),
+                ("family", C.c_int),
+                ("nlic", C.c_int), ("nltc", C.c_int), ("nlfc", C.c_int),
+                ("lic", dp), ("ltc", dp), ("lfc", dp),
+                ("nnlic", C.c_int), ("nnltc", C.c_int), ("nnlfc", C.c_int),
+                ("nicav", C.c_int), ("ntcav", C.c_int), ("nfcav", C.c_int),
+                ("icav", C.POINTER(_AV)), ("tcav", C.POINTER(_AV)), ("fcav", C.POINTER(_AV)),
+                ("nicf", C.c_int), ("nucf", C.c_int), ("nfcf", C.c_int),
+                ("nicostav", C.c_int), ("ntcostav", C.c_int), ("nfcostav", C.c_int),
+                ("icostav", C.POINTER(_AV)), ("tcostav", C.POINTER(_AV)), ("fcostav", C.POINTER(_AV))]
+
+
+class SolveOpts(C.Structure):
+    _fields_ = [("itlim", C.c_int), ("opttol", C.c_double), ("steplimit", C.c_double),
+                ("ls_mu", C.c_double), ("ls_eta", C.c_double), ("ls_maxfev", C.c_int),
+                ("hessian", C.c_int), ("fixed_iters", C.c_int), ("block_threads", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libntg_amd.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NtgError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.ntg_last_error.restype = C.c_char_p
+        L.ntg_solve_kernel_name.restype = C.c_char_p
+        L.ntg_batch_workspace_bytes.restype = C.c_longlong
+        L.ntg_batch_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ntg_plan_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ntg_plan_destroy.argtypes = [C.c_void_p]
+        L.ntg_plan_dims.argtypes = [C.c_void_p] + [ip] * 7
+        L.ntg_plan_tables.argtypes = [C.c_void_p, dp, ip, dp]
+        L.ntg_batch_bounds.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.ntg_batch_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        L.ntg_batch_solve.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_longlong, C.c_void_p]
+        L.ntg_basis_batch.argtypes = [C.c_int] * 6 + [C.c_void_p] * 5
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise NtgError(f"libntg_amd error {rc}: {lib().ntg_last_error().decode()}")
+
+
+def default_opts(**kw) -> SolveOpts:
+    o = SolveOpts()
+    lib().ntg_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Plan:
+    """Device-resident, batch-shared part of a problem (ntg_plan)."""
+
+    def __init__(self, spec: Spec, device: int = 0):
+        self.spec = spec
+        self.device = device
+        k = self._keep = {}
+        k["bps"] = np.ascontiguousarray(spec.bps, dtype=np.float64)
+        for nm in ("kninterv", "order", "mult", "maxderiv"):
+            k[nm] = np.asarray(getattr(spec, nm), dtype=np.int32)
+        k["knots"] = [np.ascontiguousarray(x, dtype=np.float64) for x in spec.knots]
+        k["kp"] = (dp * spec.nout)(*[x.ctypes.data_as(dp) for x in k["knots"]])
+        for nm in ("lic", "ltc", "lfc"):
+            k[nm] = np.ascontiguousarray(getattr(spec, nm), dtype=np.float64).reshape(-1)
+
+        def avs(lst):
+            arr = (_AV * max(len(lst), 1))()
+            for j, (o, d) in enumerate(lst):
+                arr[j].output, arr[j].deriv = o, d
+            return arr
+        for nm in ("icav", "tcav", "fcav", "icostav", "tcostav", "fcostav"):
+            k[nm] = avs(list(getattr(spec, nm)))
+        s = _Spec()
+        s.nout, s.nbps = spec.nout, spec.nbps
+        s.bps = k["bps"].ctypes.data_as(dp)
+        s.kninterv = k["kninterv"].ctypes.data_as(ip); s.order = k["order"].ctypes.data_as(ip)
+        s.mult = k["mult"].ctypes.data_as(ip); s.maxderiv = k["maxderiv"].ctypes.data_as(ip)
+        s.knots = k["kp"]; s.family = spec.family
+        s.nlic, s.nltc, s.nlfc = spec.nlic, spec.nltc, spec.nlfc
+        s.lic, s.ltc, s.lfc = (k[nm].ctypes.data_as(dp) for nm in ("lic", "ltc", "lfc"))
+        s.nnlic, s.nnltc, s.nnlfc = spec.nnlic, spec.nnltc, spec.nnlfc
+        s.nicav, s.ntcav, s.nfcav = len(spec.icav), len(spec.tcav), len(spec.fcav)
+        s.icav, s.tcav, s.fcav = k["icav"], k["tcav"], k["fcav"]
+        s.nicf, s.nucf, s.nfcf = spec.nicf, spec.nucf, spec.nfcf
+        s.nicostav, s.ntcostav, s.nfcostav = len(spec.icostav), len(spec.tcostav), len(spec.fcostav)
+        s.icostav, s.tcostav, s.fcostav = k["icostav"], k["tcostav"], k["fcostav"]
+        self._cspec = s
+        h = C.c_void_p()
+        _check(lib().ntg_plan_create(C.byref(s), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ntg_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup tables (host copies) ----
+    def tables(self):
+        sp = self.spec
+        nblk = sum(sp.nbps * k * d for k, d in zip(sp.order, sp.maxderiv))
+        blk = np.zeros(nblk); off = np.zeros((sp.nout, sp.nbps), dtype=np.int32)
+        A = np.zeros((sp.nC, max(sp.nclin, 1)))
+        _check(lib().ntg_plan_tables(self.h, blk.ctypes.data_as(dp), off.ctypes.data_as(ip), A.ctypes.data_as(dp)))
+        return dict(blk=blk, off=off, A=(A.T.copy() if sp.nclin else np.zeros((0, sp.nC))))
+
+    # ---- batched entry points; tensors are torch CUDA(HIP) float64/int32, contiguous ----
+    def bounds(self, lower, upper):
+        import torch
+        sp = self.spec
+        batch = lower.shape[0]
+        ntot = sp.nC + sp.nclin + sp.ncnln
+        bl = torch.empty((batch, ntot), dtype=torch.float64, device=lower.device); bu = torch.empty_like(bl)
+        _check(lib().ntg_batch_bounds(self.h, batch, _ptr(lower), _ptr(upper), _ptr(bl), _ptr(bu), self._stream()))
+        return bl, bu
+
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def eval(self, x, mode: int = 2, want_dense_jac: bool = False):
+        import torch
+        sp = self.spec
+        assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+        batch = x.shape[0]
+        dev = x.device
+        f = torch.empty(batch, dtype=torch.float64, device=dev)
+        g = torch.empty((batch, sp.nC), dtype=torch.float64, device=dev)
+        c = jb = cj = None
+        if sp.ncnln:
+            c = torch.zeros((batch, sp.ncnln), dtype=torch.float64, device=dev)
+            jb = torch.zeros((batch, sp.ncnln, sp.sumk), dtype=torch.float64, device=dev)
+            if want_dense_jac:
+                cj = torch.empty((batch, sp.nC, sp.ncnln), dtype=torch.float64, device=dev)
+        _check(lib().ntg_batch_eval(self.h, batch, _ptr(x), mode, _ptr(f), _ptr(g), _ptr(c), _ptr(jb), _ptr(cj), self._stream()))
+        out = dict(f=f, g=g)
+        if sp.ncnln:
+            out.update(c=c, jband=jb)
+            if want_dense_jac:
+                out["cJac"] = cj.transpose(1, 2).contiguous()
+        return out
+
+    def workspace_bytes(self, batch: int, opts: Optional[SolveOpts] = None) -> int:
+        return int(lib().ntg_batch_workspace_bytes(self.h, batch, C.byref(opts) if opts is not None else None))
+
+    def solve(self, lower, upper, x, opts: Optional[SolveOpts] = None, work=None, out=None, want_lambda: bool = False):
+        """In place on x.  Returns dict(objective, inform, iters, nfev[, clambda])."""
+        import torch
+        sp = self.spec
+        assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+        assert lower.is_contiguous() and upper.is_contiguous()
+        batch = x.shape[0]
+        dev = x.device
+        o = opts if opts is not None else default_opts()
+        need = self.workspace_bytes(batch, o)
+        if work is None:
+            work = torch.empty(need, dtype=torch.uint8, device=dev)
+        assert work.numel() * work.element_size() >= need
+        if out is None:
+            out = dict(objective=torch.empty(batch, dtype=torch.float64, device=dev),
+                       inform=torch.empty(batch, dtype=torch.int32, device=dev),
+                       iters=torch.empty(batch, dtype=torch.int32, device=dev),
+                       nfev=torch.empty(batch, dtype=torch.int32, device=dev))
+            if want_lambda:
+                out["clambda"] = torch.empty((batch, sp.nC + sp.nclin + sp.ncnln), dtype=torch.float64, device=dev)
+        _check(lib().ntg_batch_solve(self.h, batch, _ptr(lower), _ptr(upper), _ptr(x), C.byref(o),
+                                     _ptr(out["objective"]), _ptr(out["inform"]), _ptr(out["iters"]), _ptr(out["nfev"]),
+                                     _ptr(out.get("clambda")), _ptr(work), work.numel() * work.element_size(), self._stream()))
+        return out
+
+
+def basis_batch(knots, bps, order: int, mult: int, maxderiv: int):
+    """bsplvd at every collocation point of many grids: knots [G, l+1], bps [G, P] (torch, device)."""
+    import torch
+    G, l1 = knots.shape
+    P = bps.shape[1]
+    blk = torch.empty((G, P, order, maxderiv), dtype=torch.float64, device=knots.device)
+    off = torch.empty((G, P), dtype=torch.int32, device=knots.device)
+    _check(lib().ntg_basis_batch(G, l1 - 1, order, mult, maxderiv, P, _ptr(knots), _ptr(bps), _ptr(blk), _ptr(off),
+                                 C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return blk, off

@@ -1,0 +1,958 @@
+// kernels.hip -- hand-written HIP kernels for gfx950 (MI355X) and their launchers.
+//
+//   basis_kernel    PGS knots/interv/bsplvb/bsplvd at every collocation point
+//                   (reference call sites colloc.c:92-111; the Fortran is absent from the
+//                   reference tree, algorithm from de Boor's PGS)
+//   linrows_kernel  banded rows of the linear-constraint matrix (constraints.c:198-261)
+//   bounds_kernel   bounds() (constraints.c:5-33)
+//   eval_kernel     NPfunobj + NPfuncon (ntg.c:274-371): Z = M C (colloc.c:318-367), cost and
+//                   constraint functors, banded gradient / Jacobian assembly (cost.c:38-139,
+//                   constraints.c:88-195, colloc.c:243-316), trapezoid quadrature (integrator.c)
+//   sqp_kernel      the npsol_() call of ntg.c:250: one workgroup owns one problem for the
+//                   whole solve (feasibility, projected inverse-BFGS, line search)
+//
+// Mapping to CDNA4: one workgroup per problem; breakpoints (then coefficients) across the
+// lanes; basis tables, knots/breakpoints and the coefficient vector staged in LDS; the only
+// HBM traffic inside a solve is the quasi-Newton history (coalesced, 8 B/lane); reductions are
+// 64-lane wavefront shuffles + one LDS hop across the waves of the workgroup.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "ntg_dev.hpp"
+#include "families.hpp"
+#include "linesearch.hpp"
+
+// ------------------------------------------------------------------------------------------
+// reductions: sum K values over the workgroup, result broadcast to every lane
+// ------------------------------------------------------------------------------------------
+template <int NT, int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *red)
+{
+	constexpr int NW = NT / 64;
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+#pragma unroll
+		for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
+	}
+	if (NW == 1) {
+#pragma unroll
+		for (int k = 0; k < K; k++) v[k] = __shfl(v[k], 0, 64);
+		return;
+	}
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	__syncthreads(); // red[] may still be read by the previous call
+	if (lane == 0) {
+#pragma unroll
+		for (int k = 0; k < K; k++) red[k * NW + wave] = v[k];
+	}
+	__syncthreads();
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		double s = red[k * NW];
+#pragma unroll
+		for (int w = 1; w < NW; w++) s += red[k * NW + w];
+		v[k] = s;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// PGS on the device.  The augmented knot vector is never materialised: t(idx) is read through
+// the break sequence (knots(): first/last break k times, interior breaks k-m times).
+// ------------------------------------------------------------------------------------------
+struct AugKnots {
+	const double *brk; int l, k, m;
+	__device__ __forceinline__ double operator()(int idx1) const // 1-based like the Fortran
+	{
+		const int idx = idx1 - 1, n = l * (k - m) + m;
+		if (idx < k) return brk[0];
+		if (idx >= n) return brk[l];
+		return brk[1 + (idx - k) / (k - m)];
+	}
+};
+
+// interv on the break sequence (2nd-edition rule at the right end), 1-based interval index
+__device__ __forceinline__ int interv_breaks(const double *brk, int l, double x)
+{
+	const int lxt = l + 1;
+	if (x < brk[0]) return 1;
+	if (x >= brk[lxt - 1]) {
+		for (int i = lxt - 1; i >= 1; i--)
+			if (brk[i - 1] < brk[lxt - 1]) return i;
+		return 1;
+	}
+	int lo = 1, hi = lxt;
+	while (hi - lo > 1) {
+		const int mid = (lo + hi) >> 1;
+		if (x >= brk[mid - 1]) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+// bsplvb/bsplvd (PGS).  db is [nderiv][k] (m-major) == Fortran dbiatx(k,nderiv) column-major.
+__device__ void bsplvd_dev(const AugKnots &t, int k, double x, int left, int nderiv, double *db)
+{
+	double a[NTG_MAX_ORDER * NTG_MAX_ORDER];
+	double deltal[NTG_MAX_ORDER], deltar[NTG_MAX_ORDER];
+	int j = 1;
+	const int mhigh = max(min(nderiv, k), 1), kp1 = k + 1;
+#define DB(r, c) db[((c) - 1) * k + ((r) - 1)]
+#define A_(r, c) a[((c) - 1) * k + ((r) - 1)]
+	auto raise = [&](int jhigh, double *biatx) {
+		while (j < jhigh) {
+			const int jp1 = j + 1;
+			deltar[j - 1] = t(left + j) - x;
+			deltal[j - 1] = x - t(left + 1 - j);
+			double saved = 0.0;
+			for (int i = 1; i <= j; i++) {
+				const double term = biatx[i - 1] / (deltar[i - 1] + deltal[jp1 - i - 1]);
+				biatx[i - 1] = saved + deltar[i - 1] * term;
+				saved = deltal[jp1 - i - 1] * term;
+			}
+			biatx[jp1 - 1] = saved;
+			j = jp1;
+		}
+	};
+	db[0] = 1.0;
+	raise(kp1 - mhigh, db);
+	if (mhigh == 1) return;
+	int ideriv = mhigh;
+	for (int m = 2; m <= mhigh; m++) {
+		int jp1mid = 1;
+		for (int jj = ideriv; jj <= k; jj++) { DB(jj, ideriv) = DB(jp1mid, 1); jp1mid++; }
+		ideriv--;
+		raise(kp1 - ideriv, db);
+	}
+	int jlow = 1;
+	for (int i = 1; i <= k; i++) {
+		for (int jj = jlow; jj <= k; jj++) A_(jj, i) = 0.0;
+		jlow = i;
+		A_(i, i) = 1.0;
+	}
+	for (int m = 2; m <= mhigh; m++) {
+		const int kp1mm = kp1 - m;
+		const double fkp1mm = (double)kp1mm;
+		int il = left, i = k;
+		for (int ld = 1; ld <= kp1mm; ld++) {
+			const double factor = fkp1mm / (t(il + kp1mm) - t(il));
+			for (int jj = 1; jj <= i; jj++) A_(i, jj) = (A_(i, jj) - A_(i - 1, jj)) * factor;
+			il--; i--;
+		}
+		for (i = 1; i <= k; i++) {
+			double sum = 0.0;
+			const int jl = i > m ? i : m;
+			for (int jj = jl; jj <= k; jj++) sum = A_(jj, i) * DB(jj, m) + sum;
+			DB(i, m) = sum;
+		}
+	}
+#undef DB
+#undef A_
+}
+
+// one thread per (grid, breakpoint); the grid's break sequence is staged in LDS
+__global__ void basis_kernel(int ngrids, int l, int k, int m, int d, int P,
+                             const double *__restrict__ knots, const double *__restrict__ bps,
+                             long long knots_stride, long long bps_stride,
+                             double *__restrict__ blk, int *__restrict__ off)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	double *sbrk = reinterpret_cast<double *>(smem_raw);
+	const int g = blockIdx.y;
+	if (g >= ngrids) return;
+	for (int i = threadIdx.x; i <= l; i += blockDim.x) sbrk[i] = knots[g * knots_stride + i];
+	__syncthreads();
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= P) return;
+	const double x = bps[g * bps_stride + i];
+	const int ivl = interv_breaks(sbrk, l, x);        // colloc.c:107 on the un-augmented knots
+	const int left = k + (ivl - 1) * (k - m);         // == interv_ on the augmented knots (colloc.c:98)
+	AugKnots t{sbrk, l, k, m};
+	double db[NTG_MAX_ORDER * NTG_MAX_ORDER];
+	bsplvd_dev(t, k, x, left, d, db);
+	double *o = blk + ((size_t)g * P + i) * k * d;
+	for (int q = 0; q < k; q++)
+		for (int r = 0; r < d; r++) o[q * d + r] = db[r * k + q];   // FTranspose (colloc.c:100-101)
+	off[(size_t)g * P + i] = (ivl - 1) * (k - m);                   // colloc.c:108
+}
+
+// ------------------------------------------------------------------------------------------
+// linear-constraint rows (constraints.c:198-261 through colloc.c:243-316, band entries only)
+// row order [lic; ltc constraint-major x breakpoint; lfc]; one thread per (row, band column)
+// ------------------------------------------------------------------------------------------
+__global__ void linrows_kernel(NtgDims D, NtgTables T, const double *__restrict__ lic,
+                               const double *__restrict__ ltc, const double *__restrict__ lfc,
+                               double *__restrict__ aband, int *__restrict__ rbp)
+{
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= D.nclin * D.sumk) return;
+	const int r = idx / D.sumk, kc = idx % D.sumk;
+	int o = 0;
+	while (o + 1 < D.nout && D.koff[o + 1] <= kc) o++;
+	const int q = kc - D.koff[o];
+	const double *row; int bp;
+	if (r < D.nlic) { row = lic + (size_t)r * D.nz; bp = 0; }
+	else if (r < D.nlic + D.nltc * D.P) { const int rr = r - D.nlic; row = ltc + (size_t)(rr / D.P) * D.nz; bp = rr % D.P; }
+	else { row = lfc + (size_t)(r - D.nlic - D.nltc * D.P) * D.nz; bp = D.P - 1; }
+	const int c = D.cls[o], k = D.order[o], d = D.d[o];
+	const double *b = T.blk + D.cls_blk[c] + ((size_t)bp * k + q) * d;
+	double acc = 0.0;
+	for (int l = 0; l < d; l++) acc += row[D.iz[o] + l] * b[l];
+	aband[idx] = acc;
+	if (kc == 0) rbp[r] = bp;
+}
+
+// bounds(): constraints.c:5-33
+__global__ void bounds_kernel(NtgDims D, int batch, const double *__restrict__ lower,
+                              const double *__restrict__ upper, double *__restrict__ bl,
+                              double *__restrict__ bu, double big)
+{
+	const int ntot = D.nC + D.nclin + D.ncnln;
+	const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (long long)batch * ntot) return;
+	const int b = idx / ntot, e = idx % ntot;
+	double lo, up;
+	if (e < D.nC) { lo = -big; up = big; }
+	else {
+		int r = e - D.nC, s;
+		if (r < D.nlic) s = r;
+		else if ((r -= D.nlic) < D.nltc * D.P) s = D.nlic + r / D.P;
+		else if ((r -= D.nltc * D.P) < D.nlfc) s = D.nlic + D.nltc + r;
+		else if ((r -= D.nlfc) < D.nnlic) s = D.nlic + D.nltc + D.nlfc + r;
+		else if ((r -= D.nnlic) < D.nnltc * D.P) s = D.nlic + D.nltc + D.nlfc + D.nnlic + r / D.P;
+		else { r -= D.nnltc * D.P; s = D.nlic + D.nltc + D.nlfc + D.nnlic + D.nnltc + r; }
+		lo = lower[(size_t)b * D.nbounds + s]; up = upper[(size_t)b * D.nbounds + s];
+	}
+	bl[idx] = lo; bu[idx] = up;
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS carve-up shared by eval_kernel and sqp_kernel
+// ------------------------------------------------------------------------------------------
+struct Smem {
+	double *blk; int *off; double *bps; int *ivl_lo, *ivl_hi;
+	double *x, *dfz, *fvals, *red, *dfi, *dff, *vecs, *lam, *rho, *c2;
+	__device__ __forceinline__ Smem(char *base, const SmemLayout &L)
+	{
+		blk = (double *)(base + L.blk); off = (int *)(base + L.off); bps = (double *)(base + L.bps);
+		ivl_lo = (int *)(base + L.ivl_lo); ivl_hi = (int *)(base + L.ivl_hi);
+		x = (double *)(base + L.x); dfz = (double *)(base + L.dfz); fvals = (double *)(base + L.fvals);
+		red = (double *)(base + L.red); dfi = (double *)(base + L.dfi); dff = (double *)(base + L.dff);
+		vecs = (double *)(base + L.vecs); lam = (double *)(base + L.lam); rho = (double *)(base + L.rho);
+		c2 = (double *)(base + L.c2);
+	}
+};
+
+template <int NT>
+__device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &T, const Smem &S)
+{
+	for (int i = threadIdx.x; i < D.blk_total; i += NT) S.blk[i] = T.blk[i];
+	for (int i = threadIdx.x; i < D.nclass * D.P; i += NT) S.off[i] = T.off[i];
+	for (int i = threadIdx.x; i < D.P; i += NT) S.bps[i] = T.bps[i];
+	for (int i = threadIdx.x; i < D.ivl_total; i += NT) { S.ivl_lo[i] = T.ivl_lo[i]; S.ivl_hi[i] = T.ivl_hi[i]; }
+}
+
+// Z = M C at one breakpoint for the declared active variables (colloc.c:318-326,344-367);
+// entries that are not active stay 0 like the reference's calloc'd GZ (ntg.c:119).
+template <int NOUT>
+__device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const double *sx, int bp,
+                                          u64 mask, double *z)
+{
+	const int nout = NOUT > 0 ? NOUT : D.nout;
+#pragma unroll
+	for (int o = 0; o < nout; o++) {
+		const int k = D.order[o], c = D.cls[o];
+		const int d = NOUT > 0 ? 3 : D.d[o], iz = NOUT > 0 ? 3 * o : D.iz[o];
+		const double *b = S.blk + D.cls_blk[c] + (size_t)bp * k * d;
+		const double *cx = sx + D.iC[o] + S.off[c * D.P + bp];
+#pragma unroll
+		for (int r = 0; r < (NOUT > 0 ? 3 : NTG_MAX_ORDER); r++) {
+			if (r >= d) break;
+			double acc = 0.0;
+			if ((mask >> (iz + r)) & 1ull)
+				for (int q = 0; q < k; q++) acc += b[q * d + r] * cx[q];
+			z[iz + r] = acc;
+		}
+	}
+}
+
+// one band entry of M' v at a breakpoint: sum_r v[iz+r] * block[q][r]
+template <int NOUT>
+__device__ __forceinline__ double band_dot(const double *b, int d, const double *v)
+{
+	double acc = 0.0;
+	for (int r = 0; r < d; r++) acc += v[r] * b[r];
+	return acc;
+}
+
+// per-breakpoint cost functor pass: Z = M C, then ucf/icf/fcf -> fvals, dfz, dfi, dff in LDS
+template <int FAM, int NOUT, int NT>
+__device__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
+{
+	constexpr int NZ = NOUT > 0 ? 3 * NOUT : NTG_MAX_NZ;
+	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
+	const int tid = threadIdx.x;
+	using Fam = Family<FAM>;
+	__syncthreads(); // sx complete, previous users of dfz/fvals done
+	if (D.nucf) {
+		for (int i = tid; i < P; i += NT) {                       // cost.c:103-109
+			double z[NZ], df[NZ], f;
+			compute_z<NOUT>(D, S, sx, i, D.tcost_mask, z);
+			Fam::ucf(nout, i, z, f, df);
+			S.fvals[i] = f;
+#pragma unroll
+			for (int v = 0; v < NZ; v++) { if (v < nz) S.dfz[v * P + i] = df[v]; }
+		}
+	}
+	if (D.nicf && tid == 0) {                                     // cost.c:4-36
+		double z[NZ], df[NZ], f;
+		compute_z<NOUT>(D, S, sx, 0, D.icost_mask, z);
+		Fam::icf(nout, z, f, df);
+		for (int v = 0; v < nz; v++) S.dfi[v] = df[v];
+		S.dfi[nz] = f;
+	}
+	if (D.nfcf && tid == (NT > 64 ? 64 : 0)) {                    // cost.c:141-174
+		double z[NZ], df[NZ], f;
+		compute_z<NOUT>(D, S, sx, P - 1, D.fcost_mask, z);
+		Fam::fcf(nout, z, f, df);
+		for (int v = 0; v < nz; v++) S.dff[v] = df[v];
+		S.dff[nz] = f;
+	}
+}
+
+// quadrature + banded gradient assembly from the per-breakpoint values in LDS (fvals, dfz,
+// dfi, dff); shared by the device-functor path and the host-callback path of ntg()
+template <int NOUT, int NT>
+__device__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2)
+{
+	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
+	const int tid = threadIdx.x;
+	__syncthreads();
+	// trapezoid of the running cost (integrator.c:21-24); per-interval terms across the lanes,
+	// wavefront-shuffle reduction
+	double acc[2] = {0.0, 0.0};
+	if (D.nucf)
+		for (int i = tid; i < P - 1; i += NT)
+			acc[0] += (S.bps[i + 1] - S.bps[i]) * (S.fvals[i + 1] + S.fvals[i]) / 2;
+	// gradient: one coefficient per lane, band gather + sequential trapezoid in the reference's
+	// order (cost.c:117-134, integrator.c:44-48); structural zeros are skipped
+	for (int c = tid; c < D.nC; c += NT) {
+		int o = 0;
+		while (o + 1 < nout && D.iC[o + 1] <= c) o++;
+		const int cl = c - D.iC[o], k = D.order[o], m = D.mult[o], km = k - m, cc = D.cls[o];
+		const int d = NOUT > 0 ? 3 : D.d[o], iz = NOUT > 0 ? 3 * o : D.iz[o];
+		const double *cb = S.blk + D.cls_blk[cc];
+		const int *coff = S.off + cc * P;
+		double dI = 0.0, dIn = 0.0, dF = 0.0;
+		if (D.nucf) {
+			const int jlo = (cl - k + 1 <= 0) ? 0 : (cl - k + 1 + km - 1) / km;
+			const int jhi = min(D.ninterv[o] - 1, cl / km);
+			if (jlo <= jhi) {
+				const int ifirst = S.ivl_lo[D.cls_ivl[cc] + jlo], ilast = S.ivl_hi[D.cls_ivl[cc] + jhi];
+				if (ifirst <= ilast) {
+					const int ia = max(ifirst - 1, 0), ib = min(ilast, P - 2);
+					auto G = [&](int i) -> double {
+						if (i < ifirst || i > ilast) return 0.0;
+						const double *b = cb + ((size_t)i * k + (cl - coff[i])) * d;
+						double a2 = 0.0;
+						for (int r = 0; r < d; r++) a2 += S.dfz[(iz + r) * P + i] * b[r];
+						return a2;
+					};
+					double gprev = G(ia);
+					for (int i = ia; i <= ib; i++) {
+						const double gnext = G(i + 1);
+						dIn += (S.bps[i + 1] - S.bps[i]) * (gnext + gprev) / 2;
+						gprev = gnext;
+					}
+				}
+			}
+		}
+		if (D.nicf && cl < k) {                                   // colloc.c:243-260 (block 0, no offset)
+			const double *b = cb + (size_t)cl * d;
+			for (int r = 0; r < d; r++) dI += S.dfi[iz + r] * b[r];
+		}
+		if (D.nfcf) {                                             // colloc.c:287-316
+			const int ol = coff[P - 1];
+			if (cl >= ol && cl < ol + k) {
+				const double *b = cb + ((size_t)(P - 1) * k + (cl - ol)) * d;
+				for (int r = 0; r < d; r++) dF += S.dff[iz + r] * b[r];
+			}
+		}
+		const double g = dI + dIn + dF;                           // Vector3Add (matrix.c:177)
+		sg[c] = g;
+		acc[1] += g * g;
+	}
+	block_sum<NT, 2>(acc, S.red);
+	const double I = D.nicf ? S.dfi[nz] : 0.0, Ff = D.nfcf ? S.dff[nz] : 0.0;
+	*gnorm2 = acc[1];
+	return I + acc[0] + Ff;                                       // ntg.c:328
+}
+
+// NPfunobj (ntg.c:274-335): F and the full gradient into LDS vector sg.  Returns F; *gnorm2
+// receives |g|^2.  Every lane of the workgroup must call it (it contains barriers).
+template <int FAM, int NOUT, int NT>
+__device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2)
+{
+	cost_phase1<FAM, NOUT, NT>(D, S, sx);
+	return cost_phase2<NOUT, NT>(D, S, sg, gnorm2);
+}
+
+// NPfuncon (ntg.c:337-371, constraints.c:36-195): residuals and banded Jacobian rows straight
+// to HBM.  Row order [initial; trajectory constraint-major x breakpoint; final].
+template <int FAM, int NOUT, int NT>
+__device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *sx, int mode,
+                                 double *c_out, double *jband, double *cjac)
+{
+	using Fam = Family<FAM>;
+	constexpr int NZ = NOUT > 0 ? 3 * NOUT : NTG_MAX_NZ;
+	constexpr int NI = Fam::NNLIC > 0 ? Fam::NNLIC : 1, NTc = Fam::NNLTC > 0 ? Fam::NNLTC : 1, NF = Fam::NNLFC > 0 ? Fam::NNLFC : 1;
+	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz, tid = threadIdx.x;
+	auto emit_row = [&](int row, int bp, const double *dcrow) {
+		for (int o = 0; o < nout; o++) {
+			const int k = D.order[o], cc = D.cls[o], d = D.d[o];
+			const double *b = S.blk + D.cls_blk[cc] + (size_t)bp * k * d;
+			const int col0 = D.iC[o] + S.off[cc * P + bp];
+			for (int q = 0; q < k; q++) {
+				double a = 0.0;
+				for (int r = 0; r < d; r++) a += dcrow[D.iz[o] + r] * b[q * d + r];
+				if (jband) jband[(size_t)row * D.sumk + D.koff[o] + q] = a;
+				if (cjac) cjac[(size_t)(col0 + q) * D.ncnln + row] = a;
+			}
+		}
+	};
+	if (Fam::NNLIC > 0 && D.nnlic && tid == 0) {
+		double z[NZ], c[NI], dc[NI * NZ];
+		compute_z<NOUT>(D, S, sx, 0, D.icon_mask, z);
+		Fam::nlicf(nout, z, c, dc);
+		for (int j = 0; j < D.nnlic; j++) {
+			if (c_out && mode != 1) c_out[j] = c[j];
+			if (mode != 0) emit_row(j, 0, dc + j * nz);
+		}
+	}
+	if (Fam::NNLTC > 0 && D.nnltc) {
+		for (int i = tid; i < P; i += NT) {
+			double z[NZ], c[NTc], dc[NTc * NZ];
+			compute_z<NOUT>(D, S, sx, i, D.tcon_mask, z);
+			Fam::nltcf(nout, i, z, c, dc);
+			for (int j = 0; j < D.nnltc; j++) {
+				const int row = D.nnlic + j * P + i;              // constraints.c:139,153
+				if (c_out && mode != 1) c_out[row] = c[j];
+				if (mode != 0) emit_row(row, i, dc + j * nz);
+			}
+		}
+	}
+	if (Fam::NNLFC > 0 && D.nnlfc && tid == (NT > 64 ? 64 : 0)) {
+		double z[NZ], c[NF], dc[NF * NZ];
+		compute_z<NOUT>(D, S, sx, P - 1, D.fcon_mask, z);
+		Fam::nlfcf(nout, z, c, dc);
+		for (int j = 0; j < D.nnlfc; j++) {
+			const int row = D.nnlic + D.nnltc * P + j;
+			if (c_out && mode != 1) c_out[row] = c[j];
+			if (mode != 0) emit_row(row, P - 1, dc + j * nz);
+		}
+	}
+}
+
+// Persistent workgroups stride over the batch; tables are staged once per workgroup.
+template <int FAM, int NOUT, int NT>
+__global__ void __launch_bounds__(NT)
+eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const double *__restrict__ x,
+            double *__restrict__ f, double *__restrict__ g, double *__restrict__ c,
+            double *__restrict__ jband, double *__restrict__ cjac)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	Smem S(smem_raw, L);
+	stage_tables<NT>(D, T, S);
+	double *sg = S.vecs;
+	for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+		__syncthreads();
+		for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
+		double gn2;
+		const double F = eval_cost<FAM, NOUT, NT>(D, S, S.x, sg, &gn2);
+		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
+		if (g && mode != 0)
+			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
+		if (D.ncnln && (c || jband || cjac))
+			eval_constraints<FAM, NOUT, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
+			                                jband ? jband + (size_t)b * D.ncnln * D.sumk : nullptr,
+			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// SQP pieces
+// ------------------------------------------------------------------------------------------
+// gp = g - A'(AA')^-1 A g  (projection onto null(A)); lam receives the multipliers estimate.
+template <int NT>
+__device__ void project(const NtgDims &D, const NtgTables &T, const Smem &S, const double *sg,
+                        double *sgp, double *tmp /* LDS [2*nclin] */)
+{
+	const int m = D.nclin, tid = threadIdx.x, P = D.P;
+	__syncthreads();
+	if (m == 0) { for (int c = tid; c < D.nC; c += NT) sgp[c] = sg[c]; __syncthreads(); return; }
+	for (int r = tid; r < m; r += NT) {
+		const int bp = T.rbp[r];
+		double a = 0.0;
+		for (int o = 0; o < D.nout; o++) {
+			const double *row = T.aband + (size_t)r * D.sumk + D.koff[o];
+			const double *v = sg + D.iC[o] + S.off[D.cls[o] * P + bp];
+			for (int q = 0; q < D.order[o]; q++) a += row[q] * v[q];
+		}
+		tmp[r] = a;
+	}
+	__syncthreads();
+	for (int r = tid; r < m; r += NT) {
+		double a = 0.0;
+		for (int j = 0; j < m; j++) a += T.sinv[(size_t)r * m + j] * tmp[j];
+		S.lam[r] = a;
+	}
+	__syncthreads();
+	for (int c = tid; c < D.nC; c += NT) {
+		int o = 0;
+		while (o + 1 < D.nout && D.iC[o + 1] <= c) o++;
+		const int cl = c - D.iC[o], k = D.order[o];
+		const int *coff = S.off + D.cls[o] * P;
+		double s = 0.0;
+		for (int r = 0; r < m; r++) {
+			const int ofr = coff[T.rbp[r]];
+			if (cl >= ofr && cl < ofr + k) s += T.aband[(size_t)r * D.sumk + D.koff[o] + cl - ofr] * S.lam[r];
+		}
+		sgp[c] = sg[c] - s;
+	}
+	__syncthreads();
+}
+
+// out = W0 v : identity on null(A) (cold start) or the collocation preconditioner
+template <int NT>
+__device__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out)
+{
+	__syncthreads();
+	if (hessian == 1 && T.n0) {
+		for (int c = threadIdx.x; c < D.nC; c += NT) {
+			double a = 0.0;
+			for (int j = 0; j < D.nC; j++) a += T.n0[(size_t)j * D.nC + c] * v[j]; // symmetric: coalesced
+			out[c] = a;
+		}
+	} else {
+		for (int c = threadIdx.x; c < D.nC; c += NT) out[c] = v[c];
+	}
+	__syncthreads();
+}
+
+// t += (sum of the stored rank-2 BFGS terms) v.  Pairs are streamed from HBM/L2, 4 at a time:
+// 8 partial dots per lane, one workgroup reduction, then the axpys.
+template <int NT>
+__device__ void apply_history(const NtgDims &D, const Smem &S, const double *hist, int npairs,
+                              const double *v, double *t)
+{
+	const int n = D.nC, tid = threadIdx.x;
+	for (int base = 0; base < npairs; base += 4) {
+		const int cnt = min(4, npairs - base);
+		double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int c = tid; c < n; c += NT) {
+			const double vv = v[c];
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				if (g < cnt) {
+					const double *h = hist + (size_t)(base + g) * 2 * n;
+					acc[2 * g] += h[c] * vv;
+					acc[2 * g + 1] += h[n + c] * vv;
+				}
+			}
+		}
+		block_sum<NT, 8>(acc, S.red);
+		for (int c = tid; c < n; c += NT) {
+			double tt = t[c];
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				if (g < cnt) {
+					const double *h = hist + (size_t)(base + g) * 2 * n;
+					const double s = h[c], u = h[n + c], rho = S.rho[base + g], c2 = S.c2[base + g];
+					tt += -rho * (s * acc[2 * g + 1] + u * acc[2 * g]) + c2 * s * acc[2 * g];
+				}
+			}
+			t[c] = tt;
+		}
+	}
+	__syncthreads();
+}
+
+// One workgroup solves one problem from start to finish (ntg.c:250: the npsol_ call).
+template <int FAM, int NOUT, int NT>
+__global__ void __launch_bounds__(NT)
+sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
+           const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
+           double *__restrict__ objective, int *__restrict__ inform_out, int *__restrict__ iters_out,
+           int *__restrict__ nfev_out, double *__restrict__ clambda, double *__restrict__ hist_all)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	Smem S(smem_raw, L);
+	const int b = blockIdx.x, tid = threadIdx.x, n = D.nC, m = D.nclin, P = D.P;
+	if (b >= batch) return;
+	const int npad = (n + 1) & ~1;
+	double *sx = S.x, *sxt = S.vecs, *sgp = S.vecs + npad, *sgpt = S.vecs + 2 * npad, *sd = S.vecs + 3 * npad,
+	       *st = S.vecs + 4 * npad, *sg = S.vecs + 5 * npad, *tmp = S.vecs + 6 * npad;
+	double *hist = hist_all + (size_t)b * sp.memcap * 2 * n;
+	stage_tables<NT>(D, T, S);
+	for (int i = tid; i < n; i += NT) sx[i] = xio[(size_t)b * n + i];
+	__syncthreads();
+
+	int inform = 4, iter = 0, nfev = 0, npairs = 0;
+	// ---- scope check (uniform): linear equalities only ----
+	{
+		double bad[1] = {0.0};
+		for (int s = tid; s < D.nbounds; s += NT)
+			if (lower[(size_t)b * D.nbounds + s] != upper[(size_t)b * D.nbounds + s]) bad[0] += 1.0;
+		block_sum<NT, 1>(bad, S.red);
+		if (bad[0] != 0.0 || D.ncnln > 0) inform = 9;
+	}
+	double F = 0.0, gn2 = 0.0, alpha = 0.0, pnorm = 0.0;
+	if (inform != 9) {
+		// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
+		if (m > 0) {
+			for (int r = tid; r < m; r += NT) {
+				const int bp = T.rbp[r];
+				int s;
+				if (r < D.nlic) s = r;
+				else if (r < D.nlic + D.nltc * P) s = D.nlic + (r - D.nlic) / P;
+				else s = D.nlic + D.nltc + (r - D.nlic - D.nltc * P);
+				double a = 0.0;
+				for (int o = 0; o < D.nout; o++) {
+					const double *row = T.aband + (size_t)r * D.sumk + D.koff[o];
+					const double *v = sx + D.iC[o] + S.off[D.cls[o] * P + bp];
+					for (int q = 0; q < D.order[o]; q++) a += row[q] * v[q];
+				}
+				tmp[r] = lower[(size_t)b * D.nbounds + s] - a;
+			}
+			__syncthreads();
+			for (int r = tid; r < m; r += NT) {
+				double a = 0.0;
+				for (int j = 0; j < m; j++) a += T.sinv[(size_t)r * m + j] * tmp[j];
+				S.lam[r] = a;
+			}
+			__syncthreads();
+			for (int c = tid; c < n; c += NT) {
+				int o = 0;
+				while (o + 1 < D.nout && D.iC[o + 1] <= c) o++;
+				const int cl = c - D.iC[o], k = D.order[o];
+				const int *coff = S.off + D.cls[o] * P;
+				double s = 0.0;
+				for (int r = 0; r < m; r++) {
+					const int ofr = coff[T.rbp[r]];
+					if (cl >= ofr && cl < ofr + k) s += T.aband[(size_t)r * D.sumk + D.koff[o] + cl - ofr] * S.lam[r];
+				}
+				sx[c] += s;
+			}
+			__syncthreads();
+		}
+		F = eval_cost<FAM, NOUT, NT>(D, S, sx, sg, &gn2); nfev++;
+		project<NT>(D, T, S, sg, sgp, tmp);
+		apply_w0<NT>(D, T, sp.hessian, sgp, sd);
+
+		LineSearch ls;
+		for (iter = 0; iter < sp.itlim; iter++) {
+			double r4[4] = {0, 0, 0, 0};
+			for (int c = tid; c < n; c += NT) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; }
+			block_sum<NT, 4>(r4, S.red);
+			double dphi0 = -r4[0];
+			pnorm = sqrt(r4[1]);
+			const double xnorm = sqrt(r4[2]), gpnorm = sqrt(r4[3]), gnorm = sqrt(gn2);
+			const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), gnorm));
+			if (pnorm == 0.0 || !(dphi0 < 0.0)) {
+				if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
+					npairs = 0;
+					apply_w0<NT>(D, T, sp.hessian, sgp, sd);
+					double r2[2] = {0, 0};
+					for (int c = tid; c < n; c += NT) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; }
+					block_sum<NT, 2>(r2, S.red);
+					dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
+				}
+				if (pnorm == 0.0 || !(dphi0 < 0.0)) { inform = (gpnorm <= tolg) ? 0 : 6; break; }
+			}
+			if (!sp.fixed_iters && gpnorm <= 1e-3 * tolg) { inform = 0; break; }
+			const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
+			ls.init(F, dphi0, amax < 1.0 ? amax : 1.0, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
+			double Fn = 0.0, gn2n = 0.0;
+			int rc;
+			for (;;) {
+				const double a = ls.a;
+				for (int c = tid; c < n; c += NT) sxt[c] = sx[c] + a * (-sd[c]);
+				Fn = eval_cost<FAM, NOUT, NT>(D, S, sxt, sg, &gn2n); nfev++;
+				project<NT>(D, T, S, sg, sgpt, tmp);
+				double dd[1] = {0.0};
+				for (int c = tid; c < n; c += NT) dd[0] += sgpt[c] * (-sd[c]);
+				block_sum<NT, 1>(dd, S.red);
+				rc = ls.step(Fn, dd[0]);
+				if (rc == 1 || rc == -1) break;
+				if (rc == 2) {
+					const double a2 = ls.a;
+					for (int c = tid; c < n; c += NT) sxt[c] = sx[c] + a2 * (-sd[c]);
+					Fn = eval_cost<FAM, NOUT, NT>(D, S, sxt, sg, &gn2n); nfev++;
+					project<NT>(D, T, S, sg, sgpt, tmp);
+					rc = 1;
+					break;
+				}
+			}
+			if (rc != 1) { inform = (gpnorm <= tolg) ? 0 : 6; break; }
+			alpha = ls.a;
+			// accept: x <- xt ; t = W gp+ ; u = t - d ; BFGS pair (s, u) to HBM
+			for (int c = tid; c < n; c += NT) sg[c] = alpha * (-sd[c]);      // the step s (sg is free here)
+			if (npairs == sp.memcap) { npairs = 0; apply_w0<NT>(D, T, sp.hessian, sgp, sd); } // memory full: restart
+			apply_w0<NT>(D, T, sp.hessian, sgpt, st);
+			apply_history<NT>(D, S, hist, npairs, sgpt, st);
+			double r6[6] = {0, 0, 0, 0, 0, 0};
+			for (int c = tid; c < n; c += NT) {
+				const double s = sg[c], y = sgpt[c] - sgp[c], u = st[c] - sd[c], gpn = sgpt[c];
+				r6[0] += s * y; r6[1] += y * u; r6[2] += s * gpn; r6[3] += u * gpn; r6[4] += s * s; r6[5] += y * y;
+			}
+			block_sum<NT, 6>(r6, S.red);
+			const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
+			const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
+			double r2[2] = {0, 0};
+			for (int c = tid; c < n; c += NT) {
+				const double s = sg[c], u = st[c] - sd[c];
+				if (upd) { hist[(size_t)npairs * 2 * n + c] = s; hist[(size_t)npairs * 2 * n + n + c] = u; }
+				const double dn = upd ? st[c] - rho * (s * r6[3] + u * r6[2]) + c2 * s * r6[2] : st[c];
+				sx[c] = sxt[c];
+				sgp[c] = sgpt[c];
+				sd[c] = dn;
+				r2[0] += sxt[c] * sxt[c]; r2[1] += sgpt[c] * sgpt[c];
+			}
+			if (upd) {
+				if (tid == 0) { S.rho[npairs] = rho; S.c2[npairs] = c2; }
+				npairs++;
+			}
+			block_sum<NT, 2>(r2, S.red);   // also orders the hist/rho writes before their next use
+			F = Fn; gn2 = gn2n;
+			if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r2[0])) &&
+			    sqrt(r2[1]) <= sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inform = 0; iter++; break; }
+		}
+	}
+	__syncthreads();
+	for (int i = tid; i < n; i += NT) xio[(size_t)b * n + i] = sx[i];
+	if (clambda) {
+		const int ntot = n + m + D.ncnln;
+		for (int i = tid; i < ntot; i += NT)
+			clambda[(size_t)b * ntot + i] = (inform != 9 && i >= n && i < n + m) ? S.lam[i - n] : 0.0;
+	}
+	if (tid == 0) {
+		if (objective) objective[b] = F;
+		if (inform_out) inform_out[b] = inform;
+		if (iters_out) iters_out[b] = iter;
+		if (nfev_out) nfev_out[b] = nfev;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// host-callback path of the ntg() drop-in: the user's C function pointers run on the host
+// between two kernels -- updateZ (colloc.c:344-367) and the banded assembly + quadrature.
+// ------------------------------------------------------------------------------------------
+// Z in the reference layout Z[iZ[o] + d_o*bp + r], iZ[o] = iz[o]*P (colloc.c:328-331); only the
+// declared active variables are written (the buffer persists like GZ, ntg.c:119)
+template <int NT>
+__global__ void __launch_bounds__(NT)
+hostz_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__ x, u64 maskI, u64 maskT,
+             u64 maskF, double *__restrict__ Z)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	Smem S(smem_raw, L);
+	stage_tables<NT>(D, T, S);
+	for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[i];
+	__syncthreads();
+	for (int i = threadIdx.x; i < D.P; i += NT) {
+		const u64 mask = maskT | (i == 0 ? maskI : 0ull) | (i == D.P - 1 ? maskF : 0ull);
+		if (!mask) continue;
+		double z[NTG_MAX_NZ];
+		compute_z<0>(D, S, S.x, i, mask, z);
+		for (int o = 0; o < D.nout; o++)
+			for (int r = 0; r < D.d[o]; r++)
+				if ((mask >> (D.iz[o] + r)) & 1ull) Z[(size_t)D.iz[o] * D.P + (size_t)D.d[o] * i + r] = z[D.iz[o] + r];
+	}
+}
+
+// fT [P], dfT [P][nz] = what ucf returned at each breakpoint; fdI/fdF [nz+1] = (df, f) of icf/fcf
+template <int NT>
+__global__ void __launch_bounds__(NT)
+hostcost_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__ fT,
+                const double *__restrict__ dfT, const double *__restrict__ fdI,
+                const double *__restrict__ fdF, double *__restrict__ F, double *__restrict__ g)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	Smem S(smem_raw, L);
+	stage_tables<NT>(D, T, S);
+	const int P = D.P, nz = D.nz;
+	for (int i = threadIdx.x; i < P; i += NT) S.fvals[i] = D.nucf ? fT[i] : 0.0;
+	for (int e = threadIdx.x; e < P * nz; e += NT) { const int i = e / nz, v = e % nz; S.dfz[v * P + i] = D.nucf ? dfT[e] : 0.0; }
+	for (int v = threadIdx.x; v <= nz; v += NT) { S.dfi[v] = D.nicf ? fdI[v] : 0.0; S.dff[v] = D.nfcf ? fdF[v] : 0.0; }
+	double gn2;
+	const double val = cost_phase2<0, NT>(D, S, S.vecs, &gn2);
+	if (threadIdx.x == 0) *F = val;
+	for (int i = threadIdx.x; i < D.nC; i += NT) g[i] = S.vecs[i];
+}
+
+// dc [ncnln][nz]: row r holds the user's dc[constraint][variable] for constraint row r
+// (rows: initial; trajectory constraint-major x breakpoint; final).  One lane per row.
+__global__ void hostcon_kernel(NtgDims D, NtgTables T, const double *__restrict__ dc,
+                               double *__restrict__ jband, double *__restrict__ cjac)
+{
+	const int row = blockIdx.x * blockDim.x + threadIdx.x;
+	if (row >= D.ncnln) return;
+	int bp;
+	if (row < D.nnlic) bp = 0;
+	else if (row < D.nnlic + D.nnltc * D.P) bp = (row - D.nnlic) % D.P;
+	else bp = D.P - 1;
+	const double *dcrow = dc + (size_t)row * D.nz;
+	for (int o = 0; o < D.nout; o++) {
+		const int k = D.order[o], cc = D.cls[o], d = D.d[o];
+		const double *b = T.blk + D.cls_blk[cc] + (size_t)bp * k * d;
+		const int col0 = D.iC[o] + T.off[cc * D.P + bp];
+		for (int q = 0; q < k; q++) {
+			double a = 0.0;
+			for (int r = 0; r < d; r++) a += dcrow[D.iz[o] + r] * b[q * d + r];
+			if (jband) jband[(size_t)row * D.sumk + D.koff[o] + q] = a;
+			if (cjac) cjac[(size_t)(col0 + q) * D.ncnln + row] = a;
+		}
+	}
+}
+
+hipError_t ntg_launch_hostz(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const double *x, u64 mI,
+                            u64 mT, u64 mF, double *Z, hipStream_t st)
+{
+	auto kfn = hostz_kernel<128>;
+	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+	hipLaunchKernelGGL(kfn, dim3(1), dim3(128), L.total, st, D, T, L, x, mI, mT, mF, Z);
+	return hipGetLastError();
+}
+hipError_t ntg_launch_hostcost(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const double *fT,
+                               const double *dfT, const double *fdI, const double *fdF, double *F, double *g,
+                               hipStream_t st)
+{
+	auto kfn = hostcost_kernel<128>;
+	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+	hipLaunchKernelGGL(kfn, dim3(1), dim3(128), L.total, st, D, T, L, fT, dfT, fdI, fdF, F, g);
+	return hipGetLastError();
+}
+hipError_t ntg_launch_hostcon(const NtgDims &D, const NtgTables &T, const double *dc, double *jband, double *cjac,
+                              hipStream_t st)
+{
+	if (D.ncnln == 0) return hipSuccess;
+	hipLaunchKernelGGL(hostcon_kernel, dim3((D.ncnln + 63) / 64), dim3(64), 0, st, D, T, dc, jband, cjac);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers (called from plan.cpp)
+// ------------------------------------------------------------------------------------------
+static inline int align16(int x) { return (x + 15) & ~15; }
+
+SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int memcap)
+{
+	SmemLayout L;
+	int p = 0;
+	const int npad = (D.nC + 1) & ~1;
+	L.blk = p; p = align16(p + D.blk_total * 8);
+	L.off = p; p = align16(p + D.nclass * D.P * 4);
+	L.bps = p; p = align16(p + D.P * 8);
+	L.ivl_lo = p; p = align16(p + D.ivl_total * 4);
+	L.ivl_hi = p; p = align16(p + D.ivl_total * 4);
+	L.x = p; p = align16(p + npad * 8);
+	L.dfz = p; p = align16(p + D.nz * D.P * 8);
+	L.fvals = p; p = align16(p + D.P * 8);
+	L.red = p; p = align16(p + 8 * (nthreads / 64 + 1) * 8);
+	L.dfi = p; p = align16(p + (D.nz + 1) * 8);
+	L.dff = p; p = align16(p + (D.nz + 1) * 8);
+	L.vecs = p; p = align16(p + (nvec * npad + 2 * D.nclin + 2) * 8);
+	L.lam = p; p = align16(p + (D.nclin + 1) * 8);
+	L.rho = p; p = align16(p + (memcap + 1) * 8);
+	L.c2 = p; p = align16(p + (memcap + 1) * 8);
+	L.total = p;
+	return L;
+}
+
+template <int FAM, int NOUT>
+static hipError_t launch_eval_nt(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, int grid,
+                                 int batch, int mode, const double *x, double *f, double *g, double *c,
+                                 double *jb, double *cj, hipStream_t st)
+{
+#define NTG_EV(NTV)                                                                                         \
+	{                                                                                                       \
+		auto kfn = eval_kernel<FAM, NOUT, NTV>;                                                             \
+		if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total); \
+		hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTV), L.total, st, D, T, L, batch, mode, x, f, g, c, jb, cj); \
+	}
+	if (nt == 64) NTG_EV(64) else if (nt == 128) NTG_EV(128) else NTG_EV(256)
+#undef NTG_EV
+	return hipGetLastError();
+}
+
+template <int FAM, int NOUT>
+static hipError_t launch_sqp_nt(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L,
+                                const SolveParams &sp, int batch, const double *lo, const double *up, double *x,
+                                double *obj, int *inf, int *it, int *nf, double *cl, double *hist, hipStream_t st)
+{
+#define NTG_SQ(NTV)                                                                                         \
+	{                                                                                                       \
+		auto kfn = sqp_kernel<FAM, NOUT, NTV>;                                                              \
+		if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total); \
+		hipLaunchKernelGGL(kfn, dim3(batch), dim3(NTV), L.total, st, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist); \
+	}
+	if (nt == 64) NTG_SQ(64) else if (nt == 128) NTG_SQ(128) else NTG_SQ(256)
+#undef NTG_SQ
+	return hipGetLastError();
+}
+
+// (family, nout) dispatch: compile-time nout keeps the flat flag in registers; NOUT = 0 is the
+// generic path (runtime nout, any maxderiv)
+#define NTG_DISPATCH(CALL)                                                                      \
+	const bool d3 = [&] { for (int o = 0; o < D.nout; o++) if (D.d[o] != 3) return false; return true; }(); \
+	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 2) return CALL(NTG_FAM_KINCAR, 2);          \
+	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 6) return CALL(NTG_FAM_KINCAR, 6);          \
+	if (D.family == NTG_FAM_KINCAR) return CALL(NTG_FAM_KINCAR, 0);                               \
+	if (D.family == NTG_FAM_VANDERPOL && d3 && D.nout == 1) return CALL(NTG_FAM_VANDERPOL, 1);    \
+	if (D.family == NTG_FAM_TESTFAM && d3 && D.nout == 3) return CALL(NTG_FAM_TESTFAM, 3);        \
+	if (D.family == NTG_FAM_TESTFAM) return CALL(NTG_FAM_TESTFAM, 0);                             \
+	return hipErrorInvalidValue;
+
+hipError_t ntg_launch_eval(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, int grid, int batch,
+                           int mode, const double *x, double *f, double *g, double *c, double *jb, double *cj,
+                           hipStream_t st)
+{
+#define CALL(F, N) launch_eval_nt<F, N>(nt, D, T, L, grid, batch, mode, x, f, g, c, jb, cj, st)
+	NTG_DISPATCH(CALL)
+#undef CALL
+}
+
+hipError_t ntg_launch_sqp(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp,
+                          int batch, const double *lo, const double *up, double *x, double *obj, int *inf, int *it,
+                          int *nf, double *cl, double *hist, hipStream_t st)
+{
+#define CALL(F, N) launch_sqp_nt<F, N>(nt, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist, st)
+	NTG_DISPATCH(CALL)
+#undef CALL
+}
+
+hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,
+                            long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st)
+{
+	const int nt = 64;
+	dim3 grid((P + nt - 1) / nt, ngrids);
+	hipLaunchKernelGGL(basis_kernel, grid, dim3(nt), (size_t)(l + 1) * 8, st, ngrids, l, k, m, d, P, knots, bps,
+	                   knots_stride, bps_stride, blk, off);
+	return hipGetLastError();
+}
+
+hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,
+                              const double *lfc, double *aband, int *rbp, hipStream_t st)
+{
+	const int total = D.nclin * D.sumk;
+	if (total == 0) return hipSuccess;
+	hipLaunchKernelGGL(linrows_kernel, dim3((total + 127) / 128), dim3(128), 0, st, D, T, lic, ltc, lfc, aband, rbp);
+	return hipGetLastError();
+}
+
+hipError_t ntg_launch_bounds(const NtgDims &D, int batch, const double *lo, const double *up, double *bl, double *bu,
+                             hipStream_t st)
+{
+	const long long total = (long long)batch * (D.nC + D.nclin + D.ncnln);
+	if (total == 0) return hipSuccess;
+	hipLaunchKernelGGL(bounds_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, D, batch, lo, up, bl, bu,
+	                   1.7976931348623157e308);
+	return hipGetLastError();
+}

@@ -1,0 +1,51 @@
+// ntg_dev.hpp -- shared host/device declarations of the MI355X NTG engine (gfx950 only).
+//
+// Data layout in HBM (all fp64, indices int32):
+//   blk   per basis CLASS (outputs with identical knots/order/mult/maxderiv share one table):
+//         [bp][q][r] = D^r B_{off+q}(bps[bp])      == reference block[bp].matrix->elements[q][r]
+//         (colloc.c:100-101); classes concatenated, class c starts at cls_blk[c]
+//   off   [class][bp]  coefficient offset of the block (colloc.c:104-111)
+//   aband [nclin][sumk] banded rows of the linear-constraint matrix A (constraints.c:198-261):
+//         row r lives at breakpoint rbp[r]; for output o the k_o entries koff[o].. are the
+//         columns iC[o]+off[cls[o]][rbp[r]]+q of the dense A the reference builds
+//   x, g  [batch][nC]   coefficient vectors, problem-major (coalesced per workgroup)
+//   hist  [batch][memcap][2][nC]  quasi-Newton pairs (s_i, u_i = W_i y_i)
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ntg_amd.h"
+
+typedef unsigned long long u64;
+
+struct NtgDims {
+	int nout, P, nz, nC, nclin, ncnln, nbounds, sumk;
+	int nlic, nltc, nlfc, nnlic, nnltc, nnlfc;
+	int nicf, nucf, nfcf;
+	int family;
+	int order[NTG_MAX_OUT], mult[NTG_MAX_OUT], ninterv[NTG_MAX_OUT], d[NTG_MAX_OUT];
+	int ncoef[NTG_MAX_OUT], iC[NTG_MAX_OUT], iz[NTG_MAX_OUT], koff[NTG_MAX_OUT], cls[NTG_MAX_OUT];
+	int nclass, blk_total, ivl_total;
+	int cls_blk[NTG_MAX_OUT], cls_ivl[NTG_MAX_OUT], cls_k[NTG_MAX_OUT], cls_d[NTG_MAX_OUT], cls_l[NTG_MAX_OUT], cls_m[NTG_MAX_OUT];
+	u64 icost_mask, tcost_mask, fcost_mask, icon_mask, tcon_mask, fcon_mask;
+};
+
+struct NtgTables {
+	const double *bps;     // [P]
+	const double *blk;     // [blk_total]
+	const int *off;        // [nclass][P]
+	const int *ivl_lo;     // [ivl_total] first breakpoint of each knot interval, per class
+	const int *ivl_hi;     // [ivl_total] last breakpoint (inclusive); lo > hi if the interval holds none
+	const double *aband;   // [nclin][sumk]
+	const int *rbp;        // [nclin]
+	const double *sinv;    // [nclin][nclin]  (A A')^-1
+	const double *n0;      // [nC][nC] symmetric preconditioner, or nullptr
+};
+
+// byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
+struct SmemLayout {
+	int blk, off, bps, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2, total;
+};
+
+struct SolveParams {
+	int itlim, memcap, ls_maxfev, hessian, fixed_iters;
+	double sr, steplimit, ls_mu, ls_eta;
+};

@@ -1,0 +1,455 @@
+// plan.cpp -- host side of the C ABI in include/ntg_amd.h: plan construction (the setup phase
+// of ntg(), ntg.c:114-229), batched entry points, error handling.  No numerical fallback lives
+// here: basis values, constraint rows, evaluation and the SQP all run in kernels.hip; the host
+// only factors the tiny (nclin x nclin) A A' and, on request, builds the preconditioner.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ntg_dev.hpp"
+#include "plan.hpp"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                 \
+	do {                                                                                          \
+		hipError_t e_ = (x);                                                                      \
+		if (e_ != hipSuccess) return fail(NTG_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+extern "C" const char *ntg_last_error(void) { return g_err.c_str(); }
+extern "C" int ntg_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+extern "C" void ntg_default_opts(ntg_solve_opts *o)
+{
+	o->itlim = 0; o->opttol = 0.0; o->steplimit = 2.0; o->ls_mu = 1e-4; o->ls_eta = 0.9;
+	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->block_threads = 0;
+}
+extern "C" const char *ntg_solve_kernel_name(void) { return "sqp_kernel"; }
+
+// ---------------- small dense helpers (row-major, host) ----------------
+static bool chol_lower(std::vector<double> &a, int n)
+{
+	for (int j = 0; j < n; j++) {
+		double d = a[(size_t)j * n + j];
+		for (int k = 0; k < j; k++) d -= a[(size_t)j * n + k] * a[(size_t)j * n + k];
+		if (!(d > 0.0)) return false;
+		d = std::sqrt(d); a[(size_t)j * n + j] = d;
+		for (int i = j + 1; i < n; i++) {
+			double s = a[(size_t)i * n + j];
+			for (int k = 0; k < j; k++) s -= a[(size_t)i * n + k] * a[(size_t)j * n + k];
+			a[(size_t)i * n + j] = s / d;
+		}
+	}
+	return true;
+}
+static void chol_solve(const std::vector<double> &L, int n, double *b)
+{
+	for (int i = 0; i < n; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[(size_t)i * n + k] * b[k]; b[i] = s / L[(size_t)i * n + i]; }
+	for (int i = n - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < n; k++) s -= L[(size_t)k * n + i] * b[k]; b[i] = s / L[(size_t)i * n + i]; }
+}
+
+static u64 av_mask(const NtgDims &D, const ntg_av *av, int nav, bool *ok)
+{
+	u64 m = 0;
+	for (int i = 0; i < nav; i++) {
+		if (av[i].output < 0 || av[i].output >= D.nout || av[i].deriv < 0 || av[i].deriv >= D.d[av[i].output]) { *ok = false; continue; }
+		m |= 1ull << (D.iz[av[i].output] + av[i].deriv);
+	}
+	return m;
+}
+
+template <class T> static int dev_upload(T **dst, const T *src, size_t n, std::vector<void *> &owned)
+{
+	*dst = nullptr;
+	if (n == 0) return 0;
+	HIPCHK(hipMalloc((void **)dst, n * sizeof(T)));
+	owned.push_back(*dst);
+	if (src) HIPCHK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+	return 0;
+}
+
+extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
+{
+	if (!s || !out) return fail(NTG_E_BADARG, "null spec");
+	*out = nullptr;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+		return fail(NTG_E_NODEVICE, "no HIP device: libntg_amd has no CPU path");
+	if (device < 0 || device >= ndev) return fail(NTG_E_BADARG, "bad device index");
+	if (s->nout < 1 || s->nout > NTG_MAX_OUT) return fail(NTG_E_BADARG, "nout out of range (1..NTG_MAX_OUT)");
+	if (s->nbps < 2) return fail(NTG_E_BADARG, "need at least 2 breakpoints");
+	HIPCHK(hipSetDevice(device));
+
+	ntg_plan *p = new ntg_plan();
+	p->device = device;
+	NtgDims &D = p->D;
+	std::memset(&D, 0, sizeof(D));
+	D.nout = s->nout; D.P = s->nbps; D.family = s->family;
+	D.nlic = s->nlic; D.nltc = s->nltc; D.nlfc = s->nlfc;
+	D.nnlic = s->nnlic; D.nnltc = s->nnltc; D.nnlfc = s->nnlfc;
+	D.nicf = s->nicf; D.nucf = s->nucf; D.nfcf = s->nfcf;
+	int nz = 0, nC = 0, sumk = 0;
+	for (int o = 0; o < s->nout; o++) {
+		const int k = s->order[o], m = s->mult[o], l = s->kninterv[o], d = s->maxderiv[o];
+		if (k < 1 || k > NTG_MAX_ORDER || m < 0 || m >= k || l < 1 || d < 1 || d > k) {
+			delete p; return fail(NTG_E_BADARG, "bad spline spec (order<=NTG_MAX_ORDER, 0<=mult<order, 1<=maxderiv<=order)");
+		}
+		D.order[o] = k; D.mult[o] = m; D.ninterv[o] = l; D.d[o] = d;
+		D.ncoef[o] = l * (k - m) + m;                         // colloc.c:67
+		D.iC[o] = nC; D.iz[o] = nz; D.koff[o] = sumk;         // colloc.c:41-49
+		nC += D.ncoef[o]; nz += d; sumk += k;
+	}
+	if (nz > NTG_MAX_NZ) { delete p; return fail(NTG_E_BADARG, "sum(maxderiv) exceeds NTG_MAX_NZ"); }
+	D.nC = nC; D.nz = nz; D.sumk = sumk;
+	D.nclin = s->nlic + s->nltc * s->nbps + s->nlfc;           // ntg.c:156
+	D.ncnln = s->nnlic + s->nnltc * s->nbps + s->nnlfc;        // ntg.c:157
+	D.nbounds = s->nlic + s->nltc + s->nlfc + s->nnlic + s->nnltc + s->nnlfc;
+	if (s->family != NTG_FAM_KINCAR && s->family != NTG_FAM_VANDERPOL && s->family != NTG_FAM_TESTFAM && s->family != NTG_FAM_HOST) {
+		delete p; return fail(NTG_E_BADARG, "unknown problem family");
+	}
+	if (s->family != NTG_FAM_HOST)
+		for (int o = 0; o < s->nout; o++)
+			if (D.d[o] != 3) { delete p; return fail(NTG_E_UNSUPPORTED, "device families assume maxderiv == 3"); }
+	if (s->family == NTG_FAM_VANDERPOL && s->nout != 1) { delete p; return fail(NTG_E_BADARG, "vanderpol family has one output"); }
+	if (s->family == NTG_FAM_TESTFAM && (s->nnlic > 1 || s->nnltc > 2 || s->nnlfc > 1)) { delete p; return fail(NTG_E_BADARG, "testfam has 1/2/1 nonlinear constraints"); }
+	if ((s->family == NTG_FAM_KINCAR || s->family == NTG_FAM_VANDERPOL) && D.ncnln > 0) { delete p; return fail(NTG_E_BADARG, "family has no nonlinear constraints"); }
+
+	bool ok = true;
+	D.icost_mask = av_mask(D, s->icostav, s->nicostav, &ok);
+	D.tcost_mask = av_mask(D, s->tcostav, s->ntcostav, &ok);
+	D.fcost_mask = av_mask(D, s->fcostav, s->nfcostav, &ok);
+	D.icon_mask = av_mask(D, s->icav, s->nicav, &ok);
+	D.tcon_mask = av_mask(D, s->tcav, s->ntcav, &ok);
+	D.fcon_mask = av_mask(D, s->fcav, s->nfcav, &ok);
+	if (!ok) { delete p; return fail(NTG_E_BADARG, "active variable out of range"); }
+
+	// ---- basis classes: outputs with identical (knots, order, mult, maxderiv) share a table ----
+	p->h_knots.resize(s->nout);
+	for (int o = 0; o < s->nout; o++) p->h_knots[o].assign(s->knots[o], s->knots[o] + s->kninterv[o] + 1);
+	D.nclass = 0;
+	std::vector<int> rep;
+	int blk_total = 0, ivl_total = 0;
+	for (int o = 0; o < s->nout; o++) {
+		int c = -1;
+		for (int j = 0; j < D.nclass; j++) {
+			const int r = rep[j];
+			if (D.order[r] == D.order[o] && D.mult[r] == D.mult[o] && D.d[r] == D.d[o] && D.ninterv[r] == D.ninterv[o] &&
+			    p->h_knots[r] == p->h_knots[o]) { c = j; break; }
+		}
+		if (c < 0) {
+			c = D.nclass++;
+			rep.push_back(o);
+			D.cls_blk[c] = blk_total; D.cls_ivl[c] = ivl_total;
+			D.cls_k[c] = D.order[o]; D.cls_d[c] = D.d[o]; D.cls_l[c] = D.ninterv[o]; D.cls_m[c] = D.mult[o];
+			blk_total += s->nbps * D.order[o] * D.d[o];
+			ivl_total += D.ninterv[o];
+		}
+		D.cls[o] = c;
+	}
+	D.blk_total = blk_total; D.ivl_total = ivl_total;
+	p->class_rep = rep;
+
+	// ---- device tables ----
+	auto &own = p->owned;
+	double *d_bps = nullptr, *d_blk = nullptr; int *d_off = nullptr;
+	p->h_bps.assign(s->bps, s->bps + s->nbps);
+	if (dev_upload(&d_bps, s->bps, (size_t)s->nbps, own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+	if (dev_upload(&d_blk, (const double *)nullptr, (size_t)blk_total, own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+	if (dev_upload(&d_off, (const int *)nullptr, (size_t)D.nclass * s->nbps, own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+	for (int c = 0; c < D.nclass; c++) {
+		const int o = rep[c];
+		double *d_kn = nullptr;
+		std::vector<void *> tmp_own;
+		if (dev_upload(&d_kn, p->h_knots[o].data(), p->h_knots[o].size(), tmp_own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+		hipError_t e = ntg_launch_basis(1, D.ninterv[o], D.order[o], D.mult[o], D.d[o], s->nbps, d_kn, d_bps, 0, 0,
+		                                d_blk + D.cls_blk[c], d_off + (size_t)c * s->nbps, nullptr);
+		hipError_t e2 = hipDeviceSynchronize();
+		hipFree(d_kn);
+		if (e != hipSuccess || e2 != hipSuccess) { ntg_plan_destroy(p); return fail(NTG_E_HIP, "basis kernel failed"); }
+	}
+	p->h_blk.resize(blk_total); p->h_off.resize((size_t)D.nclass * s->nbps);
+	HIPCHK(hipMemcpy(p->h_blk.data(), d_blk, (size_t)blk_total * 8, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(p->h_off.data(), d_off, p->h_off.size() * 4, hipMemcpyDeviceToHost));
+	// interval -> breakpoint ranges (monotone bounds, see kernels.hip eval_cost)
+	std::vector<int> ivl_lo(ivl_total > 0 ? ivl_total : 1), ivl_hi(ivl_total > 0 ? ivl_total : 1);
+	for (int c = 0; c < D.nclass; c++) {
+		const int km = D.cls_k[c] - D.cls_m[c], l = D.cls_l[c], P = s->nbps;
+		const int *off = p->h_off.data() + (size_t)c * P;
+		for (int j = 0; j < l; j++) {
+			int lo = P, hi = -1;
+			for (int i = 0; i < P; i++) { const int iv = off[i] / km; if (iv >= j && i < lo) lo = i; if (iv <= j) hi = i; }
+			ivl_lo[D.cls_ivl[c] + j] = lo; ivl_hi[D.cls_ivl[c] + j] = hi;
+		}
+	}
+	int *d_ilo = nullptr, *d_ihi = nullptr;
+	if (dev_upload(&d_ilo, ivl_lo.data(), ivl_lo.size(), own) || dev_upload(&d_ihi, ivl_hi.data(), ivl_hi.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+	NtgTables &T = p->T;
+	std::memset(&T, 0, sizeof(T));
+	T.bps = d_bps; T.blk = d_blk; T.off = d_off; T.ivl_lo = d_ilo; T.ivl_hi = d_ihi;
+
+	// ---- linear constraint rows on the device, (A A')^-1 on the host ----
+	if (D.nclin > 0) {
+		double *d_lic = nullptr, *d_ltc = nullptr, *d_lfc = nullptr, *d_ab = nullptr, *d_sinv = nullptr; int *d_rbp = nullptr;
+		std::vector<void *> tmp_own;
+		if (dev_upload(&d_lic, s->lic, (size_t)s->nlic * nz, tmp_own) || dev_upload(&d_ltc, s->ltc, (size_t)s->nltc * nz, tmp_own) ||
+		    dev_upload(&d_lfc, s->lfc, (size_t)s->nlfc * nz, tmp_own) ||
+		    dev_upload(&d_ab, (const double *)nullptr, (size_t)D.nclin * sumk, own) ||
+		    dev_upload(&d_rbp, (const int *)nullptr, (size_t)D.nclin, own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+		hipError_t e = ntg_launch_linrows(D, T, d_lic, d_ltc, d_lfc, d_ab, d_rbp, nullptr);
+		hipError_t e2 = hipDeviceSynchronize();
+		for (void *q : tmp_own) hipFree(q);
+		if (e != hipSuccess || e2 != hipSuccess) { ntg_plan_destroy(p); return fail(NTG_E_HIP, "linrows kernel failed"); }
+		p->h_aband.resize((size_t)D.nclin * sumk); p->h_rbp.resize(D.nclin);
+		HIPCHK(hipMemcpy(p->h_aband.data(), d_ab, p->h_aband.size() * 8, hipMemcpyDeviceToHost));
+		HIPCHK(hipMemcpy(p->h_rbp.data(), d_rbp, p->h_rbp.size() * 4, hipMemcpyDeviceToHost));
+		T.aband = d_ab; T.rbp = d_rbp;
+		// dense rows -> S = A A' -> S^-1
+		const int m = D.nclin;
+		std::vector<double> Ad((size_t)m * nC, 0.0);
+		ntg_plan_dense_A(p, Ad.data());
+		std::vector<double> S((size_t)m * m, 0.0);
+		for (int i = 0; i < m; i++) for (int j = 0; j <= i; j++) {
+			double a = 0.0;
+			for (int c = 0; c < nC; c++) a += Ad[(size_t)i * nC + c] * Ad[(size_t)j * nC + c];
+			S[(size_t)i * m + j] = a; S[(size_t)j * m + i] = a;
+		}
+		p->lin_ok = chol_lower(S, m);
+		std::vector<double> Sinv((size_t)m * m, 0.0), col(m);
+		if (p->lin_ok) {
+			for (int j = 0; j < m; j++) {
+				std::fill(col.begin(), col.end(), 0.0); col[j] = 1.0;
+				chol_solve(S, m, col.data());
+				for (int i = 0; i < m; i++) Sinv[(size_t)i * m + j] = col[i];
+			}
+			for (int i = 0; i < m; i++) for (int j = 0; j < i; j++) { // symmetrise
+				const double a = 0.5 * (Sinv[(size_t)i * m + j] + Sinv[(size_t)j * m + i]);
+				Sinv[(size_t)i * m + j] = a; Sinv[(size_t)j * m + i] = a;
+			}
+		}
+		if (dev_upload(&d_sinv, Sinv.data(), Sinv.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+		T.sinv = d_sinv;
+		p->h_Adense.swap(Ad);
+	} else {
+		p->lin_ok = true;
+	}
+	// keep what the preconditioner build needs
+	p->tcostav.assign(s->tcostav, s->tcostav + s->ntcostav);
+	p->icostav.assign(s->icostav, s->icostav + s->nicostav);
+	p->fcostav.assign(s->fcostav, s->fcostav + s->nfcostav);
+	*out = p;
+	return 0;
+}
+
+// dense row-major [nclin][nC] A from the banded rows
+void ntg_plan_dense_A(const ntg_plan *p, double *A)
+{
+	const NtgDims &D = p->D;
+	std::fill(A, A + (size_t)D.nclin * D.nC, 0.0);
+	for (int r = 0; r < D.nclin; r++)
+		for (int o = 0; o < D.nout; o++) {
+			const int col0 = D.iC[o] + p->h_off[(size_t)D.cls[o] * D.P + p->h_rbp[r]];
+			for (int q = 0; q < D.order[o]; q++) A[(size_t)r * D.nC + col0 + q] = p->h_aband[(size_t)r * D.sumk + D.koff[o] + q];
+		}
+}
+
+extern "C" void ntg_plan_destroy(ntg_plan *p)
+{
+	if (!p) return;
+	hipSetDevice(p->device);
+	for (void *q : p->owned) hipFree(q);
+	delete p;
+}
+
+extern "C" int ntg_plan_dims(const ntg_plan *p, int *nC, int *nz, int *nclin, int *ncnln, int *nbounds, int *sumk, int *nblk)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (nC) *nC = p->D.nC; if (nz) *nz = p->D.nz; if (nclin) *nclin = p->D.nclin; if (ncnln) *ncnln = p->D.ncnln;
+	if (nbounds) *nbounds = p->D.nbounds; if (sumk) *sumk = p->D.sumk;
+	if (nblk) { int t = 0; for (int o = 0; o < p->D.nout; o++) t += p->D.P * p->D.order[o] * p->D.d[o]; *nblk = t; }
+	return 0;
+}
+
+extern "C" int ntg_plan_tables(const ntg_plan *p, double *blk, int *off, double *A)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	const NtgDims &D = p->D;
+	size_t pos = 0;
+	for (int o = 0; o < D.nout; o++) {
+		const size_t cnt = (size_t)D.P * D.order[o] * D.d[o];
+		if (blk) std::memcpy(blk + pos, p->h_blk.data() + D.cls_blk[D.cls[o]], cnt * 8);
+		if (off) std::memcpy(off + (size_t)o * D.P, p->h_off.data() + (size_t)D.cls[o] * D.P, (size_t)D.P * 4);
+		pos += cnt;
+	}
+	if (A && D.nclin) // column-major nclin x nC
+		for (int r = 0; r < D.nclin; r++)
+			for (int c = 0; c < D.nC; c++) A[(size_t)c * D.nclin + r] = p->h_Adense[(size_t)r * D.nC + c];
+	return 0;
+}
+
+// W0 = Z (Z' H0 Z)^-1 Z', H0 = trapezoid-weighted sum of m m' over the cost active variables.
+// Host, once per plan (shared by the whole batch); dense symmetric n x n uploaded to HBM.
+static int build_precond(ntg_plan *p)
+{
+	const NtgDims &D = p->D;
+	const int n = D.nC, m = D.nclin, nr = n - m, P = D.P;
+	if (nr <= 0) return fail(NTG_E_UNSUPPORTED, "no free directions");
+	std::vector<double> H0((size_t)n * n, 0.0);
+	auto add = [&](const std::vector<ntg_av> &av, int bp, double w) {
+		for (const ntg_av &a : av) {
+			const int o = a.output, r = a.deriv, k = D.order[o], d = D.d[o], c = D.cls[o];
+			const int base = D.iC[o] + p->h_off[(size_t)c * P + bp];
+			const double *b = p->h_blk.data() + D.cls_blk[c] + (size_t)bp * k * d;
+			for (int q1 = 0; q1 < k; q1++) for (int q2 = 0; q2 < k; q2++)
+				H0[(size_t)(base + q1) * n + base + q2] += w * b[q1 * d + r] * b[q2 * d + r];
+		}
+	};
+	for (int i = 0; i < P; i++) {
+		double w = 0.0;
+		if (i > 0) w += (p->h_bps[i] - p->h_bps[i - 1]) / 2;
+		if (i < P - 1) w += (p->h_bps[i + 1] - p->h_bps[i]) / 2;
+		if (D.nucf) add(p->tcostav, i, w);
+	}
+	if (D.nicf) add(p->icostav, 0, 1.0);
+	if (D.nfcf) add(p->fcostav, P - 1, 1.0);
+	// Householder QR of A' -> explicit Q (row-major n x n)
+	std::vector<double> Q((size_t)n * n, 0.0), R((size_t)n * std::max(m, 1), 0.0), v(n);
+	for (int i = 0; i < n; i++) Q[(size_t)i * n + i] = 1.0;
+	for (int j = 0; j < m; j++) for (int i = 0; i < n; i++) R[(size_t)i * m + j] = p->h_Adense[(size_t)j * n + i];
+	for (int j = 0; j < m && j < n; j++) {
+		double nrm = 0.0;
+		for (int i = j; i < n; i++) nrm += R[(size_t)i * m + j] * R[(size_t)i * m + j];
+		nrm = std::sqrt(nrm);
+		if (nrm == 0.0) continue;
+		const double alpha = R[(size_t)j * m + j] > 0 ? -nrm : nrm;
+		std::fill(v.begin(), v.end(), 0.0);
+		for (int i = j; i < n; i++) v[i] = R[(size_t)i * m + j];
+		v[j] -= alpha;
+		double vn = 0.0;
+		for (int i = j; i < n; i++) vn += v[i] * v[i];
+		if (vn == 0.0) continue;
+		for (int c = j; c < m; c++) { double s = 0.0; for (int i = j; i < n; i++) s += v[i] * R[(size_t)i * m + c]; s = 2.0 * s / vn; for (int i = j; i < n; i++) R[(size_t)i * m + c] -= s * v[i]; }
+		for (int c = 0; c < n; c++) { double s = 0.0; for (int i = j; i < n; i++) s += Q[(size_t)c * n + i] * v[i]; s = 2.0 * s / vn; for (int i = j; i < n; i++) Q[(size_t)c * n + i] -= s * v[i]; }
+	}
+	// Zt[j][:] = column m+j of Q ; T = H0 Z ; Hr = Z' T
+	std::vector<double> Zt((size_t)nr * n), Tm((size_t)nr * n), Hr((size_t)nr * nr);
+	for (int j = 0; j < nr; j++) for (int i = 0; i < n; i++) Zt[(size_t)j * n + i] = Q[(size_t)i * n + m + j];
+	for (int j = 0; j < nr; j++) for (int i = 0; i < n; i++) { double s = 0.0; const double *h = &H0[(size_t)i * n], *z = &Zt[(size_t)j * n]; for (int k = 0; k < n; k++) s += h[k] * z[k]; Tm[(size_t)j * n + i] = s; }
+	double tr = 0.0;
+	auto form_hr = [&](double reg) {
+		for (int i = 0; i < nr; i++) for (int j = 0; j <= i; j++) { double s = 0.0; const double *a = &Zt[(size_t)i * n], *b = &Tm[(size_t)j * n]; for (int k = 0; k < n; k++) s += a[k] * b[k]; Hr[(size_t)i * nr + j] = s; Hr[(size_t)j * nr + i] = s; }
+		tr = 0.0; for (int i = 0; i < nr; i++) tr += Hr[(size_t)i * nr + i];
+		for (int i = 0; i < nr; i++) Hr[(size_t)i * nr + i] += reg * tr / nr + 1e-300;
+	};
+	form_hr(1e-12);
+	if (!chol_lower(Hr, nr)) { form_hr(1e-6); if (!chol_lower(Hr, nr)) return fail(NTG_E_UNSUPPORTED, "preconditioner not positive definite"); }
+	// X[:, c] = Hr^-1 Zt[:, c] ; W0 = Zt' X
+	std::vector<double> X((size_t)n * nr), col(nr), W0((size_t)n * n);
+	for (int c = 0; c < n; c++) { for (int i = 0; i < nr; i++) col[i] = Zt[(size_t)i * n + c]; chol_solve(Hr, nr, col.data()); for (int i = 0; i < nr; i++) X[(size_t)c * nr + i] = col[i]; }
+	for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {
+		double s = 0.0;
+		for (int k = 0; k < nr; k++) s += Zt[(size_t)k * n + i] * X[(size_t)j * nr + k];
+		W0[(size_t)i * n + j] = s; W0[(size_t)j * n + i] = s;
+	}
+	double *d_n0 = nullptr;
+	if (dev_upload(&d_n0, W0.data(), W0.size(), p->owned)) return NTG_E_HIP;
+	p->T.n0 = d_n0;
+	return 0;
+}
+
+static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParams *sp, int *nt)
+{
+	const NtgDims &D = p->D;
+	ntg_solve_opts def; ntg_default_opts(&def);
+	if (!o) o = &def;
+	sp->itlim = o->itlim > 0 ? o->itlim : std::max(50, 3 * (D.nC + D.nclin) + 10 * D.ncnln);
+	sp->memcap = std::min(sp->itlim, 256);
+	sp->ls_maxfev = o->ls_maxfev > 0 ? o->ls_maxfev : 20;
+	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters;
+	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
+	sp->sr = std::sqrt(r);
+	sp->steplimit = o->steplimit > 0 ? o->steplimit : 2.0;
+	sp->ls_mu = o->ls_mu > 0 ? o->ls_mu : 1e-4; sp->ls_eta = o->ls_eta > 0 ? o->ls_eta : 0.9;
+	int t = o->block_threads;
+	if (t != 64 && t != 128 && t != 256) t = D.P <= 64 ? 64 : (D.P <= 128 && D.nC <= 512 ? 128 : 256);
+	*nt = t;
+	return 0;
+}
+
+extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, const ntg_solve_opts *o)
+{
+	if (!p) return 0;
+	SolveParams sp; int nt;
+	resolve_params(p, o, &sp, &nt);
+	return (long long)batch * sp.memcap * 2 * p->D.nC * 8 + 256;
+}
+
+extern "C" int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
+                                double *d_bl, double *d_bu, void *stream)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	HIPCHK(hipSetDevice(p->device));
+	HIPCHK(ntg_launch_bounds(p->D, batch, d_lower, d_upper, d_bl, d_bu, (hipStream_t)stream));
+	return 0;
+}
+
+extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, int mode, double *d_f, double *d_g,
+                              double *d_c, double *d_jband, double *d_cjac, void *stream)
+{
+	if (!p || !d_x) return fail(NTG_E_BADARG, "null plan or x");
+	if (mode < 0 || mode > 2) return fail(NTG_E_BADARG, "mode must be 0, 1 or 2");
+	if (p->D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans evaluate through npsolCostFunction");
+	if (batch <= 0) return 0;
+	HIPCHK(hipSetDevice(p->device));
+	const NtgDims &D = p->D;
+	const int nt = D.P <= 64 ? 64 : (D.P <= 128 && D.nC <= 512 ? 128 : 256);
+	SmemLayout L = ntg_make_layout(D, nt, 1, 0);
+	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem tables exceed 160 KiB of LDS");
+	hipStream_t st = (hipStream_t)stream;
+	if (d_cjac && D.ncnln) HIPCHK(hipMemsetAsync(d_cjac, 0, (size_t)batch * D.ncnln * D.nC * 8, st)); // GcJac starts zeroed (ntg.c:217)
+	const int wg_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(L.total, 1)));
+	const int grid = std::min(batch, 256 * wg_per_cu);
+	HIPCHK(ntg_launch_eval(nt, D, p->T, L, grid, batch, mode, d_x, d_f, d_g, d_c, d_jband, d_cjac, st));
+	return 0;
+}
+
+extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lower, const double *d_upper, double *d_x,
+                               const ntg_solve_opts *o, double *d_objective, int *d_inform, int *d_iters, int *d_nfev,
+                               double *d_clambda, void *d_work, long long work_bytes, void *stream)
+{
+	ntg_plan *p = const_cast<ntg_plan *>(pc);
+	if (!p || !d_x || !d_lower || !d_upper) return fail(NTG_E_BADARG, "null argument");
+	if (p->D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans are solved by ntg()");
+	if (!p->lin_ok) return fail(NTG_E_BADARG, "linear constraint rows are rank deficient");
+	if (batch <= 0) return 0;
+	HIPCHK(hipSetDevice(p->device));
+	SolveParams sp; int nt;
+	resolve_params(p, o, &sp, &nt);
+	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
+	if (sp.hessian == 1 && !p->T.n0) { int rc = build_precond(p); if (rc) return rc; }
+	SmemLayout L = ntg_make_layout(p->D, nt, 6, sp.memcap);
+	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
+	HIPCHK(ntg_launch_sqp(nt, p->D, p->T, L, sp, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev,
+	                      d_clambda, (double *)d_work, (hipStream_t)stream));
+	return 0;
+}
+
+extern "C" int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, int nbps, const double *d_knots,
+                               const double *d_bps, double *d_blk, int *d_off, void *stream)
+{
+	if (order < 1 || order > NTG_MAX_ORDER || mult < 0 || mult >= order || maxderiv < 1 || maxderiv > order || ninterv < 1 || nbps < 1)
+		return fail(NTG_E_BADARG, "bad spline spec");
+	if (ngrids <= 0) return 0;
+	if (ngrids > 65535) return fail(NTG_E_BADARG, "at most 65535 grids per call");
+	HIPCHK(ntg_launch_basis(ngrids, ninterv, order, mult, maxderiv, nbps, d_knots, d_bps, ninterv + 1, nbps, d_blk, d_off,
+	                        (hipStream_t)stream));
+	return 0;
+}

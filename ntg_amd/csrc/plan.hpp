@@ -1,0 +1,40 @@
+// plan.hpp -- the plan object behind include/ntg_amd.h and the launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <vector>
+#include "ntg_dev.hpp"
+
+struct ntg_plan {
+	int device = 0;
+	NtgDims D;
+	NtgTables T;
+	bool lin_ok = true;
+	std::vector<void *> owned;                  // device allocations
+	std::vector<std::vector<double>> h_knots;   // host mirrors of the setup tables
+	std::vector<double> h_bps, h_blk, h_aband, h_Adense;
+	std::vector<int> h_off, h_rbp, class_rep;
+	std::vector<ntg_av> icostav, tcostav, fcostav;
+};
+
+void ntg_plan_dense_A(const ntg_plan *p, double *A);
+
+SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int memcap);
+hipError_t ntg_launch_eval(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, int grid, int batch,
+                           int mode, const double *x, double *f, double *g, double *c, double *jb, double *cj,
+                           hipStream_t st);
+hipError_t ntg_launch_sqp(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp,
+                          int batch, const double *lo, const double *up, double *x, double *obj, int *inf, int *it,
+                          int *nf, double *cl, double *hist, hipStream_t st);
+hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,
+                            long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st);
+hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,
+                              const double *lfc, double *aband, int *rbp, hipStream_t st);
+hipError_t ntg_launch_bounds(const NtgDims &D, int batch, const double *lo, const double *up, double *bl, double *bu,
+                             hipStream_t st);
+hipError_t ntg_launch_hostz(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const double *x, u64 mI,
+                            u64 mT, u64 mF, double *Z, hipStream_t st);
+hipError_t ntg_launch_hostcost(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const double *fT,
+                               const double *dfT, const double *fdI, const double *fdF, double *F, double *g,
+                               hipStream_t st);
+hipError_t ntg_launch_hostcon(const NtgDims &D, const NtgTables &T, const double *dc, double *jband, double *cjac,
+                              hipStream_t st);

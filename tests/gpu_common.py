@@ -1,0 +1,24 @@
+"""Shared helpers for the -m gpu parity tests (all product calls go through the C ABI)."""
+import numpy as np
+import torch
+
+import orc
+from ntg_amd import api, configs as cf
+
+SPECS = {"A": cf.config_A, "K0": cf.config_K0, "B": cf.config_B, "M": cf.config_M, "T": cf.config_T}
+_plans = {}
+
+
+def plan_for(name):
+    if name not in _plans:
+        _plans[name] = api.Plan(SPECS[name](), 0)
+    return _plans[name]
+
+
+def dev(a, dtype=torch.float64):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device="cuda:0")
+
+
+def rel(a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))

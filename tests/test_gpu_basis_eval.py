@@ -1,0 +1,116 @@
+"""-m gpu: basis, linear-constraint rows, bounds and funobj/funcon kernels against the golden
+fixtures (reference C code outputs) and the oracle, through the C ABI.
+
+Tolerances (fp64): the kernels use fused multiply-adds and wavefront-shuffle reductions, the
+reference sums sequentially without contraction, so results agree to rounding, not bitwise:
+  basis blocks / A rows      |d| <= 1e-13 * max|ref|
+  f, g, c, cJac              |d| <= 1e-12 * max|ref|   (<= 1e-12 relative)
+Integer outputs (offsets, row order, bounds copies) are exact."""
+import os
+import numpy as np
+import pytest
+import torch
+
+import orc
+from ntg_amd import api, configs as cf
+from gpu_common import SPECS, plan_for, dev, rel
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gold(name):
+    return dict(np.load(os.path.join(GOLD, f"ref_{name}.npz")))
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+def test_basis_tables_and_A(name):
+    spec = SPECS[name](); g = gold(name)
+    t = plan_for(name).tables()
+    assert np.array_equal(t["off"], g["off"])                       # index work: exact
+    assert rel(t["blk"], g["blk"]) <= 1e-13
+    if spec.nclin:
+        assert t["A"].shape == g["A"].shape
+        assert np.array_equal(t["A"] != 0, g["A"] != 0)           # same band positions as the reference's dense A
+        assert rel(t["A"], g["A"]) <= 1e-13
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+def test_bounds_expansion(name):
+    spec = SPECS[name](); g = gold(name)
+    bl, bu = plan_for(name).bounds(dev(g["lowerb"][:1]), dev(g["upperb"][:1]))
+    assert np.array_equal(bl.cpu().numpy()[0], g["bl"]) and np.array_equal(bu.cpu().numpy()[0], g["bu"])
+
+
+@pytest.mark.parametrize("name", list(SPECS))
+def test_eval_matches_reference_fixture(name):
+    spec = SPECS[name](); g = gold(name)
+    out = plan_for(name).eval(dev(g["x"]), 2, want_dense_jac=True)
+    assert rel(out["f"].cpu().numpy(), g["f"]) <= 1e-12
+    assert rel(out["g"].cpu().numpy(), g["g"]) <= 1e-12
+    if spec.ncnln:
+        assert rel(out["c"].cpu().numpy(), g["c"]) <= 1e-12
+        J = out["cJac"].cpu().numpy()
+        assert np.array_equal(J != 0, g["cJac"] != 0)             # band structure identical
+        assert rel(J, g["cJac"]) <= 1e-12
+        # banded rows carry the same numbers as the dense Jacobian
+        jb = out["jband"].cpu().numpy()
+        t = plan_for(name).tables(); P = spec.nbps
+        for row in (0, spec.nnlic + 3, spec.nnlic + P + 5, spec.ncnln - 1):
+            bp = 0 if row < spec.nnlic else (P - 1 if row >= spec.nnlic + spec.nnltc * P else (row - spec.nnlic) % P)
+            koff = 0; iC = 0
+            for o in range(spec.nout):
+                k = spec.order[o]
+                col0 = iC + t["off"][o, bp]
+                assert np.array_equal(jb[0, row, koff:koff + k], J[0, row, col0:col0 + k])
+                koff += k; iC += spec.ncoef[o]
+
+
+@pytest.mark.parametrize("name", ["A", "B", "M", "T"])
+def test_eval_vs_oracle_random_batch(name):
+    spec = SPECS[name]()
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(37, spec.nC)) * 3.0                         # ragged vs the persistent grid
+    ref = orc.eval_batch(spec, x, 2)
+    for mode in (0, 1, 2):
+        out = plan_for(name).eval(dev(x), mode)
+        if mode != 1:
+            assert rel(out["f"].cpu().numpy(), ref["f"]) <= 1e-12
+        if mode != 0:
+            assert rel(out["g"].cpu().numpy(), ref["g"]) <= 1e-12
+        if spec.ncnln and mode != 1:
+            assert rel(out["c"].cpu().numpy(), ref["c"]) <= 1e-12
+
+
+def test_eval_empty_and_single():
+    p = plan_for("B"); spec = p.spec
+    out = p.eval(torch.empty((0, spec.nC), dtype=torch.float64, device="cuda:0"), 2)
+    assert out["f"].shape[0] == 0
+    x = np.ones((1, spec.nC))
+    assert rel(p.eval(dev(x), 2)["f"].cpu().numpy(), orc.eval_batch(spec, x, 2)["f"]) <= 1e-12
+
+
+def test_eval_linearity_property_large_batch():
+    """Size-independent property at full batch: the kincar cost is a quadratic form, so
+    g(a x) = a g(x) and f(a x) = a^2 f(x) for every problem of a 4096 batch."""
+    p = plan_for("M"); spec = p.spec
+    x = torch.randn((4096, spec.nC), dtype=torch.float64, device="cuda:0")
+    o1 = p.eval(x, 2); o2 = p.eval(2.0 * x, 2)
+    assert torch.allclose(o2["f"], 4.0 * o1["f"], rtol=1e-13, atol=0)
+    assert torch.allclose(o2["g"], 2.0 * o1["g"], rtol=1e-12, atol=1e-9)
+
+
+def test_basis_batch_per_problem_grids():
+    """bsplvd at every collocation point for many different horizons (per-problem grids)."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    G, l, k, m, d, P = 33, 20, 6, 3, 3, 101
+    T = rng.uniform(2.0, 9.0, G)
+    knots = np.stack([cf.linspace_c(0.0, t, l + 1) for t in T]); bps = np.stack([cf.linspace_c(0.0, t, P) for t in T])
+    blk, off = api.basis_batch(dev(knots), dev(bps), k, m, d)
+    blk = blk.cpu().numpy(); off = off.cpu().numpy()
+    for gi in (0, 7, G - 1):
+        spec = cf.config_B(); spec.knots = [knots[gi]] * 2; spec.bps = bps[gi]
+        tab = orc.export_tables(spec)
+        assert np.array_equal(off[gi], tab["off"][0])
+        assert rel(blk[gi].reshape(-1), tab["blk"][:P * k * d]) <= 1e-13

@@ -1,0 +1,141 @@
+"""-m gpu: the batched SQP kernel (replacement of the npsol_ call, ntg.c:250) against the oracle
+and against closed-form optima, through the C ABI.
+
+Tolerances: at the optimum BASELINE.md §2 (|dF| <= 1e-9 relative to max(1,|F|), |dC|inf <= 1e-6
+scaled by max(1,|C|inf), linear feasibility <= 1e-8).  For a fixed number of majors the GPU and
+the oracle run the same algorithm with different summation orders; iterates agree to 1e-7 relative
+in F after 50 majors (quasi-Newton recurrences amplify rounding), counts of majors/evaluations
+are exact."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from ntg_amd import api, configs as cf
+from gpu_common import plan_for, dev, rel
+from test_oracle_known_answers import kkt_kincar
+
+pytestmark = pytest.mark.gpu
+
+
+def solve(name, lo, up, x0, **kw):
+    p = plan_for(name)
+    x = dev(x0)
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(**kw), want_lambda=True)
+    torch.cuda.synchronize()
+    return x.cpu().numpy(), {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("hessian", [0, 1])
+def test_kincar_shipped_known_answer(hessian):
+    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
+    x, out = solve("K0", lo[None], up[None], np.ones((1, spec.nC)), hessian=hessian)
+    assert out["inform"][0] == 0
+    assert abs(out["objective"][0] - 2.457581141950512) <= 1e-9
+    np.testing.assert_allclose(x[0], [0, 5, 10, 20, 30, 35, 40, -2, -2, -2, 0, 2, 2, 2], atol=1e-6)
+
+
+@pytest.mark.parametrize("hessian", [0, 1])
+def test_vanderpol_known_answer(hessian):
+    spec = cf.config_A(); lo, up = cf.bounds_A()
+    x, out = solve("A", lo[None], up[None], np.ones((1, spec.nC)), hessian=hessian)
+    assert out["inform"][0] == 0
+    assert abs(out["objective"][0] - 1.7022142628309958) <= 1e-9
+    np.testing.assert_allclose(x[0], [1, 1, 0.3937399093, -0.0369580060, -0.4395320819, -0.7168653229, -0.2449741945], atol=1e-6)
+    o = orc.solve_one(spec, lo, up, np.ones(spec.nC), orc.default_opts(hessian=hessian))
+    assert out["iters"][0] == o["iters"] and out["nfev"][0] == o["nfev"]
+
+
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3)])
+@pytest.mark.parametrize("hessian", [0, 1])
+def test_optimum_matches_kkt_and_oracle(name, ncars, hessian):
+    spec = plan_for(name).spec
+    nb = 24
+    lo, up = cf.kincar_random_bounds(ncars, nb)
+    x, out = solve(name, lo, up, np.ones((nb, spec.nC)), hessian=hessian)
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(hessian=hessian), nthreads=8)
+    assert (out["inform"] == 0).all()
+    t = plan_for(name).tables()
+    for p in range(nb):
+        if p < 4:
+            xs, fs = kkt_kincar(spec, lo[p])
+            assert abs(out["objective"][p] - fs) <= 1e-9 * max(1.0, abs(fs))
+            assert np.abs(x[p] - xs).max() <= 1e-6 * max(1.0, np.abs(xs).max())
+        assert abs(out["objective"][p] - ref["objective"][p]) <= 1e-9 * max(1.0, abs(ref["objective"][p]))
+        assert np.abs(x[p] - ref["x"][p]).max() <= 1e-6 * max(1.0, np.abs(ref["x"][p]).max())
+        assert np.abs(t["A"] @ x[p] - lo[p]).max() <= 1e-8
+    if hessian == 1:
+        assert out["iters"].max() <= 5
+        assert np.array_equal(out["iters"], ref["iters"]) and np.array_equal(out["nfev"], ref["nfev"])
+
+
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3)])
+def test_fixed_50_majors_parity_with_oracle(name, ncars):
+    """The benchmark mode: exactly 50 majors, identity cold start."""
+    spec = plan_for(name).spec
+    nb = 16
+    lo, up = cf.kincar_random_bounds(ncars, nb)
+    x, out = solve(name, lo, up, np.ones((nb, spec.nC)), itlim=50, fixed_iters=1)
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(itlim=50, fixed_iters=1), nthreads=8)
+    assert (out["iters"] == 50).all() and (out["inform"] == 4).all()
+    assert np.array_equal(out["nfev"], ref["nfev"])
+    assert rel(out["objective"], ref["objective"]) <= 1e-7
+    assert np.abs(x - ref["x"]).max() <= 1e-5 * np.abs(ref["x"]).max()
+
+
+def test_multipliers_and_feasibility_outputs():
+    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
+    x, out = solve("K0", lo[None], up[None], np.ones((1, spec.nC)))
+    o = orc.solve_one(spec, lo, up, np.ones(spec.nC))
+    lam = out["clambda"][0]
+    assert np.all(lam[:spec.nC] == 0)
+    np.testing.assert_allclose(lam[spec.nC:], o["clambda"][spec.nC:], rtol=1e-6, atol=1e-8)
+
+
+def test_unsupported_inputs_are_loud_not_wrong():
+    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
+    up2 = up.copy(); up2[3] += 0.5
+    x, out = solve("K0", np.stack([lo, lo]), np.stack([up, up2]), np.ones((2, spec.nC)))
+    assert out["inform"][0] == 0 and out["inform"][1] == 9       # inequality: flagged, per problem
+    assert np.array_equal(x[1], np.ones(spec.nC))                 # and left untouched
+    T = plan_for("T").spec
+    xt, ot = solve("T", np.zeros((1, T.nbounds)), np.zeros((1, T.nbounds)), np.ones((1, T.nC)))
+    assert ot["inform"][0] == 9
+
+
+def test_iteration_limit_and_ragged_batch():
+    spec = cf.config_B()
+    for nb in (1, 3, 65):
+        lo, up = cf.kincar_random_bounds(1, nb)
+        x, out = solve("B", lo, up, np.ones((nb, spec.nC)), itlim=7)
+        assert (out["iters"] == 7).all() and (out["inform"] == 4).all()
+
+
+def test_full_batch_properties_config_M():
+    """BASELINE size (4096 x config M): size-independent properties instead of an oracle run:
+    linear feasibility of every solution, KKT stationarity of the projected gradient,
+    idempotence (re-solving from the solution does not move it) and batch-order invariance."""
+    p = plan_for("M"); spec = p.spec
+    nb = 4096
+    lo, up = cf.kincar_random_bounds(3, nb)
+    lo_d, up_d = dev(lo), dev(up)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(lo_d, up_d, x, api.default_opts(hessian=1))
+    assert int((out["inform"] != 0).sum()) == 0
+    A = dev(p.tables()["A"])
+    feas = (x @ A.T - lo_d).abs().max().item()
+    assert feas <= 1e-8
+    ev = p.eval(x, 2)
+    g = ev["g"]
+    lam = torch.linalg.solve(A @ A.T, A @ g.T)                   # projected gradient must vanish
+    pg = g - (A.T @ lam).T
+    assert (pg.norm(dim=1) / (1 + g.norm(dim=1))).max().item() <= 1e-6
+    # idempotence
+    x2 = x.clone()
+    out2 = p.solve(lo_d, up_d, x2, api.default_opts(hessian=1))
+    assert (out2["inform"] == 0).all() and (x2 - x).abs().max().item() <= 1e-7 * x.abs().max().item()
+    # order invariance: a permuted batch gives the permuted, bit-identical results
+    perm = torch.randperm(nb, device="cuda:0")
+    xp = torch.ones_like(x)
+    p.solve(lo_d[perm].contiguous(), up_d[perm].contiguous(), xp, api.default_opts(hessian=1))
+    assert torch.equal(xp, x[perm])
