@@ -404,7 +404,9 @@ extern "C" int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lo
 extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, int mode, double *d_f, double *d_g,
                               double *d_c, double *d_jband, double *d_cjac, void *stream)
 {
-	if (!p || !d_x) return fail(NTG_E_BADARG, "null plan or x");
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0) return 0;
+	if (!d_x) return fail(NTG_E_BADARG, "null x");
 	if (mode < 0 || mode > 2) return fail(NTG_E_BADARG, "mode must be 0, 1 or 2");
 	if (p->D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans evaluate through npsolCostFunction");
 	if (batch <= 0) return 0;
@@ -426,7 +428,9 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
                                double *d_clambda, void *d_work, long long work_bytes, void *stream)
 {
 	ntg_plan *p = const_cast<ntg_plan *>(pc);
-	if (!p || !d_x || !d_lower || !d_upper) return fail(NTG_E_BADARG, "null argument");
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0) return 0;
+	if (!d_x || !d_lower || !d_upper) return fail(NTG_E_BADARG, "null argument");
 	if (p->D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans are solved by ntg()");
 	if (!p->lin_ok) return fail(NTG_E_BADARG, "linear constraint rows are rank deficient");
 	if (batch <= 0) return 0;

@@ -86,8 +86,10 @@ def test_eval_empty_and_single():
     p = plan_for("B"); spec = p.spec
     out = p.eval(torch.empty((0, spec.nC), dtype=torch.float64, device="cuda:0"), 2)
     assert out["f"].shape[0] == 0
-    x = np.ones((1, spec.nC))
+    x = np.random.default_rng(2).normal(size=(1, spec.nC))
     assert rel(p.eval(dev(x), 2)["f"].cpu().numpy(), orc.eval_batch(spec, x, 2)["f"]) <= 1e-12
+    # all-ones coefficients: a constant spline, zero curvature cost up to rounding
+    assert abs(p.eval(dev(np.ones((1, spec.nC))), 2)["f"].item()) <= 1e-20
 
 
 def test_eval_linearity_property_large_batch():
