@@ -24,20 +24,36 @@
 // ------------------------------------------------------------------------------------------
 // reductions: sum K values over the workgroup, result broadcast to every lane
 // ------------------------------------------------------------------------------------------
+// 64-lane wavefront sum with DPP (row shifts + row broadcasts stay in the VALU; __shfl_down
+// would go through ds_bpermute, i.e. the LDS crossbar, ~100 cycles per hop).  The total lands
+// in lane 63 and is broadcast from there through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+	return v + __hiloint2double(hi, lo);   // disabled / out-of-row lanes contribute +0.0
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+	v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+	v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+	v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+	v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds its row total
+	v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+	v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	return __hiloint2double(hi, lo);
+}
+
 template <int NT, int K>
 __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 {
 	constexpr int NW = NT / 64;
 #pragma unroll
-	for (int k = 0; k < K; k++) {
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
-	}
-	if (NW == 1) {
-#pragma unroll
-		for (int k = 0; k < K; k++) v[k] = __shfl(v[k], 0, 64);
-		return;
-	}
+	for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+	if (NW == 1) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	__syncthreads(); // red[] may still be read by the previous call
 	if (lane == 0) {
@@ -53,6 +69,8 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 		v[k] = s;
 	}
 }
+
+__device__ int g_ntg_dbg = 0;   // diagnostic bit mask (tests/tools_*): 1 skip gradient gather, 2 skip phase 1, 4 skip block_sum
 
 // ------------------------------------------------------------------------------------------
 // PGS on the device.  The augmented knot vector is never materialised: t(idx) is read through
@@ -227,35 +245,107 @@ __global__ void bounds_kernel(NtgDims D, int batch, const double *__restrict__ l
 // LDS carve-up shared by eval_kernel and sqp_kernel
 // ------------------------------------------------------------------------------------------
 struct Smem {
-	double *blk; int *off; double *bps; int *ivl_lo, *ivl_hi;
+	double *blk; int *off; double *bps, *wts; int *ivl_lo, *ivl_hi;
 	double *x, *dfz, *fvals, *red, *dfi, *dff, *vecs, *lam, *rho, *c2;
-	__device__ __forceinline__ Smem(char *base, const SmemLayout &L)
+	// sparse linear-constraint operator: LDS copies when they fit, HBM/L2 otherwise
+	const int *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col; const double *csr_val, *csc_val, *sinv_val;
+	int *oinfo, *tavrow;   // per-output scalars and flag->row map in LDS (no per-lane kernarg gathers)
+	int *q_idx, *q_col; double *q_val;
+	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T)
 	{
 		blk = (double *)(base + L.blk); off = (int *)(base + L.off); bps = (double *)(base + L.bps);
+		wts = (double *)(base + L.wts);
 		ivl_lo = (int *)(base + L.ivl_lo); ivl_hi = (int *)(base + L.ivl_hi);
 		x = (double *)(base + L.x); dfz = (double *)(base + L.dfz); fvals = (double *)(base + L.fvals);
 		red = (double *)(base + L.red); dfi = (double *)(base + L.dfi); dff = (double *)(base + L.dff);
 		vecs = (double *)(base + L.vecs); lam = (double *)(base + L.lam); rho = (double *)(base + L.rho);
 		c2 = (double *)(base + L.c2);
+		if (D.lin_lds) {
+			csr_ptr = (const int *)(base + L.csr_ptr); csr_col = (const int *)(base + L.csr_col); csr_val = (const double *)(base + L.csr_val);
+			csc_ptr = (const int *)(base + L.csc_ptr); csc_row = (const int *)(base + L.csc_row); csc_val = (const double *)(base + L.csc_val);
+			sinv_ptr = (const int *)(base + L.sinv_ptr); sinv_col = (const int *)(base + L.sinv_col); sinv_val = (const double *)(base + L.sinv_val);
+		} else {
+			csr_ptr = T.csr_ptr; csr_col = T.csr_col; csr_val = T.csr_val;
+			csc_ptr = T.csc_ptr; csc_row = T.csc_row; csc_val = T.csc_val;
+			sinv_ptr = T.sinv_ptr; sinv_col = T.sinv_col; sinv_val = T.sinv_val;
+		}
+		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow);
+		q_idx = (int *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
 	}
 };
 
 template <int NT>
-__device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &T, const Smem &S)
+__device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &T, const Smem &S, char *base, const SmemLayout &L)
 {
-	for (int i = threadIdx.x; i < D.blk_total; i += NT) S.blk[i] = T.blk[i];
-	for (int i = threadIdx.x; i < D.nclass * D.P; i += NT) S.off[i] = T.off[i];
-	for (int i = threadIdx.x; i < D.P; i += NT) S.bps[i] = T.bps[i];
-	for (int i = threadIdx.x; i < D.ivl_total; i += NT) { S.ivl_lo[i] = T.ivl_lo[i]; S.ivl_hi[i] = T.ivl_hi[i]; }
+	const int tid = threadIdx.x;
+	for (int i = tid; i < D.blk_total; i += NT) S.blk[i] = T.blk[i];
+	for (int i = tid; i < D.nclass * D.P; i += NT) S.off[i] = T.off[i];
+	for (int i = tid; i < D.P; i += NT) {
+		S.bps[i] = T.bps[i];
+		// trapezoid weight of breakpoint i: integrator.c:21-24 regrouped per node
+		double w = 0.0;
+		if (i > 0) w += (T.bps[i] - T.bps[i - 1]) / 2;
+		if (i < D.P - 1) w += (T.bps[i + 1] - T.bps[i]) / 2;
+		S.wts[i] = w;
+	}
+	for (int i = tid; i < D.ivl_total; i += NT) { S.ivl_lo[i] = T.ivl_lo[i]; S.ivl_hi[i] = T.ivl_hi[i]; }
+	if (D.lin_lds) {
+		int *rp = (int *)(base + L.csr_ptr), *rc = (int *)(base + L.csr_col), *cp = (int *)(base + L.csc_ptr), *cr = (int *)(base + L.csc_row);
+		double *rv = (double *)(base + L.csr_val), *cv = (double *)(base + L.csc_val), *sv = (double *)(base + L.sinv_val);
+		int *sp_ = (int *)(base + L.sinv_ptr), *sc = (int *)(base + L.sinv_col);
+		for (int i = tid; i <= D.nclin; i += NT) rp[i] = T.csr_ptr[i];
+		for (int i = tid; i <= D.nC; i += NT) cp[i] = T.csc_ptr[i];
+		for (int i = tid; i < D.lin_nnz; i += NT) { rc[i] = T.csr_col[i]; rv[i] = T.csr_val[i]; cr[i] = T.csc_row[i]; cv[i] = T.csc_val[i]; }
+		for (int i = tid; i <= D.nclin; i += NT) sp_[i] = T.sinv_ptr[i];
+		for (int i = tid; i < D.sinv_nnz; i += NT) { sc[i] = T.sinv_col[i]; sv[i] = T.sinv_val[i]; }
+	}
+	// per-output scalars: k, m, l, d, iC, iz, class blk offset, class off offset, class ivl offset, ncoef
+	for (int o = tid; o < D.nout; o += NT) {
+		int *q = S.oinfo + o * 10;
+		q[0] = D.order[o]; q[1] = D.mult[o]; q[2] = D.ninterv[o]; q[3] = D.d[o]; q[4] = D.iC[o]; q[5] = D.iz[o];
+		q[6] = D.cls_blk[D.cls[o]]; q[7] = D.cls[o] * D.P; q[8] = D.cls_ivl[D.cls[o]]; q[9] = D.ncoef[o];
+	}
+	for (int v = tid; v < D.nz; v += NT) S.tavrow[v] = D.tav_row[v];
+	if (D.q_use) {
+		for (int i = tid; i < D.nC; i += NT) S.q_idx[i] = T.q_idx[i];
+		for (int i = tid; i < D.q_nt * D.q_w; i += NT) { S.q_col[i] = T.q_col[i]; S.q_val[i] = T.q_val[i]; }
+	}
 }
 
 // Z = M C at one breakpoint for the declared active variables (colloc.c:318-326,344-367);
 // entries that are not active stay 0 like the reference's calloc'd GZ (ntg.c:119).
-template <int NOUT>
+template <int NOUT, int K>
 __device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const double *sx, int bp,
                                           u64 mask, double *z)
 {
 	const int nout = NOUT > 0 ? NOUT : D.nout;
+	if (NOUT > 0 && K > 0 && D.uniform) {
+		// one basis class, compile-time order and maxderiv == 3: the breakpoint's block is read
+		// once into registers and reused by every output; all loops unroll
+		constexpr int KK = K > 0 ? K : 1;
+		double b[KK * 3];
+		const double *bp_blk = S.blk + (size_t)bp * KK * 3;
+#pragma unroll
+		for (int e = 0; e < KK * 3; e++) b[e] = bp_blk[e];
+		const int ofs = S.off[bp], nco = D.ncoef[0];
+#pragma unroll
+		for (int o = 0; o < (NOUT > 0 ? NOUT : 1); o++) {
+			const double *cx = sx + o * nco + ofs;
+			double xv[KK];
+#pragma unroll
+			for (int q = 0; q < KK; q++) xv[q] = cx[q];
+#pragma unroll
+			for (int r = 0; r < 3; r++) {
+				double acc = 0.0;
+				if ((mask >> (3 * o + r)) & 1ull) {
+#pragma unroll
+					for (int q = 0; q < KK; q++) acc += b[q * 3 + r] * xv[q];
+				}
+				z[3 * o + r] = acc;
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (int o = 0; o < nout; o++) {
 		const int k = D.order[o], c = D.cls[o];
@@ -283,7 +373,7 @@ __device__ __forceinline__ double band_dot(const double *b, int d, const double 
 }
 
 // per-breakpoint cost functor pass: Z = M C, then ucf/icf/fcf -> fvals, dfz, dfi, dff in LDS
-template <int FAM, int NOUT, int NT>
+template <int FAM, int NOUT, int K, int NT>
 __device__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
 {
 	constexpr int NZ = NOUT > 0 ? 3 * NOUT : NTG_MAX_NZ;
@@ -291,26 +381,27 @@ __device__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
 	const int tid = threadIdx.x;
 	using Fam = Family<FAM>;
 	__syncthreads(); // sx complete, previous users of dfz/fvals done
-	if (D.nucf) {
+	if (D.nucf && !(g_ntg_dbg & 2)) {
 		for (int i = tid; i < P; i += NT) {                       // cost.c:103-109
 			double z[NZ], df[NZ], f;
-			compute_z<NOUT>(D, S, sx, i, D.tcost_mask, z);
+			compute_z<NOUT, K>(D, S, sx, i, D.tcost_mask, z);
 			Fam::ucf(nout, i, z, f, df);
 			S.fvals[i] = f;
+			const double w = S.wts[i];
 #pragma unroll
-			for (int v = 0; v < NZ; v++) { if (v < nz) S.dfz[v * P + i] = df[v]; }
+			for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * P + i] = w * df[v]; }
 		}
 	}
 	if (D.nicf && tid == 0) {                                     // cost.c:4-36
 		double z[NZ], df[NZ], f;
-		compute_z<NOUT>(D, S, sx, 0, D.icost_mask, z);
+		compute_z<NOUT, K>(D, S, sx, 0, D.icost_mask, z);
 		Fam::icf(nout, z, f, df);
 		for (int v = 0; v < nz; v++) S.dfi[v] = df[v];
 		S.dfi[nz] = f;
 	}
 	if (D.nfcf && tid == (NT > 64 ? 64 : 0)) {                    // cost.c:141-174
 		double z[NZ], df[NZ], f;
-		compute_z<NOUT>(D, S, sx, P - 1, D.fcost_mask, z);
+		compute_z<NOUT, K>(D, S, sx, P - 1, D.fcost_mask, z);
 		Fam::fcf(nout, z, f, df);
 		for (int v = 0; v < nz; v++) S.dff[v] = df[v];
 		S.dff[nz] = f;
@@ -319,7 +410,7 @@ __device__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
 
 // quadrature + banded gradient assembly from the per-breakpoint values in LDS (fvals, dfz,
 // dfi, dff); shared by the device-functor path and the host-callback path of ntg()
-template <int NOUT, int NT>
+template <int NOUT, int K, int NT>
 __device__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2)
 {
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
@@ -331,35 +422,68 @@ __device__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, doubl
 	if (D.nucf)
 		for (int i = tid; i < P - 1; i += NT)
 			acc[0] += (S.bps[i + 1] - S.bps[i]) * (S.fvals[i + 1] + S.fvals[i]) / 2;
-	// gradient: one coefficient per lane, band gather + sequential trapezoid in the reference's
-	// order (cost.c:117-134, integrator.c:44-48); structural zeros are skipped
+	// gradient: one coefficient per lane gathers its band.  The reference integrates the dense
+	// nbps x nC matrix column by column (cost.c:117-134, integrator.c:44-48); the same sum is
+	// taken here node-wise, sum_i w_i G_i(c), over the breakpoints whose block covers c only
+	const int dbg = g_ntg_dbg;
 	for (int c = tid; c < D.nC; c += NT) {
-		int o = 0;
-		while (o + 1 < nout && D.iC[o + 1] <= c) o++;
-		const int cl = c - D.iC[o], k = D.order[o], m = D.mult[o], km = k - m, cc = D.cls[o];
-		const int d = NOUT > 0 ? 3 : D.d[o], iz = NOUT > 0 ? 3 * o : D.iz[o];
-		const double *cb = S.blk + D.cls_blk[cc];
-		const int *coff = S.off + cc * P;
+		if (dbg & 1) { sg[c] = 0.0; continue; }
+		int o;
+		if (D.uniform) o = c / D.ncoef[0];
+		else { o = 0; while (o + 1 < nout && S.oinfo[(o + 1) * 10 + 4] <= c) o++; }
+		const int *oi = S.oinfo + (D.uniform ? 0 : o) * 10;   // uniform: every output shares k, m, l, class
+		const int k = oi[0], m = oi[1], km = k - m, nint = oi[2];
+		const int d = NOUT > 0 ? 3 : oi[3], iz = NOUT > 0 ? 3 * o : S.oinfo[o * 10 + 5];
+		const int cl = c - (D.uniform ? o * D.ncoef[0] : S.oinfo[o * 10 + 4]);
+		const double *cb = S.blk + oi[6];
+		const int *coff = S.off + oi[7];
+		const int ivb = oi[8];
 		double dI = 0.0, dIn = 0.0, dF = 0.0;
 		if (D.nucf) {
 			const int jlo = (cl - k + 1 <= 0) ? 0 : (cl - k + 1 + km - 1) / km;
-			const int jhi = min(D.ninterv[o] - 1, cl / km);
-			if (jlo <= jhi) {
-				const int ifirst = S.ivl_lo[D.cls_ivl[cc] + jlo], ilast = S.ivl_hi[D.cls_ivl[cc] + jhi];
-				if (ifirst <= ilast) {
-					const int ia = max(ifirst - 1, 0), ib = min(ilast, P - 2);
-					auto G = [&](int i) -> double {
-						if (i < ifirst || i > ilast) return 0.0;
-						const double *b = cb + ((size_t)i * k + (cl - coff[i])) * d;
-						double a2 = 0.0;
-						for (int r = 0; r < d; r++) a2 += S.dfz[(iz + r) * P + i] * b[r];
-						return a2;
-					};
-					double gprev = G(ia);
-					for (int i = ia; i <= ib; i++) {
-						const double gnext = G(i + 1);
-						dIn += (S.bps[i + 1] - S.bps[i]) * (gnext + gprev) / 2;
-						gprev = gnext;
+			const int jhi = min(nint - 1, cl / km);
+			const int stride = k * d;
+			// breakpoints of one knot interval share the block offset j*km, so the band entry of
+			// coefficient c is column q = cl - j*km of every block in the interval.  The gather is
+			// written with fixed trip counts and clamped indices (weight 0 when out of range) so
+			// that all LDS reads of a coefficient are independent and issue back to back.
+			constexpr int MAXJ = 4, MAXI = 8;
+			if (D.max_bpi <= MAXI && k <= MAXJ * km) {
+				for (int r = 0; r < d; r++) {
+					if (!((D.tav_rmask >> r) & 1)) continue;       // uniform: no output has a cost AV on D^r
+					const int row = S.tavrow[iz + r];
+					const double *wdf = S.dfz + max(row, 0) * P;
+					const double on_r = row >= 0 ? 1.0 : 0.0;
+#pragma unroll
+					for (int jj = 0; jj < MAXJ; jj++) {
+						if (jj * km >= k) break;                   // uniform: at most ceil(k/km) intervals overlap
+						const int j = min(jlo + jj, nint - 1);
+						const bool jon = jlo + jj <= jhi;
+						const int i0 = S.ivl_lo[ivb + j], i1 = S.ivl_hi[ivb + j];
+						const double *bq = cb + (size_t)max(cl - j * km, 0) * d + r;
+						double wv[MAXI], bv[MAXI];
+#pragma unroll
+						for (int ii = 0; ii < MAXI; ii++) {
+							const int i = min(i0 + ii, P - 1);
+							wv[ii] = wdf[i];
+							bv[ii] = bq[(size_t)i * stride];
+						}
+#pragma unroll
+						for (int ii = 0; ii < MAXI; ii++)
+							dIn += ((jon && i0 + ii <= i1) ? on_r : 0.0) * wv[ii] * bv[ii];
+					}
+				}
+			} else {
+				for (int j = jlo; j <= jhi; j++) {
+					const int i0 = S.ivl_lo[ivb + j], i1 = S.ivl_hi[ivb + j];
+					const int q = cl - j * km;
+					for (int r = 0; r < d; r++) {
+						const int row = S.tavrow[iz + r];
+						if (row < 0) continue;
+						const double *wdf = S.dfz + row * P;
+						const double *bq = cb + (size_t)q * d + r;
+#pragma unroll 4
+						for (int i = i0; i <= i1; i++) dIn += wdf[i] * bq[(size_t)i * stride];
 					}
 				}
 			}
@@ -379,7 +503,7 @@ __device__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, doubl
 		sg[c] = g;
 		acc[1] += g * g;
 	}
-	block_sum<NT, 2>(acc, S.red);
+	if (!(dbg & 4)) block_sum<NT, 2>(acc, S.red);
 	const double I = D.nicf ? S.dfi[nz] : 0.0, Ff = D.nfcf ? S.dff[nz] : 0.0;
 	*gnorm2 = acc[1];
 	return I + acc[0] + Ff;                                       // ntg.c:328
@@ -387,16 +511,22 @@ __device__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, doubl
 
 // NPfunobj (ntg.c:274-335): F and the full gradient into LDS vector sg.  Returns F; *gnorm2
 // receives |g|^2.  Every lane of the workgroup must call it (it contains barriers).
-template <int FAM, int NOUT, int NT>
-__device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2)
+template <int FAM, int NOUT, int K, int NT>
+__device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
+                                            unsigned long long *tk = nullptr)
 {
-	cost_phase1<FAM, NOUT, NT>(D, S, sx);
-	return cost_phase2<NOUT, NT>(D, S, sg, gnorm2);
+	unsigned long long t0 = 0;
+	if (tk) t0 = __builtin_amdgcn_s_memtime();
+	cost_phase1<FAM, NOUT, K, NT>(D, S, sx);
+	if (tk) { __syncthreads(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
+	const double F = cost_phase2<NOUT, K, NT>(D, S, sg, gnorm2);
+	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
+	return F;
 }
 
 // NPfuncon (ntg.c:337-371, constraints.c:36-195): residuals and banded Jacobian rows straight
 // to HBM.  Row order [initial; trajectory constraint-major x breakpoint; final].
-template <int FAM, int NOUT, int NT>
+template <int FAM, int NOUT, int K, int NT>
 __device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *sx, int mode,
                                  double *c_out, double *jband, double *cjac)
 {
@@ -419,7 +549,7 @@ __device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *
 	};
 	if (Fam::NNLIC > 0 && D.nnlic && tid == 0) {
 		double z[NZ], c[NI], dc[NI * NZ];
-		compute_z<NOUT>(D, S, sx, 0, D.icon_mask, z);
+		compute_z<NOUT, K>(D, S, sx, 0, D.icon_mask, z);
 		Fam::nlicf(nout, z, c, dc);
 		for (int j = 0; j < D.nnlic; j++) {
 			if (c_out && mode != 1) c_out[j] = c[j];
@@ -429,7 +559,7 @@ __device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *
 	if (Fam::NNLTC > 0 && D.nnltc) {
 		for (int i = tid; i < P; i += NT) {
 			double z[NZ], c[NTc], dc[NTc * NZ];
-			compute_z<NOUT>(D, S, sx, i, D.tcon_mask, z);
+			compute_z<NOUT, K>(D, S, sx, i, D.tcon_mask, z);
 			Fam::nltcf(nout, i, z, c, dc);
 			for (int j = 0; j < D.nnltc; j++) {
 				const int row = D.nnlic + j * P + i;              // constraints.c:139,153
@@ -440,7 +570,7 @@ __device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *
 	}
 	if (Fam::NNLFC > 0 && D.nnlfc && tid == (NT > 64 ? 64 : 0)) {
 		double z[NZ], c[NF], dc[NF * NZ];
-		compute_z<NOUT>(D, S, sx, P - 1, D.fcon_mask, z);
+		compute_z<NOUT, K>(D, S, sx, P - 1, D.fcon_mask, z);
 		Fam::nlfcf(nout, z, c, dc);
 		for (int j = 0; j < D.nnlfc; j++) {
 			const int row = D.nnlic + D.nnltc * P + j;
@@ -451,26 +581,26 @@ __device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *
 }
 
 // Persistent workgroups stride over the batch; tables are staged once per workgroup.
-template <int FAM, int NOUT, int NT>
+template <int FAM, int NOUT, int K, int NT>
 __global__ void __launch_bounds__(NT)
 eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const double *__restrict__ x,
             double *__restrict__ f, double *__restrict__ g, double *__restrict__ c,
             double *__restrict__ jband, double *__restrict__ cjac)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	Smem S(smem_raw, L);
-	stage_tables<NT>(D, T, S);
+	Smem S(smem_raw, L, D, T);
+	stage_tables<NT>(D, T, S, smem_raw, L);
 	double *sg = S.vecs;
 	for (int b = blockIdx.x; b < batch; b += gridDim.x) {
 		__syncthreads();
 		for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
 		double gn2;
-		const double F = eval_cost<FAM, NOUT, NT>(D, S, S.x, sg, &gn2);
+		const double F = eval_cost<FAM, NOUT, K, NT>(D, S, S.x, sg, &gn2);
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
 		if (g && mode != 0)
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
 		if (D.ncnln && (c || jband || cjac))
-			eval_constraints<FAM, NOUT, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
+			eval_constraints<FAM, NOUT, K, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
 			                                jband ? jband + (size_t)b * D.ncnln * D.sumk : nullptr,
 			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr);
 	}
@@ -479,41 +609,45 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 // ------------------------------------------------------------------------------------------
 // SQP pieces
 // ------------------------------------------------------------------------------------------
-// gp = g - A'(AA')^-1 A g  (projection onto null(A)); lam receives the multipliers estimate.
+// gp = g - A'(AA')^-1 A g  (projection onto null(A)); S.lam receives the multipliers estimate.
+// A is kept sparse (CSR for A g, CSC for A' lam); (AA')^-1 is a small dense matrix.
 template <int NT>
-__device__ void project(const NtgDims &D, const NtgTables &T, const Smem &S, const double *sg,
-                        double *sgp, double *tmp /* LDS [2*nclin] */)
+__device__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */)
 {
-	const int m = D.nclin, tid = threadIdx.x, P = D.P;
+	const int m = D.nclin, tid = threadIdx.x;
 	__syncthreads();
 	if (m == 0) { for (int c = tid; c < D.nC; c += NT) sgp[c] = sg[c]; __syncthreads(); return; }
-	for (int r = tid; r < m; r += NT) {
-		const int bp = T.rbp[r];
-		double a = 0.0;
-		for (int o = 0; o < D.nout; o++) {
-			const double *row = T.aband + (size_t)r * D.sumk + D.koff[o];
-			const double *v = sg + D.iC[o] + S.off[D.cls[o] * P + bp];
-			for (int q = 0; q < D.order[o]; q++) a += row[q] * v[q];
+	if (D.q_use) {
+		// gp = g - Q g with Q = A'(AA')^-1 A stored as ELL over its non-zero rows: one pass, no
+		// intermediate barrier; the padded entries (value 0, column 0) keep every load unconditional
+		const int w = D.q_w;
+		for (int c = tid; c < D.nC; c += NT) {
+			const int t = S.q_idx[c];
+			double s = 0.0;
+			if (t >= 0) {
+#pragma unroll 4
+				for (int e = 0; e < w; e++) s += S.q_val[t * w + e] * sg[S.q_col[t * w + e]];
+			}
+			sgp[c] = sg[c] - s;
 		}
+		__syncthreads();
+		return;
+	}
+	for (int r = tid; r < m; r += NT) {
+		double a = 0.0;
+		for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
 		tmp[r] = a;
 	}
 	__syncthreads();
 	for (int r = tid; r < m; r += NT) {
 		double a = 0.0;
-		for (int j = 0; j < m; j++) a += T.sinv[(size_t)r * m + j] * tmp[j];
+		for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
 		S.lam[r] = a;
 	}
 	__syncthreads();
 	for (int c = tid; c < D.nC; c += NT) {
-		int o = 0;
-		while (o + 1 < D.nout && D.iC[o + 1] <= c) o++;
-		const int cl = c - D.iC[o], k = D.order[o];
-		const int *coff = S.off + D.cls[o] * P;
 		double s = 0.0;
-		for (int r = 0; r < m; r++) {
-			const int ofr = coff[T.rbp[r]];
-			if (cl >= ofr && cl < ofr + k) s += T.aband[(size_t)r * D.sumk + D.koff[o] + cl - ofr] * S.lam[r];
-		}
+		for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * S.lam[S.csc_row[e]];
 		sgp[c] = sg[c] - s;
 	}
 	__syncthreads();
@@ -536,13 +670,54 @@ __device__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, cons
 	__syncthreads();
 }
 
-// t += (sum of the stored rank-2 BFGS terms) v.  Pairs are streamed from HBM/L2, 4 at a time:
-// 8 partial dots per lane, one workgroup reduction, then the axpys.
+// t += (sum of the stored rank-2 BFGS terms) v.  Pairs are streamed from HBM/L2 once, G at a
+// time: 2G partial dots per lane, ONE workgroup reduction, then the axpys from the registers
+// that still hold the pair elements.
 template <int NT>
 __device__ void apply_history(const NtgDims &D, const Smem &S, const double *hist, int npairs,
                               const double *v, double *t)
 {
+	constexpr int G = 8, EPT = 4;
 	const int n = D.nC, tid = threadIdx.x;
+	if (n <= EPT * NT) {
+		double vv[EPT], tt[EPT];
+#pragma unroll
+		for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; vv[e] = c < n ? v[c] : 0.0; tt[e] = c < n ? t[c] : 0.0; }
+		for (int base = 0; base < npairs; base += G) {
+			const int cnt = min(G, npairs - base);
+			double hs[G][EPT], hu[G][EPT], acc[2 * G];
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				acc[2 * g] = 0.0; acc[2 * g + 1] = 0.0;
+				const double *h = hist + (size_t)(base + g) * 2 * n;
+#pragma unroll
+				for (int e = 0; e < EPT; e++) {
+					const int c = tid + e * NT;
+					const bool on = g < cnt && c < n;
+					hs[g][e] = on ? h[c] : 0.0;
+					hu[g][e] = on ? h[n + c] : 0.0;
+				}
+			}
+#pragma unroll
+			for (int g = 0; g < G; g++)
+#pragma unroll
+				for (int e = 0; e < EPT; e++) { acc[2 * g] += hs[g][e] * vv[e]; acc[2 * g + 1] += hu[g][e] * vv[e]; }
+			block_sum<NT, 2 * G>(acc, S.red);
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				if (g < cnt) {
+					const double rho = S.rho[base + g], c2 = S.c2[base + g];
+#pragma unroll
+					for (int e = 0; e < EPT; e++)
+						tt[e] += -rho * (hs[g][e] * acc[2 * g + 1] + hu[g][e] * acc[2 * g]) + c2 * hs[g][e] * acc[2 * g];
+				}
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; if (c < n) t[c] = tt[e]; }
+		__syncthreads();
+		return;
+	}
 	for (int base = 0; base < npairs; base += 4) {
 		const int cnt = min(4, npairs - base);
 		double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -575,7 +750,7 @@ __device__ void apply_history(const NtgDims &D, const Smem &S, const double *his
 }
 
 // One workgroup solves one problem from start to finish (ntg.c:250: the npsol_ call).
-template <int FAM, int NOUT, int NT>
+template <int FAM, int NOUT, int K, int NT>
 __global__ void __launch_bounds__(NT)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
@@ -583,18 +758,22 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            int *__restrict__ nfev_out, double *__restrict__ clambda, double *__restrict__ hist_all)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	Smem S(smem_raw, L);
+	Smem S(smem_raw, L, D, T);
 	const int b = blockIdx.x, tid = threadIdx.x, n = D.nC, m = D.nclin, P = D.P;
 	if (b >= batch) return;
 	const int npad = (n + 1) & ~1;
 	double *sx = S.x, *sxt = S.vecs, *sgp = S.vecs + npad, *sgpt = S.vecs + 2 * npad, *sd = S.vecs + 3 * npad,
 	       *st = S.vecs + 4 * npad, *sg = S.vecs + 5 * npad, *tmp = S.vecs + 6 * npad;
 	double *hist = hist_all + (size_t)b * sp.memcap * 2 * n;
-	stage_tables<NT>(D, T, S);
+	stage_tables<NT>(D, T, S, smem_raw, L);
 	for (int i = tid; i < n; i += NT) sx[i] = xio[(size_t)b * n + i];
 	__syncthreads();
 
 	int inform = 4, iter = 0, nfev = 0, npairs = 0;
+	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history / rest
+	unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define NTG_STAMP(slot) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot] += now_ - tlast; tlast = now_; } } while (0)
+	if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
 	// ---- scope check (uniform): linear equalities only ----
 	{
 		double bad[1] = {0.0};
@@ -608,49 +787,42 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
 		if (m > 0) {
 			for (int r = tid; r < m; r += NT) {
-				const int bp = T.rbp[r];
 				int s;
 				if (r < D.nlic) s = r;
 				else if (r < D.nlic + D.nltc * P) s = D.nlic + (r - D.nlic) / P;
 				else s = D.nlic + D.nltc + (r - D.nlic - D.nltc * P);
 				double a = 0.0;
-				for (int o = 0; o < D.nout; o++) {
-					const double *row = T.aband + (size_t)r * D.sumk + D.koff[o];
-					const double *v = sx + D.iC[o] + S.off[D.cls[o] * P + bp];
-					for (int q = 0; q < D.order[o]; q++) a += row[q] * v[q];
-				}
+				for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sx[S.csr_col[e]];
 				tmp[r] = lower[(size_t)b * D.nbounds + s] - a;
 			}
 			__syncthreads();
 			for (int r = tid; r < m; r += NT) {
 				double a = 0.0;
-				for (int j = 0; j < m; j++) a += T.sinv[(size_t)r * m + j] * tmp[j];
+				for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
 				S.lam[r] = a;
 			}
 			__syncthreads();
 			for (int c = tid; c < n; c += NT) {
-				int o = 0;
-				while (o + 1 < D.nout && D.iC[o + 1] <= c) o++;
-				const int cl = c - D.iC[o], k = D.order[o];
-				const int *coff = S.off + D.cls[o] * P;
 				double s = 0.0;
-				for (int r = 0; r < m; r++) {
-					const int ofr = coff[T.rbp[r]];
-					if (cl >= ofr && cl < ofr + k) s += T.aband[(size_t)r * D.sumk + D.koff[o] + cl - ofr] * S.lam[r];
-				}
+				for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * S.lam[S.csc_row[e]];
 				sx[c] += s;
 			}
 			__syncthreads();
 		}
-		F = eval_cost<FAM, NOUT, NT>(D, S, sx, sg, &gn2); nfev++;
-		project<NT>(D, T, S, sg, sgp, tmp);
+		NTG_STAMP(0);
+		F = eval_cost<FAM, NOUT, K, NT>(D, S, sx, sg, &gn2); nfev++;
+		NTG_STAMP(1);
+		project<NT>(D, S, sg, sgp, tmp);
+		NTG_STAMP(2);
 		apply_w0<NT>(D, T, sp.hessian, sgp, sd);
+		NTG_STAMP(4);
 
 		LineSearch ls;
+		// carried across iterations: gp.d, d.d, x.x, gp.gp (refreshed by the update's reduction)
+		double r4[4] = {0, 0, 0, 0};
+		for (int c = tid; c < n; c += NT) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; }
+		block_sum<NT, 4>(r4, S.red);
 		for (iter = 0; iter < sp.itlim; iter++) {
-			double r4[4] = {0, 0, 0, 0};
-			for (int c = tid; c < n; c += NT) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; }
-			block_sum<NT, 4>(r4, S.red);
 			double dphi0 = -r4[0];
 			pnorm = sqrt(r4[1]);
 			const double xnorm = sqrt(r4[2]), gpnorm = sqrt(r4[3]), gnorm = sqrt(gn2);
@@ -674,8 +846,11 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			for (;;) {
 				const double a = ls.a;
 				for (int c = tid; c < n; c += NT) sxt[c] = sx[c] + a * (-sd[c]);
-				Fn = eval_cost<FAM, NOUT, NT>(D, S, sxt, sg, &gn2n); nfev++;
-				project<NT>(D, T, S, sg, sgpt, tmp);
+				NTG_STAMP(5);
+				Fn = eval_cost<FAM, NOUT, K, NT>(D, S, sxt, sg, &gn2n, sp.stamps ? tk : nullptr); nfev++;
+				NTG_STAMP(1);
+				project<NT>(D, S, sg, sgpt, tmp);
+				NTG_STAMP(2);
 				double dd[1] = {0.0};
 				for (int c = tid; c < n; c += NT) dd[0] += sgpt[c] * (-sd[c]);
 				block_sum<NT, 1>(dd, S.red);
@@ -684,8 +859,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				if (rc == 2) {
 					const double a2 = ls.a;
 					for (int c = tid; c < n; c += NT) sxt[c] = sx[c] + a2 * (-sd[c]);
-					Fn = eval_cost<FAM, NOUT, NT>(D, S, sxt, sg, &gn2n); nfev++;
-					project<NT>(D, T, S, sg, sgpt, tmp);
+					Fn = eval_cost<FAM, NOUT, K, NT>(D, S, sxt, sg, &gn2n); nfev++;
+					project<NT>(D, S, sg, sgpt, tmp);
 					rc = 1;
 					break;
 				}
@@ -695,8 +870,11 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			// accept: x <- xt ; t = W gp+ ; u = t - d ; BFGS pair (s, u) to HBM
 			for (int c = tid; c < n; c += NT) sg[c] = alpha * (-sd[c]);      // the step s (sg is free here)
 			if (npairs == sp.memcap) { npairs = 0; apply_w0<NT>(D, T, sp.hessian, sgp, sd); } // memory full: restart
+			NTG_STAMP(5);
 			apply_w0<NT>(D, T, sp.hessian, sgpt, st);
+			NTG_STAMP(4);
 			apply_history<NT>(D, S, hist, npairs, sgpt, st);
+			NTG_STAMP(3);
 			double r6[6] = {0, 0, 0, 0, 0, 0};
 			for (int c = tid; c < n; c += NT) {
 				const double s = sg[c], y = sgpt[c] - sgp[c], u = st[c] - sd[c], gpn = sgpt[c];
@@ -705,33 +883,55 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			block_sum<NT, 6>(r6, S.red);
 			const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
 			const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
-			double r2[2] = {0, 0};
+			r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
 			for (int c = tid; c < n; c += NT) {
 				const double s = sg[c], u = st[c] - sd[c];
 				if (upd) { hist[(size_t)npairs * 2 * n + c] = s; hist[(size_t)npairs * 2 * n + n + c] = u; }
 				const double dn = upd ? st[c] - rho * (s * r6[3] + u * r6[2]) + c2 * s * r6[2] : st[c];
-				sx[c] = sxt[c];
-				sgp[c] = sgpt[c];
+				const double xn = sxt[c], gq = sgpt[c];
+				sx[c] = xn;
+				sgp[c] = gq;
 				sd[c] = dn;
-				r2[0] += sxt[c] * sxt[c]; r2[1] += sgpt[c] * sgpt[c];
+				r4[0] += gq * dn; r4[1] += dn * dn; r4[2] += xn * xn; r4[3] += gq * gq;
 			}
 			if (upd) {
 				if (tid == 0) { S.rho[npairs] = rho; S.c2[npairs] = c2; }
 				npairs++;
 			}
-			block_sum<NT, 2>(r2, S.red);   // also orders the hist/rho writes before their next use
+			block_sum<NT, 4>(r4, S.red);   // also orders the hist/rho writes before their next use
 			F = Fn; gn2 = gn2n;
-			if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r2[0])) &&
-			    sqrt(r2[1]) <= sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inform = 0; iter++; break; }
+			if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r4[2])) &&
+			    sqrt(r4[3]) <= sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inform = 0; iter++; break; }
 		}
 	}
 	__syncthreads();
 	for (int i = tid; i < n; i += NT) xio[(size_t)b * n + i] = sx[i];
+	NTG_STAMP(5);
+	if (clambda && inform != 9 && D.q_use && m > 0) {
+		// multipliers estimate lam = (AA')^-1 A g at the final point (the Q form does not produce it)
+		double gn2f;
+		(void)eval_cost<FAM, NOUT, K, NT>(D, S, sx, sg, &gn2f);
+		__syncthreads();
+		for (int r = tid; r < m; r += NT) {
+			double a = 0.0;
+			for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
+			tmp[r] = a;
+		}
+		__syncthreads();
+		for (int r = tid; r < m; r += NT) {
+			double a = 0.0;
+			for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
+			S.lam[r] = a;
+		}
+		__syncthreads();
+	}
 	if (clambda) {
 		const int ntot = n + m + D.ncnln;
 		for (int i = tid; i < ntot; i += NT)
 			clambda[(size_t)b * ntot + i] = (inform != 9 && i >= n && i < n + m) ? S.lam[i - n] : 0.0;
+		if (sp.stamps && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
 	}
+#undef NTG_STAMP
 	if (tid == 0) {
 		if (objective) objective[b] = F;
 		if (inform_out) inform_out[b] = inform;
@@ -752,15 +952,15 @@ hostz_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__ x,
              u64 maskF, double *__restrict__ Z)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	Smem S(smem_raw, L);
-	stage_tables<NT>(D, T, S);
+	Smem S(smem_raw, L, D, T);
+	stage_tables<NT>(D, T, S, smem_raw, L);
 	for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[i];
 	__syncthreads();
 	for (int i = threadIdx.x; i < D.P; i += NT) {
 		const u64 mask = maskT | (i == 0 ? maskI : 0ull) | (i == D.P - 1 ? maskF : 0ull);
 		if (!mask) continue;
 		double z[NTG_MAX_NZ];
-		compute_z<0>(D, S, S.x, i, mask, z);
+		compute_z<0, 0>(D, S, S.x, i, mask, z);
 		for (int o = 0; o < D.nout; o++)
 			for (int r = 0; r < D.d[o]; r++)
 				if ((mask >> (D.iz[o] + r)) & 1ull) Z[(size_t)D.iz[o] * D.P + (size_t)D.d[o] * i + r] = z[D.iz[o] + r];
@@ -775,14 +975,15 @@ hostcost_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__
                 const double *__restrict__ fdF, double *__restrict__ F, double *__restrict__ g)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	Smem S(smem_raw, L);
-	stage_tables<NT>(D, T, S);
+	Smem S(smem_raw, L, D, T);
+	stage_tables<NT>(D, T, S, smem_raw, L);
 	const int P = D.P, nz = D.nz;
 	for (int i = threadIdx.x; i < P; i += NT) S.fvals[i] = D.nucf ? fT[i] : 0.0;
-	for (int e = threadIdx.x; e < P * nz; e += NT) { const int i = e / nz, v = e % nz; S.dfz[v * P + i] = D.nucf ? dfT[e] : 0.0; }
+	__syncthreads();
+	for (int e = threadIdx.x; e < P * nz; e += NT) { const int i = e / nz, v = e % nz; if (D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * P + i] = D.nucf ? S.wts[i] * dfT[e] : 0.0; }
 	for (int v = threadIdx.x; v <= nz; v += NT) { S.dfi[v] = D.nicf ? fdI[v] : 0.0; S.dff[v] = D.nfcf ? fdF[v] : 0.0; }
 	double gn2;
-	const double val = cost_phase2<0, NT>(D, S, S.vecs, &gn2);
+	const double val = cost_phase2<0, 0, NT>(D, S, S.vecs, &gn2);
 	if (threadIdx.x == 0) *F = val;
 	for (int i = threadIdx.x; i < D.nC; i += NT) g[i] = S.vecs[i];
 }
@@ -850,71 +1051,96 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int memcap)
 	L.blk = p; p = align16(p + D.blk_total * 8);
 	L.off = p; p = align16(p + D.nclass * D.P * 4);
 	L.bps = p; p = align16(p + D.P * 8);
+	L.wts = p; p = align16(p + D.P * 8);
 	L.ivl_lo = p; p = align16(p + D.ivl_total * 4);
 	L.ivl_hi = p; p = align16(p + D.ivl_total * 4);
 	L.x = p; p = align16(p + npad * 8);
-	L.dfz = p; p = align16(p + D.nz * D.P * 8);
+	L.dfz = p; p = align16(p + (D.ntav > 0 ? D.ntav : 1) * D.P * 8);
 	L.fvals = p; p = align16(p + D.P * 8);
-	L.red = p; p = align16(p + 8 * (nthreads / 64 + 1) * 8);
+	L.red = p; p = align16(p + 16 * (nthreads / 64 + 1) * 8);
 	L.dfi = p; p = align16(p + (D.nz + 1) * 8);
 	L.dff = p; p = align16(p + (D.nz + 1) * 8);
 	L.vecs = p; p = align16(p + (nvec * npad + 2 * D.nclin + 2) * 8);
 	L.lam = p; p = align16(p + (D.nclin + 1) * 8);
 	L.rho = p; p = align16(p + (memcap + 1) * 8);
 	L.c2 = p; p = align16(p + (memcap + 1) * 8);
+	L.oinfo = p; p = align16(p + NTG_MAX_OUT * 10 * 4);
+	L.tavrow = p; p = align16(p + NTG_MAX_NZ * 4);
+	L.q_idx = L.q_col = L.q_val = p;
+	if (D.q_use) {
+		L.q_idx = p; p = align16(p + D.nC * 4);
+		L.q_col = p; p = align16(p + D.q_nt * D.q_w * 4);
+		L.q_val = p; p = align16(p + D.q_nt * D.q_w * 8);
+	}
+	L.csr_ptr = L.csr_col = L.csr_val = L.csc_ptr = L.csc_row = L.csc_val = L.sinv_ptr = L.sinv_col = L.sinv_val = p;
+	if (D.lin_lds) {
+		L.csr_ptr = p; p = align16(p + (D.nclin + 1) * 4);
+		L.csr_col = p; p = align16(p + D.lin_nnz * 4);
+		L.csr_val = p; p = align16(p + D.lin_nnz * 8);
+		L.csc_ptr = p; p = align16(p + (D.nC + 1) * 4);
+		L.csc_row = p; p = align16(p + D.lin_nnz * 4);
+		L.csc_val = p; p = align16(p + D.lin_nnz * 8);
+		L.sinv_ptr = p; p = align16(p + (D.nclin + 1) * 4);
+		L.sinv_col = p; p = align16(p + D.sinv_nnz * 4);
+		L.sinv_val = p; p = align16(p + D.sinv_nnz * 8);
+	}
 	L.total = p;
 	return L;
 }
 
-template <int FAM, int NOUT>
+template <int FAM, int NOUT, int K>
 static hipError_t launch_eval_nt(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, int grid,
                                  int batch, int mode, const double *x, double *f, double *g, double *c,
                                  double *jb, double *cj, hipStream_t st)
 {
 #define NTG_EV(NTV)                                                                                         \
 	{                                                                                                       \
-		auto kfn = eval_kernel<FAM, NOUT, NTV>;                                                             \
+		auto kfn = eval_kernel<FAM, NOUT, K, NTV>;                                                          \
 		if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total); \
 		hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTV), L.total, st, D, T, L, batch, mode, x, f, g, c, jb, cj); \
 	}
-	if (nt == 64) NTG_EV(64) else if (nt == 128) NTG_EV(128) else NTG_EV(256)
+	if (nt == 128) NTG_EV(128) else NTG_EV(256)
 #undef NTG_EV
 	return hipGetLastError();
 }
 
-template <int FAM, int NOUT>
+template <int FAM, int NOUT, int K>
 static hipError_t launch_sqp_nt(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L,
                                 const SolveParams &sp, int batch, const double *lo, const double *up, double *x,
                                 double *obj, int *inf, int *it, int *nf, double *cl, double *hist, hipStream_t st)
 {
 #define NTG_SQ(NTV)                                                                                         \
 	{                                                                                                       \
-		auto kfn = sqp_kernel<FAM, NOUT, NTV>;                                                              \
+		auto kfn = sqp_kernel<FAM, NOUT, K, NTV>;                                                           \
 		if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total); \
 		hipLaunchKernelGGL(kfn, dim3(batch), dim3(NTV), L.total, st, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist); \
 	}
-	if (nt == 64) NTG_SQ(64) else if (nt == 128) NTG_SQ(128) else NTG_SQ(256)
+	if (nt == 128) NTG_SQ(128) else NTG_SQ(256)
 #undef NTG_SQ
 	return hipGetLastError();
 }
 
-// (family, nout) dispatch: compile-time nout keeps the flat flag in registers; NOUT = 0 is the
-// generic path (runtime nout, any maxderiv)
+// (family, nout, order) dispatch: compile-time nout and order keep the flat flag and the basis
+// block in registers and let every inner loop unroll; <FAM, 0, 0> is the generic path
+// (runtime nout/order, any maxderiv)
 #define NTG_DISPATCH(CALL)                                                                      \
 	const bool d3 = [&] { for (int o = 0; o < D.nout; o++) if (D.d[o] != 3) return false; return true; }(); \
-	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 2) return CALL(NTG_FAM_KINCAR, 2);          \
-	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 6) return CALL(NTG_FAM_KINCAR, 6);          \
-	if (D.family == NTG_FAM_KINCAR) return CALL(NTG_FAM_KINCAR, 0);                               \
-	if (D.family == NTG_FAM_VANDERPOL && d3 && D.nout == 1) return CALL(NTG_FAM_VANDERPOL, 1);    \
-	if (D.family == NTG_FAM_TESTFAM && d3 && D.nout == 3) return CALL(NTG_FAM_TESTFAM, 3);        \
-	if (D.family == NTG_FAM_TESTFAM) return CALL(NTG_FAM_TESTFAM, 0);                             \
+	const int ku = D.uniform ? D.order[0] : 0;                                                   \
+	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 2 && ku == 6) return CALL(NTG_FAM_KINCAR, 2, 6); \
+	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 6 && ku == 6) return CALL(NTG_FAM_KINCAR, 6, 6); \
+	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 2 && ku == 5) return CALL(NTG_FAM_KINCAR, 2, 5); \
+	if (D.family == NTG_FAM_KINCAR) return CALL(NTG_FAM_KINCAR, 0, 0);                            \
+	if (D.family == NTG_FAM_VANDERPOL && d3 && ku == 5) return CALL(NTG_FAM_VANDERPOL, 1, 5);     \
+	if (D.family == NTG_FAM_VANDERPOL) return CALL(NTG_FAM_VANDERPOL, 0, 0);                      \
+	if (D.family == NTG_FAM_TESTFAM && d3 && D.nout == 3) return CALL(NTG_FAM_TESTFAM, 3, 0);     \
+	if (D.family == NTG_FAM_TESTFAM) return CALL(NTG_FAM_TESTFAM, 0, 0);                          \
 	return hipErrorInvalidValue;
 
 hipError_t ntg_launch_eval(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, int grid, int batch,
                            int mode, const double *x, double *f, double *g, double *c, double *jb, double *cj,
                            hipStream_t st)
 {
-#define CALL(F, N) launch_eval_nt<F, N>(nt, D, T, L, grid, batch, mode, x, f, g, c, jb, cj, st)
+#define CALL(F, N, KV) launch_eval_nt<F, N, KV>(nt, D, T, L, grid, batch, mode, x, f, g, c, jb, cj, st)
 	NTG_DISPATCH(CALL)
 #undef CALL
 }
@@ -923,7 +1149,7 @@ hipError_t ntg_launch_sqp(int nt, const NtgDims &D, const NtgTables &T, const Sm
                           int batch, const double *lo, const double *up, double *x, double *obj, int *inf, int *it,
                           int *nf, double *cl, double *hist, hipStream_t st)
 {
-#define CALL(F, N) launch_sqp_nt<F, N>(nt, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist, st)
+#define CALL(F, N, KV) launch_sqp_nt<F, N, KV>(nt, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist, st)
 	NTG_DISPATCH(CALL)
 #undef CALL
 }
@@ -956,3 +1182,5 @@ hipError_t ntg_launch_bounds(const NtgDims &D, int batch, const double *lo, cons
 	                   1.7976931348623157e308);
 	return hipGetLastError();
 }
+
+extern "C" int ntg_debug_set(int v) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ntg_dbg), &v, sizeof(int)); }

@@ -26,6 +26,16 @@ struct NtgDims {
 	int nclass, blk_total, ivl_total;
 	int cls_blk[NTG_MAX_OUT], cls_ivl[NTG_MAX_OUT], cls_k[NTG_MAX_OUT], cls_d[NTG_MAX_OUT], cls_l[NTG_MAX_OUT], cls_m[NTG_MAX_OUT];
 	u64 icost_mask, tcost_mask, fcost_mask, icon_mask, tcon_mask, fcon_mask;
+	// running-cost gradient rows kept in LDS: only the flag entries that can be non-zero
+	// (the declared trajectory-cost active variables; all of them for host callbacks)
+	int ntav;
+	signed char tav_row[NTG_MAX_NZ];   // flat flag index -> compact row, or -1
+	int uniform;                        // 1: one basis class and equal ncoef for every output
+	int lin_nnz, lin_lds;               // sparse A (exact zeros dropped); 1: staged in LDS
+	int sinv_nnz;                       // sparse (A A')^-1 (block diagonal when the rows decouple)
+	int q_use, q_nt, q_w;               // projector Q = A'(AA')^-1 A kept as ELL over its non-zero rows
+	int max_bpi;                        // most breakpoints inside one knot interval (over classes)
+	int tav_rmask;                      // union over outputs of the derivative indices with a cost AV
 };
 
 struct NtgTables {
@@ -38,14 +48,23 @@ struct NtgTables {
 	const int *rbp;        // [nclin]
 	const double *sinv;    // [nclin][nclin]  (A A')^-1
 	const double *n0;      // [nC][nC] symmetric preconditioner, or nullptr
+	// sparse A: CSR (rows) and CSC (columns)
+	const int *csr_ptr, *csr_col; const double *csr_val;
+	const int *csc_ptr, *csc_row; const double *csc_val;
+	const int *sinv_ptr, *sinv_col; const double *sinv_val;   // CSR of (A A')^-1
+	const int *q_idx;      // [nC] row of coefficient c in the compact Q, or -1
+	const int *q_col;      // [q_nt][q_w]
+	const double *q_val;   // [q_nt][q_w], zero padded
 };
 
 // byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
 struct SmemLayout {
-	int blk, off, bps, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2, total;
+	int blk, off, bps, wts, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
+	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, q_idx, q_col, q_val, total;
 };
 
 struct SolveParams {
 	int itlim, memcap, ls_maxfev, hessian, fixed_iters;
+	int stamps;   // diagnostic: clambda[b][0..7] receives per-phase cycle counts instead of multipliers
 	double sr, steplimit, ls_mu, ls_eta;
 };

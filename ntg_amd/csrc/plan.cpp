@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "ntg_dev.hpp"
@@ -131,6 +132,13 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	D.tcon_mask = av_mask(D, s->tcav, s->ntcav, &ok);
 	D.fcon_mask = av_mask(D, s->fcav, s->nfcav, &ok);
 	if (!ok) { delete p; return fail(NTG_E_BADARG, "active variable out of range"); }
+	// rows of the running-cost gradient kept on chip: the declared trajectory-cost active
+	// variables (device functors return zero elsewhere); every flag entry for host callbacks,
+	// whose df[] the reference uses in full (cost.c:107-108)
+	D.ntav = 0;
+	for (int v = 0; v < NTG_MAX_NZ; v++) D.tav_row[v] = -1;
+	for (int v = 0; v < nz; v++)
+		if (s->family == NTG_FAM_HOST || ((D.tcost_mask >> v) & 1ull)) D.tav_row[v] = (signed char)D.ntav++;
 
 	// ---- basis classes: outputs with identical (knots, order, mult, maxderiv) share a table ----
 	p->h_knots.resize(s->nout);
@@ -156,6 +164,10 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		D.cls[o] = c;
 	}
 	D.blk_total = blk_total; D.ivl_total = ivl_total;
+	D.tav_rmask = 0;
+	for (int o = 0; o < s->nout; o++) for (int r = 0; r < D.d[o]; r++) if (D.tav_row[D.iz[o] + r] >= 0) D.tav_rmask |= 1 << r;
+	D.uniform = D.nclass == 1;
+	for (int o = 1; o < s->nout; o++) if (D.ncoef[o] != D.ncoef[0]) D.uniform = 0;
 	p->class_rep = rep;
 
 	// ---- device tables ----
@@ -190,6 +202,8 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 			ivl_lo[D.cls_ivl[c] + j] = lo; ivl_hi[D.cls_ivl[c] + j] = hi;
 		}
 	}
+	D.max_bpi = 0;
+	for (int c = 0; c < D.nclass; c++) for (int j = 0; j < D.cls_l[c]; j++) D.max_bpi = std::max(D.max_bpi, ivl_hi[D.cls_ivl[c] + j] - ivl_lo[D.cls_ivl[c] + j] + 1);
 	int *d_ilo = nullptr, *d_ihi = nullptr;
 	if (dev_upload(&d_ilo, ivl_lo.data(), ivl_lo.size(), own) || dev_upload(&d_ihi, ivl_hi.data(), ivl_hi.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 	NtgTables &T = p->T;
@@ -237,6 +251,48 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		}
 		if (dev_upload(&d_sinv, Sinv.data(), Sinv.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 		T.sinv = d_sinv;
+		// sparse A, exact zeros dropped (a unit lic row touches one output, and a derivative at an
+		// end point touches only the first/last r+1 coefficients)
+		std::vector<int> rptr(m + 1, 0), rcol, cptr(nC + 1, 0), crow;
+		std::vector<double> rval, cval;
+		for (int i = 0; i < m; i++) { for (int c = 0; c < nC; c++) if (Ad[(size_t)i * nC + c] != 0.0) { rcol.push_back(c); rval.push_back(Ad[(size_t)i * nC + c]); } rptr[i + 1] = (int)rcol.size(); }
+		for (int c = 0; c < nC; c++) { for (int i = 0; i < m; i++) if (Ad[(size_t)i * nC + c] != 0.0) { crow.push_back(i); cval.push_back(Ad[(size_t)i * nC + c]); } cptr[c + 1] = (int)crow.size(); }
+		D.lin_nnz = (int)rcol.size();
+		if (rcol.empty()) { rcol.push_back(0); rval.push_back(0.0); crow.push_back(0); cval.push_back(0.0); }
+		int *d_rp = nullptr, *d_rc = nullptr, *d_cp = nullptr, *d_cr = nullptr; double *d_rv = nullptr, *d_cv = nullptr;
+		if (dev_upload(&d_rp, rptr.data(), rptr.size(), own) || dev_upload(&d_rc, rcol.data(), rcol.size(), own) ||
+		    dev_upload(&d_rv, rval.data(), rval.size(), own) || dev_upload(&d_cp, cptr.data(), cptr.size(), own) ||
+		    dev_upload(&d_cr, crow.data(), crow.size(), own) || dev_upload(&d_cv, cval.data(), cval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+		T.csr_ptr = d_rp; T.csr_col = d_rc; T.csr_val = d_rv; T.csc_ptr = d_cp; T.csc_row = d_cr; T.csc_val = d_cv;
+		// (A A')^-1 as CSR, exact zeros dropped (block diagonal when constraint rows decouple)
+		std::vector<int> sptr(m + 1, 0), scol; std::vector<double> sval;
+		for (int i = 0; i < m; i++) { for (int j = 0; j < m; j++) if (Sinv[(size_t)i * m + j] != 0.0) { scol.push_back(j); sval.push_back(Sinv[(size_t)i * m + j]); } sptr[i + 1] = (int)scol.size(); }
+		D.sinv_nnz = (int)scol.size();
+		if (scol.empty()) { scol.push_back(0); sval.push_back(0.0); }
+		int *d_sp = nullptr, *d_sc = nullptr; double *d_sv = nullptr;
+		if (dev_upload(&d_sp, sptr.data(), sptr.size(), own) || dev_upload(&d_sc, scol.data(), scol.size(), own) ||
+		    dev_upload(&d_sv, sval.data(), sval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+		T.sinv_ptr = d_sp; T.sinv_col = d_sc; T.sinv_val = d_sv;
+		// projector Q = A'(AA')^-1 A: only the coefficients some constraint touches have a non-zero
+		// row; keep those rows as ELL (zero padded) when that is small
+		{
+			std::vector<double> SA((size_t)m * nC, 0.0), Q((size_t)nC * nC, 0.0);
+			for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) { const double sij = Sinv[(size_t)i * m + j]; if (sij != 0.0) for (int c = 0; c < nC; c++) SA[(size_t)i * nC + c] += sij * Ad[(size_t)j * nC + c]; }
+			for (int i = 0; i < m; i++) for (int a = 0; a < nC; a++) { const double aia = Ad[(size_t)i * nC + a]; if (aia != 0.0) for (int c = 0; c < nC; c++) Q[(size_t)a * nC + c] += aia * SA[(size_t)i * nC + c]; }
+			std::vector<int> qidx(nC, -1); int nt = 0, w = 0;
+			for (int a = 0; a < nC; a++) { int cnt = 0; for (int c = 0; c < nC; c++) if (Q[(size_t)a * nC + c] != 0.0) cnt++; if (cnt) { qidx[a] = nt++; w = std::max(w, cnt); } }
+			if (nt > 0 && (size_t)nt * w * 12 + (size_t)nC * 4 <= 16 * 1024) {
+				std::vector<int> qcol((size_t)nt * w, 0); std::vector<double> qval((size_t)nt * w, 0.0);
+				for (int a = 0; a < nC; a++) if (qidx[a] >= 0) { int e = 0; for (int c = 0; c < nC; c++) if (Q[(size_t)a * nC + c] != 0.0) { qcol[(size_t)qidx[a] * w + e] = c; qval[(size_t)qidx[a] * w + e] = Q[(size_t)a * nC + c]; e++; } }
+				int *d_qi = nullptr, *d_qc = nullptr; double *d_qv = nullptr;
+				if (dev_upload(&d_qi, qidx.data(), qidx.size(), own) || dev_upload(&d_qc, qcol.data(), qcol.size(), own) ||
+				    dev_upload(&d_qv, qval.data(), qval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+				T.q_idx = d_qi; T.q_col = d_qc; T.q_val = d_qv;
+				D.q_use = 1; D.q_nt = nt; D.q_w = w;
+			}
+		}
+		// the general three-step operator (A g, (AA')^-1, A' lam) is staged in LDS only when Q is not used
+		D.lin_lds = (!D.q_use && ((size_t)D.lin_nnz * 24 + (size_t)D.sinv_nnz * 12 + (size_t)(2 * m + nC + 3) * 4) <= 24 * 1024) ? 1 : 0;
 		p->h_Adense.swap(Ad);
 	} else {
 		p->lin_ok = true;
@@ -374,12 +430,13 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	sp->memcap = std::min(sp->itlim, 256);
 	sp->ls_maxfev = o->ls_maxfev > 0 ? o->ls_maxfev : 20;
 	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters;
+	sp->stamps = getenv("NTG_AMD_STAMPS") ? 1 : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
 	sp->sr = std::sqrt(r);
 	sp->steplimit = o->steplimit > 0 ? o->steplimit : 2.0;
 	sp->ls_mu = o->ls_mu > 0 ? o->ls_mu : 1e-4; sp->ls_eta = o->ls_eta > 0 ? o->ls_eta : 0.9;
 	int t = o->block_threads;
-	if (t != 64 && t != 128 && t != 256) t = D.P <= 64 ? 64 : (D.P <= 128 && D.nC <= 512 ? 128 : 256);
+	if (t != 128 && t != 256) t = (D.P <= 128 && D.nC <= 512) ? 128 : 256;
 	*nt = t;
 	return 0;
 }
@@ -412,7 +469,7 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	if (batch <= 0) return 0;
 	HIPCHK(hipSetDevice(p->device));
 	const NtgDims &D = p->D;
-	const int nt = D.P <= 64 ? 64 : (D.P <= 128 && D.nC <= 512 ? 128 : 256);
+	const int nt = (D.P <= 128 && D.nC <= 512) ? 128 : 256;
 	SmemLayout L = ntg_make_layout(D, nt, 1, 0);
 	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem tables exceed 160 KiB of LDS");
 	hipStream_t st = (hipStream_t)stream;
