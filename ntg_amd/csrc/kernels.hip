@@ -20,6 +20,19 @@
 #include "ntg_dev.hpp"
 #include "families.hpp"
 #include "linesearch.hpp"
+#include <type_traits>
+
+// tuning knobs: minimum waves per SIMD the register allocator must leave room
+// for, and how many quasi-Newton pairs one reduction round of apply_history covers
+#ifndef NTG_SQP_WAVES
+#define NTG_SQP_WAVES 2
+#endif
+#ifndef NTG_EVAL_WAVES
+#define NTG_EVAL_WAVES 2
+#endif
+#ifndef NTG_HIST_G
+#define NTG_HIST_G 6
+#endif
 
 // ------------------------------------------------------------------------------------------
 // reductions: sum K values over the workgroup, result broadcast to every lane
@@ -67,6 +80,19 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 #pragma unroll
 		for (int w = 1; w < NW; w++) s += red[k * NW + w];
 		v[k] = s;
+	}
+}
+
+// every lane owns the vector elements c = tid + e*NT.  For n <= 3*NT the three slots are unrolled
+// so that their (independent) LDS dependency chains overlap; longer vectors take the plain loop.
+template <int NT, class F>
+__device__ __forceinline__ void for_vec(int n, F f)
+{
+	if (n <= 3 * NT) {
+#pragma unroll
+		for (int e = 0; e < 3; e++) { const int c = threadIdx.x + e * NT; if (c < n) f(c); }
+	} else {
+		for (int c = threadIdx.x; c < n; c += NT) f(c);
 	}
 }
 
@@ -245,15 +271,18 @@ __global__ void bounds_kernel(NtgDims D, int batch, const double *__restrict__ l
 // LDS carve-up shared by eval_kernel and sqp_kernel
 // ------------------------------------------------------------------------------------------
 struct Smem {
-	double *blk; int *off; double *bps, *wts; int *ivl_lo, *ivl_hi;
+	double *rowv; unsigned short *coli; unsigned char *colq; int *chrow, *chcol;
+	int *off; double *bps, *wts; int *ivl_lo, *ivl_hi;
 	double *x, *dfz, *fvals, *red, *dfi, *dff, *vecs, *lam, *rho, *c2;
 	// sparse linear-constraint operator: LDS copies when they fit, HBM/L2 otherwise
 	const int *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col; const double *csr_val, *csc_val, *sinv_val;
 	int *oinfo, *tavrow;   // per-output scalars and flag->row map in LDS (no per-lane kernarg gathers)
-	int *q_idx, *q_col; double *q_val;
+	short *q_idx; int *q_col; double *q_val;
 	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T)
 	{
-		blk = (double *)(base + L.blk); off = (int *)(base + L.off); bps = (double *)(base + L.bps);
+		rowv = (double *)(base + L.rowv); coli = (unsigned short *)(base + L.coli); colq = (unsigned char *)(base + L.colq);
+		chrow = (int *)(base + L.chrow); chcol = (int *)(base + L.chcol);
+		off = (int *)(base + L.off); bps = (double *)(base + L.bps);
 		wts = (double *)(base + L.wts);
 		ivl_lo = (int *)(base + L.ivl_lo); ivl_hi = (int *)(base + L.ivl_hi);
 		x = (double *)(base + L.x); dfz = (double *)(base + L.dfz); fvals = (double *)(base + L.fvals);
@@ -270,7 +299,7 @@ struct Smem {
 			sinv_ptr = T.sinv_ptr; sinv_col = T.sinv_col; sinv_val = T.sinv_val;
 		}
 		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow);
-		q_idx = (int *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
+		q_idx = (short *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
 	}
 };
 
@@ -278,7 +307,9 @@ template <int NT>
 __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &T, const Smem &S, char *base, const SmemLayout &L)
 {
 	const int tid = threadIdx.x;
-	for (int i = tid; i < D.blk_total; i += NT) S.blk[i] = T.blk[i];
+	for (int i = tid; i < D.row_total; i += NT) S.rowv[i] = T.rowv[i];
+	for (int i = tid; i < D.col_total; i += NT) { S.coli[i] = T.coli[i]; S.colq[i] = T.colq[i]; }
+	for (int i = tid; i < D.nclass * NTG_MAX_ORDER; i += NT) { S.chrow[i] = T.chrow[i]; S.chcol[i] = T.chcol[i]; }
 	for (int i = tid; i < D.nclass * D.P; i += NT) S.off[i] = T.off[i];
 	for (int i = tid; i < D.P; i += NT) {
 		S.bps[i] = T.bps[i];
@@ -288,7 +319,6 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 		if (i < D.P - 1) w += (T.bps[i + 1] - T.bps[i]) / 2;
 		S.wts[i] = w;
 	}
-	for (int i = tid; i < D.ivl_total; i += NT) { S.ivl_lo[i] = T.ivl_lo[i]; S.ivl_hi[i] = T.ivl_hi[i]; }
 	if (D.lin_lds) {
 		int *rp = (int *)(base + L.csr_ptr), *rc = (int *)(base + L.csr_col), *cp = (int *)(base + L.csc_ptr), *cr = (int *)(base + L.csc_row);
 		double *rv = (double *)(base + L.csr_val), *cv = (double *)(base + L.csc_val), *sv = (double *)(base + L.sinv_val);
@@ -303,9 +333,10 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 	for (int o = tid; o < D.nout; o += NT) {
 		int *q = S.oinfo + o * 10;
 		q[0] = D.order[o]; q[1] = D.mult[o]; q[2] = D.ninterv[o]; q[3] = D.d[o]; q[4] = D.iC[o]; q[5] = D.iz[o];
-		q[6] = D.cls_blk[D.cls[o]]; q[7] = D.cls[o] * D.P; q[8] = D.cls_ivl[D.cls[o]]; q[9] = D.ncoef[o];
+		q[6] = D.cls[o] * NTG_MAX_ORDER; q[7] = D.cls[o] * D.P; q[8] = D.cls_W[D.cls[o]]; q[9] = D.ncoef[o];
 	}
 	for (int v = tid; v < D.nz; v += NT) S.tavrow[v] = D.tav_row[v];
+	for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;   // padding target of the column form
 	if (D.q_use) {
 		for (int i = tid; i < D.nC; i += NT) S.q_idx[i] = T.q_idx[i];
 		for (int i = tid; i < D.q_nt * D.q_w; i += NT) { S.q_col[i] = T.q_col[i]; S.q_val[i] = T.q_val[i]; }
@@ -318,15 +349,23 @@ template <int NOUT, int K>
 __device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const double *sx, int bp,
                                           u64 mask, double *z)
 {
-	const int nout = NOUT > 0 ? NOUT : D.nout;
+	const int nout = NOUT > 0 ? NOUT : D.nout, P = D.P;
 	if (NOUT > 0 && K > 0 && D.uniform) {
-		// one basis class, compile-time order and maxderiv == 3: the breakpoint's block is read
-		// once into registers and reused by every output; all loops unroll
+		// one basis class, compile-time order, maxderiv == 3: the rows of the active derivative
+		// channels at this breakpoint are read once into registers and reused by every output
 		constexpr int KK = K > 0 ? K : 1;
-		double b[KK * 3];
-		const double *bp_blk = S.blk + (size_t)bp * KK * 3;
+		double b[3][KK];
 #pragma unroll
-		for (int e = 0; e < KK * 3; e++) b[e] = bp_blk[e];
+		for (int r = 0; r < 3; r++) {
+			const int ch = S.chrow[r];
+			if (ch >= 0) {                                   // wave-uniform
+#pragma unroll
+				for (int q = 0; q < KK; q++) b[r][q] = S.rowv[ch + q * P + bp];
+			} else {
+#pragma unroll
+				for (int q = 0; q < KK; q++) b[r][q] = 0.0;
+			}
+		}
 		const int ofs = S.off[bp], nco = D.ncoef[0];
 #pragma unroll
 		for (int o = 0; o < (NOUT > 0 ? NOUT : 1); o++) {
@@ -337,9 +376,9 @@ __device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const
 #pragma unroll
 			for (int r = 0; r < 3; r++) {
 				double acc = 0.0;
-				if ((mask >> (3 * o + r)) & 1ull) {
+				if ((mask >> (3 * o + r)) & 1ull) {           // wave-uniform
 #pragma unroll
-					for (int q = 0; q < KK; q++) acc += b[q * 3 + r] * xv[q];
+					for (int q = 0; q < KK; q++) acc += b[r][q] * xv[q];
 				}
 				z[3 * o + r] = acc;
 			}
@@ -350,31 +389,44 @@ __device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const
 	for (int o = 0; o < nout; o++) {
 		const int k = D.order[o], c = D.cls[o];
 		const int d = NOUT > 0 ? 3 : D.d[o], iz = NOUT > 0 ? 3 * o : D.iz[o];
-		const double *b = S.blk + D.cls_blk[c] + (size_t)bp * k * d;
-		const double *cx = sx + D.iC[o] + S.off[c * D.P + bp];
+		const double *cx = sx + D.iC[o] + S.off[c * P + bp];
 #pragma unroll
 		for (int r = 0; r < (NOUT > 0 ? 3 : NTG_MAX_ORDER); r++) {
 			if (r >= d) break;
 			double acc = 0.0;
-			if ((mask >> (iz + r)) & 1ull)
-				for (int q = 0; q < k; q++) acc += b[q * d + r] * cx[q];
+			if ((mask >> (iz + r)) & 1ull) {
+				const double *rv = S.rowv + S.chrow[c * NTG_MAX_ORDER + r] + bp;
+				for (int q = 0; q < k; q++) acc += rv[q * P] * cx[q];
+			}
 			z[iz + r] = acc;
 		}
 	}
 }
 
-// one band entry of M' v at a breakpoint: sum_r v[iz+r] * block[q][r]
-template <int NOUT>
-__device__ __forceinline__ double band_dot(const double *b, int d, const double *v)
+// which coefficients a lane owns (c = tid + e*NT) and where their column-form data sit: decoded
+// once per kernel, kept in registers for every evaluation of the solve
+template <int EPT>
+struct CoefMap {
+	int o[EPT], cl[EPT];   // output and local coefficient index of slot e (c = tid + e*NT), o = -1: no coefficient
+};
+template <int NT, int EPT>
+__device__ __forceinline__ void make_coefmap(const NtgDims &D, const Smem &S, CoefMap<EPT> &cm)
 {
-	double acc = 0.0;
-	for (int r = 0; r < d; r++) acc += v[r] * b[r];
-	return acc;
+#pragma unroll
+	for (int e = 0; e < EPT; e++) {
+		const int c = threadIdx.x + e * NT;
+		cm.o[e] = -1; cm.cl[e] = 0;
+		if (c < D.nC) {
+			int o = 0;
+			while (o + 1 < D.nout && D.iC[o + 1] <= c) o++;
+			cm.o[e] = o; cm.cl[e] = c - D.iC[o];
+		}
+	}
 }
 
 // per-breakpoint cost functor pass: Z = M C, then ucf/icf/fcf -> fvals, dfz, dfi, dff in LDS
 template <int FAM, int NOUT, int K, int NT>
-__device__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
+__device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
 {
 	constexpr int NZ = NOUT > 0 ? 3 * NOUT : NTG_MAX_NZ;
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
@@ -389,7 +441,7 @@ __device__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
 			S.fvals[i] = f;
 			const double w = S.wts[i];
 #pragma unroll
-			for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * P + i] = w * df[v]; }
+			for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = w * df[v]; }
 		}
 	}
 	if (D.nicf && tid == 0) {                                     // cost.c:4-36
@@ -411,97 +463,91 @@ __device__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
 // quadrature + banded gradient assembly from the per-breakpoint values in LDS (fvals, dfz,
 // dfi, dff); shared by the device-functor path and the host-callback path of ntg()
 template <int NOUT, int K, int NT>
-__device__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2)
+__device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<4> &cm)
 {
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
 	__syncthreads();
 	// trapezoid of the running cost (integrator.c:21-24); per-interval terms across the lanes,
-	// wavefront-shuffle reduction
+	// wavefront reduction
 	double acc[2] = {0.0, 0.0};
 	if (D.nucf)
 		for (int i = tid; i < P - 1; i += NT)
 			acc[0] += (S.bps[i + 1] - S.bps[i]) * (S.fvals[i + 1] + S.fvals[i]) / 2;
-	// gradient: one coefficient per lane gathers its band.  The reference integrates the dense
-	// nbps x nC matrix column by column (cost.c:117-134, integrator.c:44-48); the same sum is
-	// taken here node-wise, sum_i w_i G_i(c), over the breakpoints whose block covers c only
 	const int dbg = g_ntg_dbg;
-	for (int c = tid; c < D.nC; c += NT) {
-		if (dbg & 1) { sg[c] = 0.0; continue; }
-		int o;
-		if (D.uniform) o = c / D.ncoef[0];
-		else { o = 0; while (o + 1 < nout && S.oinfo[(o + 1) * 10 + 4] <= c) o++; }
-		const int *oi = S.oinfo + (D.uniform ? 0 : o) * 10;   // uniform: every output shares k, m, l, class
-		const int k = oi[0], m = oi[1], km = k - m, nint = oi[2];
-		const int d = NOUT > 0 ? 3 : oi[3], iz = NOUT > 0 ? 3 * o : S.oinfo[o * 10 + 5];
-		const int cl = c - (D.uniform ? o * D.ncoef[0] : S.oinfo[o * 10 + 4]);
-		const double *cb = S.blk + oi[6];
-		const int *coff = S.off + oi[7];
-		const int ivb = oi[8];
-		double dI = 0.0, dIn = 0.0, dF = 0.0;
-		if (D.nucf) {
-			const int jlo = (cl - k + 1 <= 0) ? 0 : (cl - k + 1 + km - 1) / km;
-			const int jhi = min(nint - 1, cl / km);
-			const int stride = k * d;
-			// breakpoints of one knot interval share the block offset j*km, so the band entry of
-			// coefficient c is column q = cl - j*km of every block in the interval.  The gather is
-			// written with fixed trip counts and clamped indices (weight 0 when out of range) so
-			// that all LDS reads of a coefficient are independent and issue back to back.
-			constexpr int MAXJ = 4, MAXI = 8;
-			if (D.max_bpi <= MAXI && k <= MAXJ * km) {
-				for (int r = 0; r < d; r++) {
-					if (!((D.tav_rmask >> r) & 1)) continue;       // uniform: no output has a cost AV on D^r
-					const int row = S.tavrow[iz + r];
-					const double *wdf = S.dfz + max(row, 0) * P;
-					const double on_r = row >= 0 ? 1.0 : 0.0;
+	// gradient: the reference integrates the dense nbps x nC matrix column by column
+	// (cost.c:117-134, integrator.c:44-48); here every lane owns a coefficient and takes the same
+	// sum node-wise, g[c] = sum_s colv[c][s] * (w_i df_i)[coli[c][s]], over the non-zeros of column c
+	// of the collocation matrix only.  The column form is s-major ([s][cl]): lanes with consecutive
+	// coefficients read consecutive LDS words.
+	if (NOUT > 0 && !D.nicf && !D.nfcf) {
+		// all (breakpoint, block column) pairs of a column are read first, then all values and
+		// weighted gradients, then the FMAs: two LDS round trips per coefficient, independent of W
+		auto gather = [&](auto Wtag) {
+			constexpr int W = decltype(Wtag)::value;   // 0: run-time width
 #pragma unroll
-					for (int jj = 0; jj < MAXJ; jj++) {
-						if (jj * km >= k) break;                   // uniform: at most ceil(k/km) intervals overlap
-						const int j = min(jlo + jj, nint - 1);
-						const bool jon = jlo + jj <= jhi;
-						const int i0 = S.ivl_lo[ivb + j], i1 = S.ivl_hi[ivb + j];
-						const double *bq = cb + (size_t)max(cl - j * km, 0) * d + r;
-						double wv[MAXI], bv[MAXI];
+			for (int e = 0; e < 4; e++) {
+				const int c = tid + e * NT;
+				if (c >= D.nC) break;
+				if (dbg & 1) { sg[c] = 0.0; continue; }
+				double dIn = 0.0;
+				const int o = cm.o[e], cl = cm.cl[e];
+				const int *oi = S.oinfo + o * 10;
+				const int chb = oi[6], nc = oi[9], Wr = oi[8];
 #pragma unroll
-						for (int ii = 0; ii < MAXI; ii++) {
-							const int i = min(i0 + ii, P - 1);
-							wv[ii] = wdf[i];
-							bv[ii] = bq[(size_t)i * stride];
-						}
+				for (int r = 0; r < 3; r++) {
+					if (!((D.tav_rmask >> r) & 1)) continue;                 // wave-uniform
+					const int row = S.tavrow[3 * o + r], chc = S.chcol[chb + r];
+					if (row < 0 || chc < 0) continue;
+					const unsigned short *ci = S.coli + chc + cl; const unsigned char *cq = S.colq + chc + cl;
+					const double *rv = S.rowv + S.chrow[chb + r]; const double *wdf = S.dfz + row * (P + 1);
+					if (W > 0) {
+						int ii[W > 0 ? W : 1], qq[W > 0 ? W : 1];
 #pragma unroll
-						for (int ii = 0; ii < MAXI; ii++)
-							dIn += ((jon && i0 + ii <= i1) ? on_r : 0.0) * wv[ii] * bv[ii];
+						for (int s2 = 0; s2 < W; s2++) { ii[s2] = ci[s2 * nc]; qq[s2] = cq[s2 * nc]; }
+						double vv[W > 0 ? W : 1], ww[W > 0 ? W : 1];
+#pragma unroll
+						for (int s2 = 0; s2 < W; s2++) { vv[s2] = rv[qq[s2] * P + ii[s2]]; ww[s2] = wdf[ii[s2]]; }
+#pragma unroll
+						for (int s2 = 0; s2 < W; s2++) dIn += vv[s2] * ww[s2];
+					} else {
+						for (int s2 = 0; s2 < Wr; s2++) { const int i2 = ci[s2 * nc]; dIn += rv[cq[s2 * nc] * P + i2] * wdf[i2]; }
 					}
 				}
-			} else {
-				for (int j = jlo; j <= jhi; j++) {
-					const int i0 = S.ivl_lo[ivb + j], i1 = S.ivl_hi[ivb + j];
-					const int q = cl - j * km;
-					for (int r = 0; r < d; r++) {
-						const int row = S.tavrow[iz + r];
-						if (row < 0) continue;
-						const double *wdf = S.dfz + row * P;
-						const double *bq = cb + (size_t)q * d + r;
-#pragma unroll 4
-						for (int i = i0; i <= i1; i++) dIn += wdf[i] * bq[(size_t)i * stride];
-					}
+				sg[c] = dIn;
+				acc[1] += dIn * dIn;
+				__builtin_amdgcn_sched_barrier(0);   // keep the slots sequential: their temporaries share registers
+			}
+		};
+		const int W4 = D.uniform ? D.cls_W[0] : 1000;
+		if (W4 <= 8) gather(std::integral_constant<int, 8>());
+		else if (W4 <= 12) gather(std::integral_constant<int, 12>());
+		else if (W4 <= 16) gather(std::integral_constant<int, 16>());
+		else gather(std::integral_constant<int, 0>());
+	} else {
+		for (int c = tid; c < D.nC; c += NT) {
+			int o = 0;
+			while (o + 1 < nout && S.oinfo[(o + 1) * 10 + 4] <= c) o++;
+			const int *oi = S.oinfo + o * 10;
+			const int k = oi[0], d = oi[3], iz = oi[5], cl = c - oi[4], chb = oi[6], W4 = oi[8], nc = oi[9];
+			const int *coff = S.off + oi[7];
+			double dI = 0.0, dIn = 0.0, dF = 0.0;
+			for (int r = 0; r < d; r++) {
+				const int row = S.tavrow[iz + r], chc = S.chcol[chb + r], chr = S.chrow[chb + r];
+				if (D.nucf && row >= 0 && chc >= 0) {
+					const unsigned short *ci = S.coli + chc + cl; const unsigned char *cq = S.colq + chc + cl; const double *wdf = S.dfz + row * (P + 1);
+					for (int s = 0; s < W4; s++) { const int i2 = ci[s * nc]; dIn += S.rowv[chr + cq[s * nc] * P + i2] * wdf[i2]; }
+				}
+				if (chr >= 0) {
+					if (D.nicf && cl < k) dI += S.dfi[iz + r] * S.rowv[chr + cl * P];             // colloc.c:243-260 (block 0)
+					const int ol = coff[P - 1];
+					if (D.nfcf && cl >= ol && cl < ol + k) dF += S.dff[iz + r] * S.rowv[chr + (cl - ol) * P + P - 1];   // colloc.c:287-316
 				}
 			}
+			const double g = dI + dIn + dF;                       // Vector3Add (matrix.c:177)
+			sg[c] = g;
+			acc[1] += g * g;
 		}
-		if (D.nicf && cl < k) {                                   // colloc.c:243-260 (block 0, no offset)
-			const double *b = cb + (size_t)cl * d;
-			for (int r = 0; r < d; r++) dI += S.dfi[iz + r] * b[r];
-		}
-		if (D.nfcf) {                                             // colloc.c:287-316
-			const int ol = coff[P - 1];
-			if (cl >= ol && cl < ol + k) {
-				const double *b = cb + ((size_t)(P - 1) * k + (cl - ol)) * d;
-				for (int r = 0; r < d; r++) dF += S.dff[iz + r] * b[r];
-			}
-		}
-		const double g = dI + dIn + dF;                           // Vector3Add (matrix.c:177)
-		sg[c] = g;
-		acc[1] += g * g;
 	}
 	if (!(dbg & 4)) block_sum<NT, 2>(acc, S.red);
 	const double I = D.nicf ? S.dfi[nz] : 0.0, Ff = D.nfcf ? S.dff[nz] : 0.0;
@@ -513,13 +559,13 @@ __device__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, doubl
 // receives |g|^2.  Every lane of the workgroup must call it (it contains barriers).
 template <int FAM, int NOUT, int K, int NT>
 __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
-                                            unsigned long long *tk = nullptr)
+                                            const CoefMap<4> &cm, unsigned long long *tk = nullptr)
 {
 	unsigned long long t0 = 0;
 	if (tk) t0 = __builtin_amdgcn_s_memtime();
 	cost_phase1<FAM, NOUT, K, NT>(D, S, sx);
 	if (tk) { __syncthreads(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
-	const double F = cost_phase2<NOUT, K, NT>(D, S, sg, gnorm2);
+	const double F = cost_phase2<NOUT, K, NT>(D, S, sg, gnorm2, cm);
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
 }
@@ -527,7 +573,7 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 // NPfuncon (ntg.c:337-371, constraints.c:36-195): residuals and banded Jacobian rows straight
 // to HBM.  Row order [initial; trajectory constraint-major x breakpoint; final].
 template <int FAM, int NOUT, int K, int NT>
-__device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *sx, int mode,
+__device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S, const double *sx, int mode,
                                  double *c_out, double *jband, double *cjac)
 {
 	using Fam = Family<FAM>;
@@ -537,11 +583,13 @@ __device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *
 	auto emit_row = [&](int row, int bp, const double *dcrow) {
 		for (int o = 0; o < nout; o++) {
 			const int k = D.order[o], cc = D.cls[o], d = D.d[o];
-			const double *b = S.blk + D.cls_blk[cc] + (size_t)bp * k * d;
 			const int col0 = D.iC[o] + S.off[cc * P + bp];
 			for (int q = 0; q < k; q++) {
 				double a = 0.0;
-				for (int r = 0; r < d; r++) a += dcrow[D.iz[o] + r] * b[q * d + r];
+				for (int r = 0; r < d; r++) {
+					const int chr = S.chrow[cc * NTG_MAX_ORDER + r];
+					if (chr >= 0) a += dcrow[D.iz[o] + r] * S.rowv[chr + q * P + bp];
+				}
 				if (jband) jband[(size_t)row * D.sumk + D.koff[o] + q] = a;
 				if (cjac) cjac[(size_t)(col0 + q) * D.ncnln + row] = a;
 			}
@@ -582,7 +630,7 @@ __device__ void eval_constraints(const NtgDims &D, const Smem &S, const double *
 
 // Persistent workgroups stride over the batch; tables are staged once per workgroup.
 template <int FAM, int NOUT, int K, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, NTG_EVAL_WAVES)
 eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const double *__restrict__ x,
             double *__restrict__ f, double *__restrict__ g, double *__restrict__ c,
             double *__restrict__ jband, double *__restrict__ cjac)
@@ -591,11 +639,14 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 	Smem S(smem_raw, L, D, T);
 	stage_tables<NT>(D, T, S, smem_raw, L);
 	double *sg = S.vecs;
+	__syncthreads();
+	CoefMap<4> cm;
+	if (NOUT > 0) make_coefmap<NT, 4>(D, S, cm);   // the host only picks a NOUT > 0 instance when nC <= 4 NT
 	for (int b = blockIdx.x; b < batch; b += gridDim.x) {
 		__syncthreads();
 		for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
 		double gn2;
-		const double F = eval_cost<FAM, NOUT, K, NT>(D, S, S.x, sg, &gn2);
+		const double F = eval_cost<FAM, NOUT, K, NT>(D, S, S.x, sg, &gn2, cm);
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
 		if (g && mode != 0)
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
@@ -612,7 +663,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 // gp = g - A'(AA')^-1 A g  (projection onto null(A)); S.lam receives the multipliers estimate.
 // A is kept sparse (CSR for A g, CSC for A' lam); (AA')^-1 is a small dense matrix.
 template <int NT>
-__device__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */)
+__device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */)
 {
 	const int m = D.nclin, tid = threadIdx.x;
 	__syncthreads();
@@ -621,7 +672,7 @@ __device__ void project(const NtgDims &D, const Smem &S, const double *sg, doubl
 		// gp = g - Q g with Q = A'(AA')^-1 A stored as ELL over its non-zero rows: one pass, no
 		// intermediate barrier; the padded entries (value 0, column 0) keep every load unconditional
 		const int w = D.q_w;
-		for (int c = tid; c < D.nC; c += NT) {
+		for_vec<NT>(D.nC, [&](int c) {
 			const int t = S.q_idx[c];
 			double s = 0.0;
 			if (t >= 0) {
@@ -629,7 +680,7 @@ __device__ void project(const NtgDims &D, const Smem &S, const double *sg, doubl
 				for (int e = 0; e < w; e++) s += S.q_val[t * w + e] * sg[S.q_col[t * w + e]];
 			}
 			sgp[c] = sg[c] - s;
-		}
+		});
 		__syncthreads();
 		return;
 	}
@@ -653,20 +704,33 @@ __device__ void project(const NtgDims &D, const Smem &S, const double *sg, doubl
 	__syncthreads();
 }
 
+// out = W0 v for the collocation preconditioner (ELL, rows streamed from L2).  Kept out of line:
+// it runs a handful of times per solve and must not add to the register pressure of the main loop.
+template <int NT>
+__device__ __attribute__((noinline)) void apply_n0(int n, int w, const double *__restrict__ n0,
+                                                   const unsigned short *__restrict__ n0c, const double *v, double *out)
+{
+	for (int c = threadIdx.x; c < n; c += NT) {
+		double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+		int s = 0;
+		for (; s + 4 <= w; s += 4) {   // four independent chains: the L2 loads of a row overlap
+			a0 += n0[(size_t)(s + 0) * n + c] * v[n0c[(size_t)(s + 0) * n + c]];
+			a1 += n0[(size_t)(s + 1) * n + c] * v[n0c[(size_t)(s + 1) * n + c]];
+			a2 += n0[(size_t)(s + 2) * n + c] * v[n0c[(size_t)(s + 2) * n + c]];
+			a3 += n0[(size_t)(s + 3) * n + c] * v[n0c[(size_t)(s + 3) * n + c]];
+		}
+		for (; s < w; s++) a0 += n0[(size_t)s * n + c] * v[n0c[(size_t)s * n + c]];
+		out[c] = (a0 + a1) + (a2 + a3);
+	}
+}
+
 // out = W0 v : identity on null(A) (cold start) or the collocation preconditioner
 template <int NT>
-__device__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out)
+__device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out)
 {
 	__syncthreads();
-	if (hessian == 1 && T.n0) {
-		for (int c = threadIdx.x; c < D.nC; c += NT) {
-			double a = 0.0;
-			for (int j = 0; j < D.nC; j++) a += T.n0[(size_t)j * D.nC + c] * v[j]; // symmetric: coalesced
-			out[c] = a;
-		}
-	} else {
-		for (int c = threadIdx.x; c < D.nC; c += NT) out[c] = v[c];
-	}
+	if (hessian == 1 && T.n0) apply_n0<NT>(D.nC, T.n0_w, T.n0, T.n0c, v, out);
+	else for_vec<NT>(D.nC, [&](int c) { out[c] = v[c]; });
 	__syncthreads();
 }
 
@@ -674,10 +738,10 @@ __device__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, cons
 // time: 2G partial dots per lane, ONE workgroup reduction, then the axpys from the registers
 // that still hold the pair elements.
 template <int NT>
-__device__ void apply_history(const NtgDims &D, const Smem &S, const double *hist, int npairs,
+__device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, const double *hist, int npairs,
                               const double *v, double *t)
 {
-	constexpr int G = 8, EPT = 4;
+	constexpr int G = NTG_HIST_G, EPT = 3;
 	const int n = D.nC, tid = threadIdx.x;
 	if (n <= EPT * NT) {
 		double vv[EPT], tt[EPT];
@@ -689,7 +753,7 @@ __device__ void apply_history(const NtgDims &D, const Smem &S, const double *his
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				acc[2 * g] = 0.0; acc[2 * g + 1] = 0.0;
-				const double *h = hist + (size_t)(base + g) * 2 * n;
+				const double *h = hist + (size_t)(base + g) * (2 * n + 2);
 #pragma unroll
 				for (int e = 0; e < EPT; e++) {
 					const int c = tid + e * NT;
@@ -706,7 +770,8 @@ __device__ void apply_history(const NtgDims &D, const Smem &S, const double *his
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				if (g < cnt) {
-					const double rho = S.rho[base + g], c2 = S.c2[base + g];
+					const double *hh = hist + (size_t)(base + g) * (2 * n + 2) + 2 * n;
+					const double rho = hh[0], c2 = hh[1];
 #pragma unroll
 					for (int e = 0; e < EPT; e++)
 						tt[e] += -rho * (hs[g][e] * acc[2 * g + 1] + hu[g][e] * acc[2 * g]) + c2 * hs[g][e] * acc[2 * g];
@@ -726,7 +791,7 @@ __device__ void apply_history(const NtgDims &D, const Smem &S, const double *his
 #pragma unroll
 			for (int g = 0; g < 4; g++) {
 				if (g < cnt) {
-					const double *h = hist + (size_t)(base + g) * 2 * n;
+					const double *h = hist + (size_t)(base + g) * (2 * n + 2);
 					acc[2 * g] += h[c] * vv;
 					acc[2 * g + 1] += h[n + c] * vv;
 				}
@@ -738,8 +803,8 @@ __device__ void apply_history(const NtgDims &D, const Smem &S, const double *his
 #pragma unroll
 			for (int g = 0; g < 4; g++) {
 				if (g < cnt) {
-					const double *h = hist + (size_t)(base + g) * 2 * n;
-					const double s = h[c], u = h[n + c], rho = S.rho[base + g], c2 = S.c2[base + g];
+					const double *h = hist + (size_t)(base + g) * (2 * n + 2);
+					const double s = h[c], u = h[n + c], rho = h[2 * n], c2 = h[2 * n + 1];
 					tt += -rho * (s * acc[2 * g + 1] + u * acc[2 * g]) + c2 * s * acc[2 * g];
 				}
 			}
@@ -750,8 +815,12 @@ __device__ void apply_history(const NtgDims &D, const Smem &S, const double *his
 }
 
 // One workgroup solves one problem from start to finish (ntg.c:250: the npsol_ call).
+// The loop below has ONE evaluation site (funobj + projection at the trial point sxt); what the
+// result means is decided by `state`: the first evaluation, a line-search trial, a forced
+// acceptance, or the final multiplier estimate.  One site keeps the assembly code inlined once
+// and the register state (coefficient map, line search) out of scratch.
 template <int FAM, int NOUT, int K, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, NTG_SQP_WAVES)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
            double *__restrict__ objective, int *__restrict__ inform_out, int *__restrict__ iters_out,
@@ -763,13 +832,17 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	if (b >= batch) return;
 	const int npad = (n + 1) & ~1;
 	double *sx = S.x, *sxt = S.vecs, *sgp = S.vecs + npad, *sgpt = S.vecs + 2 * npad, *sd = S.vecs + 3 * npad,
-	       *st = S.vecs + 4 * npad, *sg = S.vecs + 5 * npad, *tmp = S.vecs + 6 * npad;
-	double *hist = hist_all + (size_t)b * sp.memcap * 2 * n;
+	       *st = sxt /* t = W gp+ lives in the trial-point buffer once x is committed */, *sg = S.vecs + 4 * npad,
+	       *tmp = S.vecs + 5 * npad;
+	double *hist = hist_all + (size_t)b * sp.memcap * (2 * n + 2);   // pair i: [s (n) | u (n) | rho | c2]
 	stage_tables<NT>(D, T, S, smem_raw, L);
 	for (int i = tid; i < n; i += NT) sx[i] = xio[(size_t)b * n + i];
 	__syncthreads();
+	CoefMap<4> cm;
+	if (NOUT > 0) make_coefmap<NT, 4>(D, S, cm);
 
-	int inform = 4, iter = 0, nfev = 0, npairs = 0;
+	enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3 };
+	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
 	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history / rest
 	unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define NTG_STAMP(slot) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot] += now_ - tlast; tlast = now_; } } while (0)
@@ -809,122 +882,160 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			__syncthreads();
 		}
+		for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 		NTG_STAMP(0);
-		F = eval_cost<FAM, NOUT, K, NT>(D, S, sx, sg, &gn2); nfev++;
-		NTG_STAMP(1);
-		project<NT>(D, S, sg, sgp, tmp);
-		NTG_STAMP(2);
-		apply_w0<NT>(D, T, sp.hessian, sgp, sd);
-		NTG_STAMP(4);
 
-		LineSearch ls;
-		// carried across iterations: gp.d, d.d, x.x, gp.gp (refreshed by the update's reduction)
-		double r4[4] = {0, 0, 0, 0};
-		for (int c = tid; c < n; c += NT) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; }
-		block_sum<NT, 4>(r4, S.red);
-		for (iter = 0; iter < sp.itlim; iter++) {
-			double dphi0 = -r4[0];
-			pnorm = sqrt(r4[1]);
-			const double xnorm = sqrt(r4[2]), gpnorm = sqrt(r4[3]), gnorm = sqrt(gn2);
-			const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), gnorm));
-			if (pnorm == 0.0 || !(dphi0 < 0.0)) {
-				if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
-					npairs = 0;
-					apply_w0<NT>(D, T, sp.hessian, sgp, sd);
-					double r2[2] = {0, 0};
-					for (int c = tid; c < n; c += NT) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; }
-					block_sum<NT, 2>(r2, S.red);
-					dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
+		// line-search state lives in LDS (17 doubles would otherwise sit in every lane's registers);
+		// each step works on a register copy and lane 0 publishes it back between two barriers
+		LineSearch *lsm = (LineSearch *)(smem_raw + L.ls);
+		double r4[4] = {0, 0, 0, 0};   // gp.d, d.d, x.x, gp.gp of the current iterate
+		bool finished = false;
+		for (;;) {
+			// ================= the one evaluation site =================
+			double gn2n;
+			const double Fn = eval_cost<FAM, NOUT, K, NT>(D, S, sxt, sg, &gn2n, cm, sp.stamps ? tk : nullptr);
+			NTG_STAMP(1);
+			if (state == ST_FINAL) {
+				// multipliers estimate lam = (AA')^-1 A g at the final point
+				__syncthreads();
+				for (int r = tid; r < m; r += NT) {
+					double a = 0.0;
+					for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
+					tmp[r] = a;
 				}
-				if (pnorm == 0.0 || !(dphi0 < 0.0)) { inform = (gpnorm <= tolg) ? 0 : 6; break; }
+				__syncthreads();
+				for (int r = tid; r < m; r += NT) {
+					double a = 0.0;
+					for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
+					S.lam[r] = a;
+				}
+				__syncthreads();
+				break;
 			}
-			if (!sp.fixed_iters && gpnorm <= 1e-3 * tolg) { inform = 0; break; }
-			const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
-			ls.init(F, dphi0, amax < 1.0 ? amax : 1.0, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
-			double Fn = 0.0, gn2n = 0.0;
-			int rc;
-			for (;;) {
-				const double a = ls.a;
-				for (int c = tid; c < n; c += NT) sxt[c] = sx[c] + a * (-sd[c]);
-				NTG_STAMP(5);
-				Fn = eval_cost<FAM, NOUT, K, NT>(D, S, sxt, sg, &gn2n, sp.stamps ? tk : nullptr); nfev++;
-				NTG_STAMP(1);
-				project<NT>(D, S, sg, sgpt, tmp);
-				NTG_STAMP(2);
-				double dd[1] = {0.0};
-				for (int c = tid; c < n; c += NT) dd[0] += sgpt[c] * (-sd[c]);
-				block_sum<NT, 1>(dd, S.red);
-				rc = ls.step(Fn, dd[0]);
-				if (rc == 1 || rc == -1) break;
-				if (rc == 2) {
-					const double a2 = ls.a;
-					for (int c = tid; c < n; c += NT) sxt[c] = sx[c] + a2 * (-sd[c]);
-					Fn = eval_cost<FAM, NOUT, K, NT>(D, S, sxt, sg, &gn2n); nfev++;
-					project<NT>(D, S, sg, sgpt, tmp);
-					rc = 1;
-					break;
+			nfev++;
+			project<NT>(D, S, sg, sgpt, tmp);
+			NTG_STAMP(2);
+			bool new_major = false;
+			if (state == ST_INIT) {
+				F = Fn; gn2 = gn2n;
+				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
+				apply_w0<NT>(D, T, sp.hessian, sgp, sd);
+				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
+				for_vec<NT>(n, [&](int c) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; });
+				block_sum<NT, 4>(r4, S.red);
+				NTG_STAMP(4);
+				new_major = true;
+			} else {
+				int rc = 1;
+				if (state == ST_LS) {
+					double dd[1] = {0.0};
+					for_vec<NT>(n, [&](int c) { dd[0] += sgpt[c] * (-sd[c]); });
+					block_sum<NT, 1>(dd, S.red);
+					LineSearch lsr = *lsm;
+					rc = lsr.step(Fn, dd[0]);
+					__syncthreads();
+					if (tid == 0) *lsm = lsr;
+					__syncthreads();
+				}
+				if (rc == 0 || rc == 2) {
+					if (rc == 2) state = ST_FORCE;
+					const double a = lsm->a;
+					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * (-sd[c]); });
+					NTG_STAMP(5);
+					continue;
+				}
+				if (rc != 1) {
+					const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+					inform = (sqrt(r4[3]) <= tolg) ? 0 : 6;
+					finished = true;
+				} else {
+					alpha = lsm->a;
+					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
+					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
+					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT>(D, T, sp.hessian, sgp, sd); } // memory full: restart
+					NTG_STAMP(5);
+					apply_w0<NT>(D, T, sp.hessian, sgpt, st);
+					NTG_STAMP(4);
+					apply_history<NT>(D, S, hist, npairs, sgpt, st);
+					NTG_STAMP(3);
+					double r6[6] = {0, 0, 0, 0, 0, 0};
+					for_vec<NT>(n, [&](int c) {
+						const double s = sg[c], y = sgpt[c] - sgp[c], u = st[c] - sd[c], gpn = sgpt[c];
+						r6[0] += s * y; r6[1] += y * u; r6[2] += s * gpn; r6[3] += u * gpn; r6[4] += s * s; r6[5] += y * y;
+					});
+					block_sum<NT, 6>(r6, S.red);
+					const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
+					const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
+					r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
+					for_vec<NT>(n, [&](int c) {
+						const double s = sg[c], u = st[c] - sd[c];
+						if (upd) { hist[(size_t)npairs * (2 * n + 2) + c] = s; hist[(size_t)npairs * (2 * n + 2) + n + c] = u; }
+						const double dn = upd ? st[c] - rho * (s * r6[3] + u * r6[2]) + c2 * s * r6[2] : st[c];
+						const double xn = sx[c], gq = sgpt[c];
+						sgp[c] = gq;
+						sd[c] = dn;
+						r4[0] += gq * dn; r4[1] += dn * dn; r4[2] += xn * xn; r4[3] += gq * gq;
+					});
+					if (upd) {
+						if (tid == 0) { hist[(size_t)npairs * (2 * n + 2) + 2 * n] = rho; hist[(size_t)npairs * (2 * n + 2) + 2 * n + 1] = c2; }
+						npairs++;
+					}
+					__threadfence_block();
+					block_sum<NT, 4>(r4, S.red);   // also orders the hist/rho writes before their next use
+					F = Fn; gn2 = gn2n;
+					iter++;
+					if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r4[2])) &&
+					    sqrt(r4[3]) <= sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inform = 0; finished = true; }
+					else new_major = true;
 				}
 			}
-			if (rc != 1) { inform = (gpnorm <= tolg) ? 0 : 6; break; }
-			alpha = ls.a;
-			// accept: x <- xt ; t = W gp+ ; u = t - d ; BFGS pair (s, u) to HBM
-			for (int c = tid; c < n; c += NT) sg[c] = alpha * (-sd[c]);      // the step s (sg is free here)
-			if (npairs == sp.memcap) { npairs = 0; apply_w0<NT>(D, T, sp.hessian, sgp, sd); } // memory full: restart
+			if (new_major) {
+				// ---- start of a major iteration at (sx, sgp, sd) ----
+				if (iter >= sp.itlim) { inform = 4; finished = true; }
+				else {
+					double dphi0 = -r4[0];
+					pnorm = sqrt(r4[1]);
+					const double xnorm = sqrt(r4[2]), gpnorm = sqrt(r4[3]);
+					const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+					if (pnorm == 0.0 || !(dphi0 < 0.0)) {
+						if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
+							npairs = 0;
+							apply_w0<NT>(D, T, sp.hessian, sgp, sd);
+							double r2[2] = {0, 0};
+							for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
+							block_sum<NT, 2>(r2, S.red);
+							r4[0] = r2[0]; r4[1] = r2[1];
+							dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
+						}
+						if (pnorm == 0.0 || !(dphi0 < 0.0)) { inform = (gpnorm <= tolg) ? 0 : 6; finished = true; }
+					}
+					if (!finished && !sp.fixed_iters && gpnorm <= 1e-3 * tolg) { inform = 0; finished = true; }
+					if (!finished) {
+						const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
+						const double a = amax < 1.0 ? amax : 1.0;
+						__syncthreads();
+						if (tid == 0) lsm->init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
+						__syncthreads();
+						state = ST_LS;
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * (-sd[c]); });
+					}
+				}
+			}
 			NTG_STAMP(5);
-			apply_w0<NT>(D, T, sp.hessian, sgpt, st);
-			NTG_STAMP(4);
-			apply_history<NT>(D, S, hist, npairs, sgpt, st);
-			NTG_STAMP(3);
-			double r6[6] = {0, 0, 0, 0, 0, 0};
-			for (int c = tid; c < n; c += NT) {
-				const double s = sg[c], y = sgpt[c] - sgp[c], u = st[c] - sd[c], gpn = sgpt[c];
-				r6[0] += s * y; r6[1] += y * u; r6[2] += s * gpn; r6[3] += u * gpn; r6[4] += s * s; r6[5] += y * y;
+			if (finished) {
+				if (clambda && D.q_use && m > 0) {   // one more pass for the multipliers (the Q form does not produce them)
+					state = ST_FINAL;
+					__syncthreads();
+					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+					continue;
+				}
+				break;
 			}
-			block_sum<NT, 6>(r6, S.red);
-			const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
-			const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
-			r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
-			for (int c = tid; c < n; c += NT) {
-				const double s = sg[c], u = st[c] - sd[c];
-				if (upd) { hist[(size_t)npairs * 2 * n + c] = s; hist[(size_t)npairs * 2 * n + n + c] = u; }
-				const double dn = upd ? st[c] - rho * (s * r6[3] + u * r6[2]) + c2 * s * r6[2] : st[c];
-				const double xn = sxt[c], gq = sgpt[c];
-				sx[c] = xn;
-				sgp[c] = gq;
-				sd[c] = dn;
-				r4[0] += gq * dn; r4[1] += dn * dn; r4[2] += xn * xn; r4[3] += gq * gq;
-			}
-			if (upd) {
-				if (tid == 0) { S.rho[npairs] = rho; S.c2[npairs] = c2; }
-				npairs++;
-			}
-			block_sum<NT, 4>(r4, S.red);   // also orders the hist/rho writes before their next use
-			F = Fn; gn2 = gn2n;
-			if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r4[2])) &&
-			    sqrt(r4[3]) <= sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inform = 0; iter++; break; }
 		}
 	}
 	__syncthreads();
 	for (int i = tid; i < n; i += NT) xio[(size_t)b * n + i] = sx[i];
 	NTG_STAMP(5);
-	if (clambda && inform != 9 && D.q_use && m > 0) {
-		// multipliers estimate lam = (AA')^-1 A g at the final point (the Q form does not produce it)
-		double gn2f;
-		(void)eval_cost<FAM, NOUT, K, NT>(D, S, sx, sg, &gn2f);
-		__syncthreads();
-		for (int r = tid; r < m; r += NT) {
-			double a = 0.0;
-			for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
-			tmp[r] = a;
-		}
-		__syncthreads();
-		for (int r = tid; r < m; r += NT) {
-			double a = 0.0;
-			for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
-			S.lam[r] = a;
-		}
-		__syncthreads();
-	}
 	if (clambda) {
 		const int ntot = n + m + D.ncnln;
 		for (int i = tid; i < ntot; i += NT)
@@ -980,10 +1091,10 @@ hostcost_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__
 	const int P = D.P, nz = D.nz;
 	for (int i = threadIdx.x; i < P; i += NT) S.fvals[i] = D.nucf ? fT[i] : 0.0;
 	__syncthreads();
-	for (int e = threadIdx.x; e < P * nz; e += NT) { const int i = e / nz, v = e % nz; if (D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * P + i] = D.nucf ? S.wts[i] * dfT[e] : 0.0; }
+	for (int e = threadIdx.x; e < P * nz; e += NT) { const int i = e / nz, v = e % nz; if (D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = D.nucf ? S.wts[i] * dfT[e] : 0.0; }
 	for (int v = threadIdx.x; v <= nz; v += NT) { S.dfi[v] = D.nicf ? fdI[v] : 0.0; S.dff[v] = D.nfcf ? fdF[v] : 0.0; }
 	double gn2;
-	const double val = cost_phase2<0, 0, NT>(D, S, S.vecs, &gn2);
+	const double val = cost_phase2<0, 0, NT>(D, S, S.vecs, &gn2, CoefMap<4>());
 	if (threadIdx.x == 0) *F = val;
 	for (int i = threadIdx.x; i < D.nC; i += NT) g[i] = S.vecs[i];
 }
@@ -1002,11 +1113,13 @@ __global__ void hostcon_kernel(NtgDims D, NtgTables T, const double *__restrict_
 	const double *dcrow = dc + (size_t)row * D.nz;
 	for (int o = 0; o < D.nout; o++) {
 		const int k = D.order[o], cc = D.cls[o], d = D.d[o];
-		const double *b = T.blk + D.cls_blk[cc] + (size_t)bp * k * d;
 		const int col0 = D.iC[o] + T.off[cc * D.P + bp];
 		for (int q = 0; q < k; q++) {
 			double a = 0.0;
-			for (int r = 0; r < d; r++) a += dcrow[D.iz[o] + r] * b[q * d + r];
+			for (int r = 0; r < d; r++) {
+				const int chr = T.chrow[cc * NTG_MAX_ORDER + r];
+				if (chr >= 0) a += dcrow[D.iz[o] + r] * T.rowv[chr + q * D.P + bp];
+			}
 			if (jband) jband[(size_t)row * D.sumk + D.koff[o] + q] = a;
 			if (cjac) cjac[(size_t)(col0 + q) * D.ncnln + row] = a;
 		}
@@ -1048,27 +1161,30 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int memcap)
 	SmemLayout L;
 	int p = 0;
 	const int npad = (D.nC + 1) & ~1;
-	L.blk = p; p = align16(p + D.blk_total * 8);
+	L.rowv = p; p = align16(p + D.row_total * 8);
+	L.coli = p; p = align16(p + D.col_total * 2);
+	L.colq = p; p = align16(p + D.col_total);
+	L.chrow = p; p = align16(p + D.nclass * NTG_MAX_ORDER * 4);
+	L.chcol = p; p = align16(p + D.nclass * NTG_MAX_ORDER * 4);
 	L.off = p; p = align16(p + D.nclass * D.P * 4);
 	L.bps = p; p = align16(p + D.P * 8);
 	L.wts = p; p = align16(p + D.P * 8);
-	L.ivl_lo = p; p = align16(p + D.ivl_total * 4);
-	L.ivl_hi = p; p = align16(p + D.ivl_total * 4);
+	L.ivl_lo = L.ivl_hi = p;
 	L.x = p; p = align16(p + npad * 8);
-	L.dfz = p; p = align16(p + (D.ntav > 0 ? D.ntav : 1) * D.P * 8);
+	L.dfz = p; p = align16(p + (D.ntav > 0 ? D.ntav : 1) * (D.P + 1) * 8);   // [row][P+1], last entry stays 0 (padding target)
 	L.fvals = p; p = align16(p + D.P * 8);
 	L.red = p; p = align16(p + 16 * (nthreads / 64 + 1) * 8);
 	L.dfi = p; p = align16(p + (D.nz + 1) * 8);
 	L.dff = p; p = align16(p + (D.nz + 1) * 8);
 	L.vecs = p; p = align16(p + (nvec * npad + 2 * D.nclin + 2) * 8);
 	L.lam = p; p = align16(p + (D.nclin + 1) * 8);
-	L.rho = p; p = align16(p + (memcap + 1) * 8);
-	L.c2 = p; p = align16(p + (memcap + 1) * 8);
-	L.oinfo = p; p = align16(p + NTG_MAX_OUT * 10 * 4);
-	L.tavrow = p; p = align16(p + NTG_MAX_NZ * 4);
+	L.rho = L.c2 = p;   // rho_i, c2_i travel with the pair in HBM
+	L.oinfo = p; p = align16(p + D.nout * 10 * 4);
+	L.tavrow = p; p = align16(p + D.nz * 4);
+	L.ls = p; p = align16(p + (int)sizeof(LineSearch));
 	L.q_idx = L.q_col = L.q_val = p;
 	if (D.q_use) {
-		L.q_idx = p; p = align16(p + D.nC * 4);
+		L.q_idx = p; p = align16(p + D.nC * 2);
 		L.q_col = p; p = align16(p + D.q_nt * D.q_w * 4);
 		L.q_val = p; p = align16(p + D.q_nt * D.q_w * 8);
 	}
@@ -1125,14 +1241,14 @@ static hipError_t launch_sqp_nt(int nt, const NtgDims &D, const NtgTables &T, co
 // (runtime nout/order, any maxderiv)
 #define NTG_DISPATCH(CALL)                                                                      \
 	const bool d3 = [&] { for (int o = 0; o < D.nout; o++) if (D.d[o] != 3) return false; return true; }(); \
-	const int ku = D.uniform ? D.order[0] : 0;                                                   \
+	const int ku = (D.uniform && D.nC <= 4 * nt) ? D.order[0] : 0;                               \
 	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 2 && ku == 6) return CALL(NTG_FAM_KINCAR, 2, 6); \
 	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 6 && ku == 6) return CALL(NTG_FAM_KINCAR, 6, 6); \
 	if (D.family == NTG_FAM_KINCAR && d3 && D.nout == 2 && ku == 5) return CALL(NTG_FAM_KINCAR, 2, 5); \
 	if (D.family == NTG_FAM_KINCAR) return CALL(NTG_FAM_KINCAR, 0, 0);                            \
 	if (D.family == NTG_FAM_VANDERPOL && d3 && ku == 5) return CALL(NTG_FAM_VANDERPOL, 1, 5);     \
 	if (D.family == NTG_FAM_VANDERPOL) return CALL(NTG_FAM_VANDERPOL, 0, 0);                      \
-	if (D.family == NTG_FAM_TESTFAM && d3 && D.nout == 3) return CALL(NTG_FAM_TESTFAM, 3, 0);     \
+	if (D.family == NTG_FAM_TESTFAM && d3 && D.nout == 3 && D.nC <= 4 * nt) return CALL(NTG_FAM_TESTFAM, 3, 0); \
 	if (D.family == NTG_FAM_TESTFAM) return CALL(NTG_FAM_TESTFAM, 0, 0);                          \
 	return hipErrorInvalidValue;
 

@@ -35,6 +35,10 @@ struct NtgDims {
 	int sinv_nnz;                       // sparse (A A')^-1 (block diagonal when the rows decouple)
 	int q_use, q_nt, q_w;               // projector Q = A'(AA')^-1 A kept as ELL over its non-zero rows
 	int max_bpi;                        // most breakpoints inside one knot interval (over classes)
+	// collocation matrix of every ACTIVE (class, derivative) channel, in two sparse forms
+	int row_total, col_total;           // doubles in rowv / entries in colv+coli
+	int cls_W[NTG_MAX_OUT];             // padded (multiple of 4) support width of the column form, per class
+	int cls_nc[NTG_MAX_OUT];            // coefficients per output of the class
 	int tav_rmask;                      // union over outputs of the derivative indices with a cost AV
 };
 
@@ -47,20 +51,27 @@ struct NtgTables {
 	const double *aband;   // [nclin][sumk]
 	const int *rbp;        // [nclin]
 	const double *sinv;    // [nclin][nclin]  (A A')^-1
-	const double *n0;      // [nC][nC] symmetric preconditioner, or nullptr
+	// preconditioner W0 = Z(Z'H0Z)^-1 Z' as ELL, s-major ([s][nC]) so that lanes with consecutive rows
+	// read consecutive words; exact zeros dropped (block diagonal when outputs decouple); nullptr: none
+	const double *n0; const unsigned short *n0c; int n0_w;
 	// sparse A: CSR (rows) and CSC (columns)
 	const int *csr_ptr, *csr_col; const double *csr_val;
 	const int *csc_ptr, *csc_row; const double *csc_val;
 	const int *sinv_ptr, *sinv_col; const double *sinv_val;   // CSR of (A A')^-1
-	const int *q_idx;      // [nC] row of coefficient c in the compact Q, or -1
+	// rowv[chrow + q*P + bp]  = D^r B_{off(bp)+q}(bps[bp])      (by breakpoint: Z = M C, Jacobian rows)
+	// (coli, colq)[chcol + s*nc + cl] = breakpoint and block column of the s-th non-zero of column cl of
+	// the same matrix (value = rowv[chrow + colq*P + coli]); padding entries point at (P, 0) -> weight 0
+	// chrow/chcol[class*NTG_MAX_ORDER + r] = channel offsets, -1 when no active variable uses D^r
+	const double *rowv; const unsigned short *coli; const unsigned char *colq; const int *chrow, *chcol;
+	const short *q_idx;    // [nC] row of coefficient c in the compact Q, or -1
 	const int *q_col;      // [q_nt][q_w]
 	const double *q_val;   // [q_nt][q_w], zero padded
 };
 
 // byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
 struct SmemLayout {
-	int blk, off, bps, wts, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
-	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, q_idx, q_col, q_val, total;
+	int rowv, coli, colq, chrow, chcol, off, bps, wts, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
+	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, q_idx, q_col, q_val, ls, total;
 };
 
 struct SolveParams {

@@ -35,6 +35,8 @@ extern "C" void ntg_default_opts(ntg_solve_opts *o)
 	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->block_threads = 0;
 }
 extern "C" const char *ntg_solve_kernel_name(void) { return "sqp_kernel"; }
+// diagnostic: LDS bytes and block size the solve / eval launches of this plan use
+extern "C" int ntg_debug_layout(const ntg_plan *p, const ntg_solve_opts *o, int *lds_solve, int *lds_eval, int *nt_solve);
 
 // ---------------- small dense helpers (row-major, host) ----------------
 static bool chol_lower(std::vector<double> &a, int n)
@@ -209,6 +211,50 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	NtgTables &T = p->T;
 	std::memset(&T, 0, sizeof(T));
 	T.bps = d_bps; T.blk = d_blk; T.off = d_off; T.ivl_lo = d_ilo; T.ivl_hi = d_ihi;
+	// ---- active (class, derivative) channels: a derivative row is kept on chip only if some
+	//      active variable (any of the six lists) uses it; host callbacks use all of them ----
+	{
+		const u64 all = D.icost_mask | D.tcost_mask | D.fcost_mask | D.icon_mask | D.tcon_mask | D.fcon_mask;
+		std::vector<int> chrow((size_t)D.nclass * NTG_MAX_ORDER, -1), chcol((size_t)D.nclass * NTG_MAX_ORDER, -1);
+		std::vector<double> rowv; std::vector<unsigned short> coli; std::vector<unsigned char> colq;
+		if (s->nbps > 65535) { ntg_plan_destroy(p); return fail(NTG_E_UNSUPPORTED, "more than 65535 breakpoints"); }
+		for (int c = 0; c < D.nclass; c++) {
+			const int k = D.cls_k[c], dd = D.cls_d[c], P = s->nbps, nc = D.ncoef[rep[c]];
+			const double *blk = p->h_blk.data() + D.cls_blk[c];
+			const int *off = p->h_off.data() + (size_t)c * P;
+			// support width of the column form (same for every derivative of the class)
+			std::vector<int> cnt(nc, 0);
+			for (int i = 0; i < P; i++) for (int q = 0; q < k; q++) cnt[off[i] + q]++;
+			int W = 0; for (int v : cnt) W = std::max(W, v);
+			const int W4 = (W + 3) & ~3;
+			D.cls_W[c] = W4; D.cls_nc[c] = nc;
+			for (int r = 0; r < dd; r++) {
+				bool active = s->family == NTG_FAM_HOST;
+				for (int o = 0; o < s->nout; o++) if (D.cls[o] == c && ((all >> (D.iz[o] + r)) & 1ull)) active = true;
+				if (!active) continue;
+				chrow[(size_t)c * NTG_MAX_ORDER + r] = (int)rowv.size();
+				chcol[(size_t)c * NTG_MAX_ORDER + r] = (int)coli.size();
+				for (int q = 0; q < k; q++) for (int i = 0; i < P; i++) rowv.push_back(blk[((size_t)i * k + q) * dd + r]);
+				const size_t base = coli.size();
+				// padding entries point at breakpoint index P (the always-zero tail of a dfz row), column 0
+				coli.resize(base + (size_t)W4 * nc, (unsigned short)P); colq.resize(base + (size_t)W4 * nc, 0);
+				std::vector<int> fill(nc, 0);
+				for (int i = 0; i < P; i++) for (int q = 0; q < k; q++) {
+					const int cl = off[i] + q, sidx = fill[cl]++;
+					coli[base + (size_t)sidx * nc + cl] = (unsigned short)i;
+					colq[base + (size_t)sidx * nc + cl] = (unsigned char)q;
+				}
+			}
+		}
+		D.row_total = (int)rowv.size() + 1; D.col_total = (int)coli.size();   // +1: padding entries read rowv[ch + P] (finite, times 0)
+		rowv.push_back(0.0);
+		if (coli.empty()) { coli.push_back(0); colq.push_back(0); }
+		double *d_rowv = nullptr; unsigned short *d_coli = nullptr; unsigned char *d_colq = nullptr; int *d_chrow = nullptr, *d_chcol = nullptr;
+		if (dev_upload(&d_rowv, rowv.data(), rowv.size(), own) || dev_upload(&d_colq, colq.data(), colq.size(), own) ||
+		    dev_upload(&d_coli, coli.data(), coli.size(), own) || dev_upload(&d_chrow, chrow.data(), chrow.size(), own) ||
+		    dev_upload(&d_chcol, chcol.data(), chcol.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+		T.rowv = d_rowv; T.colq = d_colq; T.coli = d_coli; T.chrow = d_chrow; T.chcol = d_chcol;
+	}
 
 	// ---- linear constraint rows on the device, (A A')^-1 on the host ----
 	if (D.nclin > 0) {
@@ -279,12 +325,12 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 			std::vector<double> SA((size_t)m * nC, 0.0), Q((size_t)nC * nC, 0.0);
 			for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) { const double sij = Sinv[(size_t)i * m + j]; if (sij != 0.0) for (int c = 0; c < nC; c++) SA[(size_t)i * nC + c] += sij * Ad[(size_t)j * nC + c]; }
 			for (int i = 0; i < m; i++) for (int a = 0; a < nC; a++) { const double aia = Ad[(size_t)i * nC + a]; if (aia != 0.0) for (int c = 0; c < nC; c++) Q[(size_t)a * nC + c] += aia * SA[(size_t)i * nC + c]; }
-			std::vector<int> qidx(nC, -1); int nt = 0, w = 0;
-			for (int a = 0; a < nC; a++) { int cnt = 0; for (int c = 0; c < nC; c++) if (Q[(size_t)a * nC + c] != 0.0) cnt++; if (cnt) { qidx[a] = nt++; w = std::max(w, cnt); } }
-			if (nt > 0 && (size_t)nt * w * 12 + (size_t)nC * 4 <= 16 * 1024) {
+			std::vector<short> qidx(nC, -1); int nt = 0, w = 0;
+			for (int a = 0; a < nC; a++) { int cnt = 0; for (int c = 0; c < nC; c++) if (Q[(size_t)a * nC + c] != 0.0) cnt++; if (cnt) { qidx[a] = (short)std::min(nt, 32000); nt++; w = std::max(w, cnt); } }
+			if (nt > 0 && nt < 32000 && (size_t)nt * w * 12 + (size_t)nC * 2 <= 16 * 1024) {
 				std::vector<int> qcol((size_t)nt * w, 0); std::vector<double> qval((size_t)nt * w, 0.0);
 				for (int a = 0; a < nC; a++) if (qidx[a] >= 0) { int e = 0; for (int c = 0; c < nC; c++) if (Q[(size_t)a * nC + c] != 0.0) { qcol[(size_t)qidx[a] * w + e] = c; qval[(size_t)qidx[a] * w + e] = Q[(size_t)a * nC + c]; e++; } }
-				int *d_qi = nullptr, *d_qc = nullptr; double *d_qv = nullptr;
+				short *d_qi = nullptr; int *d_qc = nullptr; double *d_qv = nullptr;
 				if (dev_upload(&d_qi, qidx.data(), qidx.size(), own) || dev_upload(&d_qc, qcol.data(), qcol.size(), own) ||
 				    dev_upload(&d_qv, qval.data(), qval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 				T.q_idx = d_qi; T.q_col = d_qc; T.q_val = d_qv;
@@ -415,9 +461,19 @@ static int build_precond(ntg_plan *p)
 		for (int k = 0; k < nr; k++) s += Zt[(size_t)k * n + i] * X[(size_t)j * nr + k];
 		W0[(size_t)i * n + j] = s; W0[(size_t)j * n + i] = s;
 	}
-	double *d_n0 = nullptr;
-	if (dev_upload(&d_n0, W0.data(), W0.size(), p->owned)) return NTG_E_HIP;
-	p->T.n0 = d_n0;
+	// entries at rounding level relative to the diagonal are noise of the orthogonal factorisation
+	// (outputs that no constraint couples give exactly decoupled blocks): drop them
+	for (int i = 0; i < n; i++) for (int j = 0; j < n; j++)
+		if (std::fabs(W0[(size_t)i * n + j]) <= 1e-13 * std::sqrt(std::fabs(W0[(size_t)i * n + i] * W0[(size_t)j * n + j]))) W0[(size_t)i * n + j] = 0.0;
+	// ELL, s-major, zeros dropped
+	int w = 0;
+	for (int i = 0; i < n; i++) { int cnt = 0; for (int j = 0; j < n; j++) if (W0[(size_t)i * n + j] != 0.0) cnt++; w = std::max(w, cnt); }
+	if (n > 65535) return fail(NTG_E_UNSUPPORTED, "preconditioner: more than 65535 coefficients");
+	std::vector<double> ev((size_t)w * n, 0.0); std::vector<unsigned short> ec((size_t)w * n, 0);
+	for (int i = 0; i < n; i++) { int e = 0; for (int j = 0; j < n; j++) if (W0[(size_t)i * n + j] != 0.0) { ev[(size_t)e * n + i] = W0[(size_t)i * n + j]; ec[(size_t)e * n + i] = (unsigned short)j; e++; } }
+	double *d_n0 = nullptr; unsigned short *d_n0c = nullptr;
+	if (dev_upload(&d_n0, ev.data(), ev.size(), p->owned) || dev_upload(&d_n0c, ec.data(), ec.size(), p->owned)) return NTG_E_HIP;
+	p->T.n0 = d_n0; p->T.n0c = d_n0c; p->T.n0_w = w;
 	return 0;
 }
 
@@ -446,7 +502,7 @@ extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, con
 	if (!p) return 0;
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
-	return (long long)batch * sp.memcap * 2 * p->D.nC * 8 + 256;
+	return (long long)batch * sp.memcap * (2 * p->D.nC + 2) * 8 + 256;
 }
 
 extern "C" int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
@@ -496,7 +552,7 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	resolve_params(p, o, &sp, &nt);
 	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
 	if (sp.hessian == 1 && !p->T.n0) { int rc = build_precond(p); if (rc) return rc; }
-	SmemLayout L = ntg_make_layout(p->D, nt, 6, sp.memcap);
+	SmemLayout L = ntg_make_layout(p->D, nt, 5, sp.memcap);
 	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
 	HIPCHK(ntg_launch_sqp(nt, p->D, p->T, L, sp, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev,
 	                      d_clambda, (double *)d_work, (hipStream_t)stream));
@@ -512,5 +568,16 @@ extern "C" int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int
 	if (ngrids > 65535) return fail(NTG_E_BADARG, "at most 65535 grids per call");
 	HIPCHK(ntg_launch_basis(ngrids, ninterv, order, mult, maxderiv, nbps, d_knots, d_bps, ninterv + 1, nbps, d_blk, d_off,
 	                        (hipStream_t)stream));
+	return 0;
+}
+
+extern "C" int ntg_debug_layout(const ntg_plan *p, const ntg_solve_opts *o, int *lds_solve, int *lds_eval, int *nt_solve)
+{
+	if (!p) return NTG_E_BADARG;
+	SolveParams sp; int nt;
+	resolve_params(p, o, &sp, &nt);
+	if (lds_solve) *lds_solve = ntg_make_layout(p->D, nt, 5, sp.memcap).total;
+	if (lds_eval) *lds_eval = ntg_make_layout(p->D, (p->D.P <= 128 && p->D.nC <= 512) ? 128 : 256, 1, 0).total;
+	if (nt_solve) *nt_solve = nt;
 	return 0;
 }
