@@ -37,6 +37,14 @@
 // ------------------------------------------------------------------------------------------
 // reductions: sum K values over the workgroup, result broadcast to every lane
 // ------------------------------------------------------------------------------------------
+// Workgroup barrier for LDS-only hand-offs.  __syncthreads() also drains vmcnt(0), which would
+// serialise every in-flight HBM load (history pairs, prefetched coefficient vectors) behind each of
+// the many barriers of this kernel; LDS visibility only needs lgkmcnt(0) on both sides.
+__device__ __forceinline__ void lds_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // 64-lane wavefront sum with DPP (row shifts + row broadcasts stay in the VALU; __shfl_down
 // would go through ds_bpermute, i.e. the LDS crossbar, ~100 cycles per hop).  The total lands
 // in lane 63 and is broadcast from there through an SGPR.
@@ -68,12 +76,12 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 	for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
 	if (NW == 1) return;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	__syncthreads(); // red[] may still be read by the previous call
+	lds_sync(); // red[] may still be read by the previous call
 	if (lane == 0) {
 #pragma unroll
 		for (int k = 0; k < K; k++) red[k * NW + wave] = v[k];
 	}
-	__syncthreads();
+	lds_sync();
 #pragma unroll
 	for (int k = 0; k < K; k++) {
 		double s = red[k * NW];
@@ -271,7 +279,7 @@ __global__ void bounds_kernel(NtgDims D, int batch, const double *__restrict__ l
 // LDS carve-up shared by eval_kernel and sqp_kernel
 // ------------------------------------------------------------------------------------------
 struct Smem {
-	double *rowv; unsigned short *coli; unsigned char *colq; int *chrow, *chcol;
+	double *rowv; unsigned int *colp; int *chrow, *chcol;
 	int *off; double *bps, *wts; int *ivl_lo, *ivl_hi;
 	double *x, *dfz, *fvals, *red, *dfi, *dff, *vecs, *lam, *rho, *c2;
 	// sparse linear-constraint operator: LDS copies when they fit, HBM/L2 otherwise
@@ -280,7 +288,7 @@ struct Smem {
 	short *q_idx; int *q_col; double *q_val;
 	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T)
 	{
-		rowv = (double *)(base + L.rowv); coli = (unsigned short *)(base + L.coli); colq = (unsigned char *)(base + L.colq);
+		rowv = (double *)(base + L.rowv); colp = (unsigned int *)(base + L.colp);
 		chrow = (int *)(base + L.chrow); chcol = (int *)(base + L.chcol);
 		off = (int *)(base + L.off); bps = (double *)(base + L.bps);
 		wts = (double *)(base + L.wts);
@@ -308,7 +316,7 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 {
 	const int tid = threadIdx.x;
 	for (int i = tid; i < D.row_total; i += NT) S.rowv[i] = T.rowv[i];
-	for (int i = tid; i < D.col_total; i += NT) { S.coli[i] = T.coli[i]; S.colq[i] = T.colq[i]; }
+	for (int i = tid; i < D.col_total; i += NT) S.colp[i] = T.colp[i];
 	for (int i = tid; i < D.nclass * NTG_MAX_ORDER; i += NT) { S.chrow[i] = T.chrow[i]; S.chcol[i] = T.chcol[i]; }
 	for (int i = tid; i < D.nclass * D.P; i += NT) S.off[i] = T.off[i];
 	for (int i = tid; i < D.P; i += NT) {
@@ -432,7 +440,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
 	using Fam = Family<FAM>;
-	__syncthreads(); // sx complete, previous users of dfz/fvals done
+	lds_sync(); // sx complete, previous users of dfz/fvals done
 	if (D.nucf && !(g_ntg_dbg & 2)) {
 		for (int i = tid; i < P; i += NT) {                       // cost.c:103-109
 			double z[NZ], df[NZ], f;
@@ -467,7 +475,7 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 {
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
-	__syncthreads();
+	lds_sync();
 	// trapezoid of the running cost (integrator.c:21-24); per-interval terms across the lanes,
 	// wavefront reduction
 	double acc[2] = {0.0, 0.0};
@@ -499,19 +507,21 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 					if (!((D.tav_rmask >> r) & 1)) continue;                 // wave-uniform
 					const int row = S.tavrow[3 * o + r], chc = S.chcol[chb + r];
 					if (row < 0 || chc < 0) continue;
-					const unsigned short *ci = S.coli + chc + cl; const unsigned char *cq = S.colq + chc + cl;
 					const double *rv = S.rowv + S.chrow[chb + r]; const double *wdf = S.dfz + row * (P + 1);
 					if (W > 0) {
-						int ii[W > 0 ? W : 1], qq[W > 0 ? W : 1];
+						// W packed entries of this column, contiguous and 16-byte aligned: read as uint4
+						const uint4 *cp4 = (const uint4 *)(S.colp + chc + cl * Wr);
+						unsigned int pe[W > 0 ? W : 4];
 #pragma unroll
-						for (int s2 = 0; s2 < W; s2++) { ii[s2] = ci[s2 * nc]; qq[s2] = cq[s2 * nc]; }
+						for (int s4 = 0; s4 < W / 4; s4++) { const uint4 t4 = cp4[s4]; pe[4 * s4] = t4.x; pe[4 * s4 + 1] = t4.y; pe[4 * s4 + 2] = t4.z; pe[4 * s4 + 3] = t4.w; }
 						double vv[W > 0 ? W : 1], ww[W > 0 ? W : 1];
 #pragma unroll
-						for (int s2 = 0; s2 < W; s2++) { vv[s2] = rv[qq[s2] * P + ii[s2]]; ww[s2] = wdf[ii[s2]]; }
+						for (int s2 = 0; s2 < W; s2++) { vv[s2] = rv[pe[s2] >> 16]; ww[s2] = wdf[pe[s2] & 0xffffu]; }
 #pragma unroll
 						for (int s2 = 0; s2 < W; s2++) dIn += vv[s2] * ww[s2];
 					} else {
-						for (int s2 = 0; s2 < Wr; s2++) { const int i2 = ci[s2 * nc]; dIn += rv[cq[s2 * nc] * P + i2] * wdf[i2]; }
+						const unsigned int *cp = S.colp + chc + cl * Wr;
+						for (int s2 = 0; s2 < Wr; s2++) { const unsigned int pe = cp[s2]; dIn += rv[pe >> 16] * wdf[pe & 0xffffu]; }
 					}
 				}
 				sg[c] = dIn;
@@ -520,9 +530,9 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 			}
 		};
 		const int W4 = D.uniform ? D.cls_W[0] : 1000;
-		if (W4 <= 8) gather(std::integral_constant<int, 8>());
-		else if (W4 <= 12) gather(std::integral_constant<int, 12>());
-		else if (W4 <= 16) gather(std::integral_constant<int, 16>());
+		if (W4 == 8) gather(std::integral_constant<int, 8>());
+		else if (W4 == 12) gather(std::integral_constant<int, 12>());
+		else if (W4 == 16) gather(std::integral_constant<int, 16>());
 		else gather(std::integral_constant<int, 0>());
 	} else {
 		for (int c = tid; c < D.nC; c += NT) {
@@ -535,8 +545,8 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 			for (int r = 0; r < d; r++) {
 				const int row = S.tavrow[iz + r], chc = S.chcol[chb + r], chr = S.chrow[chb + r];
 				if (D.nucf && row >= 0 && chc >= 0) {
-					const unsigned short *ci = S.coli + chc + cl; const unsigned char *cq = S.colq + chc + cl; const double *wdf = S.dfz + row * (P + 1);
-					for (int s = 0; s < W4; s++) { const int i2 = ci[s * nc]; dIn += S.rowv[chr + cq[s * nc] * P + i2] * wdf[i2]; }
+					const unsigned int *cp = S.colp + chc + cl * W4; const double *wdf = S.dfz + row * (P + 1);
+					for (int s = 0; s < W4; s++) { const unsigned int pe = cp[s]; dIn += S.rowv[chr + (pe >> 16)] * wdf[pe & 0xffffu]; }
 				}
 				if (chr >= 0) {
 					if (D.nicf && cl < k) dI += S.dfi[iz + r] * S.rowv[chr + cl * P];             // colloc.c:243-260 (block 0)
@@ -564,7 +574,7 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	unsigned long long t0 = 0;
 	if (tk) t0 = __builtin_amdgcn_s_memtime();
 	cost_phase1<FAM, NOUT, K, NT>(D, S, sx);
-	if (tk) { __syncthreads(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
+	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
 	const double F = cost_phase2<NOUT, K, NT>(D, S, sg, gnorm2, cm);
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
@@ -639,16 +649,36 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 	Smem S(smem_raw, L, D, T);
 	stage_tables<NT>(D, T, S, smem_raw, L);
 	double *sg = S.vecs;
-	__syncthreads();
+	lds_sync();
 	CoefMap<4> cm;
 	if (NOUT > 0) make_coefmap<NT, 4>(D, S, cm);   // the host only picks a NOUT > 0 instance when nC <= 4 NT
+	// software pipeline over problems: the coefficient vector of the NEXT problem is already in
+	// flight (registers) while the current one is evaluated
+	constexpr int XE = 4;
+	const bool xreg = D.nC <= XE * NT;
+	double xn[XE];
+	if (xreg && (int)blockIdx.x < batch) {
+#pragma unroll
+		for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; xn[e] = i < D.nC ? x[(size_t)blockIdx.x * D.nC + i] : 0.0; }
+	}
+	const int dbgk = g_ntg_dbg;
 	for (int b = blockIdx.x; b < batch; b += gridDim.x) {
-		__syncthreads();
-		for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
+		lds_sync();
+		if (xreg) {
+#pragma unroll
+			for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; if (i < D.nC) S.x[i] = xn[e]; }
+			const int bn = b + gridDim.x;
+			if (bn < batch && !(dbgk & 16)) {
+#pragma unroll
+				for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; xn[e] = i < D.nC ? x[(size_t)bn * D.nC + i] : 0.0; }
+			}
+		} else {
+			for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
+		}
 		double gn2;
 		const double F = eval_cost<FAM, NOUT, K, NT>(D, S, S.x, sg, &gn2, cm);
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
-		if (g && mode != 0)
+		if (g && mode != 0 && !(dbgk & 8))
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
 		if (D.ncnln && (c || jband || cjac))
 			eval_constraints<FAM, NOUT, K, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
@@ -666,8 +696,8 @@ template <int NT>
 __device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */)
 {
 	const int m = D.nclin, tid = threadIdx.x;
-	__syncthreads();
-	if (m == 0) { for (int c = tid; c < D.nC; c += NT) sgp[c] = sg[c]; __syncthreads(); return; }
+	lds_sync();
+	if (m == 0) { for (int c = tid; c < D.nC; c += NT) sgp[c] = sg[c]; lds_sync(); return; }
 	if (D.q_use) {
 		// gp = g - Q g with Q = A'(AA')^-1 A stored as ELL over its non-zero rows: one pass, no
 		// intermediate barrier; the padded entries (value 0, column 0) keep every load unconditional
@@ -681,7 +711,7 @@ __device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const d
 			}
 			sgp[c] = sg[c] - s;
 		});
-		__syncthreads();
+		lds_sync();
 		return;
 	}
 	for (int r = tid; r < m; r += NT) {
@@ -689,19 +719,19 @@ __device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const d
 		for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
 		tmp[r] = a;
 	}
-	__syncthreads();
+	lds_sync();
 	for (int r = tid; r < m; r += NT) {
 		double a = 0.0;
 		for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
 		S.lam[r] = a;
 	}
-	__syncthreads();
+	lds_sync();
 	for (int c = tid; c < D.nC; c += NT) {
 		double s = 0.0;
 		for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * S.lam[S.csc_row[e]];
 		sgp[c] = sg[c] - s;
 	}
-	__syncthreads();
+	lds_sync();
 }
 
 // out = W0 v for the collocation preconditioner (ELL, rows streamed from L2).  Kept out of line:
@@ -728,10 +758,10 @@ __device__ __attribute__((noinline)) void apply_n0(int n, int w, const double *_
 template <int NT>
 __device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out)
 {
-	__syncthreads();
+	lds_sync();
 	if (hessian == 1 && T.n0) apply_n0<NT>(D.nC, T.n0_w, T.n0, T.n0c, v, out);
 	else for_vec<NT>(D.nC, [&](int c) { out[c] = v[c]; });
-	__syncthreads();
+	lds_sync();
 }
 
 // t += (sum of the stored rank-2 BFGS terms) v.  Pairs are streamed from HBM/L2 once, G at a
@@ -780,7 +810,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 		}
 #pragma unroll
 		for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; if (c < n) t[c] = tt[e]; }
-		__syncthreads();
+		lds_sync();
 		return;
 	}
 	for (int base = 0; base < npairs; base += 4) {
@@ -811,7 +841,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 			t[c] = tt;
 		}
 	}
-	__syncthreads();
+	lds_sync();
 }
 
 // One workgroup solves one problem from start to finish (ntg.c:250: the npsol_ call).
@@ -837,7 +867,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	double *hist = hist_all + (size_t)b * sp.memcap * (2 * n + 2);   // pair i: [s (n) | u (n) | rho | c2]
 	stage_tables<NT>(D, T, S, smem_raw, L);
 	for (int i = tid; i < n; i += NT) sx[i] = xio[(size_t)b * n + i];
-	__syncthreads();
+	lds_sync();
 	CoefMap<4> cm;
 	if (NOUT > 0) make_coefmap<NT, 4>(D, S, cm);
 
@@ -868,19 +898,19 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sx[S.csr_col[e]];
 				tmp[r] = lower[(size_t)b * D.nbounds + s] - a;
 			}
-			__syncthreads();
+			lds_sync();
 			for (int r = tid; r < m; r += NT) {
 				double a = 0.0;
 				for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
 				S.lam[r] = a;
 			}
-			__syncthreads();
+			lds_sync();
 			for (int c = tid; c < n; c += NT) {
 				double s = 0.0;
 				for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * S.lam[S.csc_row[e]];
 				sx[c] += s;
 			}
-			__syncthreads();
+			lds_sync();
 		}
 		for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 		NTG_STAMP(0);
@@ -897,19 +927,19 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			NTG_STAMP(1);
 			if (state == ST_FINAL) {
 				// multipliers estimate lam = (AA')^-1 A g at the final point
-				__syncthreads();
+				lds_sync();
 				for (int r = tid; r < m; r += NT) {
 					double a = 0.0;
 					for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
 					tmp[r] = a;
 				}
-				__syncthreads();
+				lds_sync();
 				for (int r = tid; r < m; r += NT) {
 					double a = 0.0;
 					for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
 					S.lam[r] = a;
 				}
-				__syncthreads();
+				lds_sync();
 				break;
 			}
 			nfev++;
@@ -933,9 +963,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					block_sum<NT, 1>(dd, S.red);
 					LineSearch lsr = *lsm;
 					rc = lsr.step(Fn, dd[0]);
-					__syncthreads();
+					lds_sync();
 					if (tid == 0) *lsm = lsr;
-					__syncthreads();
+					lds_sync();
 				}
 				if (rc == 0 || rc == 2) {
 					if (rc == 2) state = ST_FORCE;
@@ -981,7 +1011,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						npairs++;
 					}
 					__threadfence_block();
-					block_sum<NT, 4>(r4, S.red);   // also orders the hist/rho writes before their next use
+					__syncthreads();   // rho/c2 of the new pair go through HBM/L2: needs the full barrier (vmcnt(0))
+					block_sum<NT, 4>(r4, S.red);
 					F = Fn; gn2 = gn2n;
 					iter++;
 					if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r4[2])) &&
@@ -1013,9 +1044,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (!finished) {
 						const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
 						const double a = amax < 1.0 ? amax : 1.0;
-						__syncthreads();
+						lds_sync();
 						if (tid == 0) lsm->init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
-						__syncthreads();
+						lds_sync();
 						state = ST_LS;
 						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * (-sd[c]); });
 					}
@@ -1025,7 +1056,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (finished) {
 				if (clambda && D.q_use && m > 0) {   // one more pass for the multipliers (the Q form does not produce them)
 					state = ST_FINAL;
-					__syncthreads();
+					lds_sync();
 					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 					continue;
 				}
@@ -1033,7 +1064,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 		}
 	}
-	__syncthreads();
+	lds_sync();
 	for (int i = tid; i < n; i += NT) xio[(size_t)b * n + i] = sx[i];
 	NTG_STAMP(5);
 	if (clambda) {
@@ -1066,7 +1097,7 @@ hostz_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__ x,
 	Smem S(smem_raw, L, D, T);
 	stage_tables<NT>(D, T, S, smem_raw, L);
 	for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[i];
-	__syncthreads();
+	lds_sync();
 	for (int i = threadIdx.x; i < D.P; i += NT) {
 		const u64 mask = maskT | (i == 0 ? maskI : 0ull) | (i == D.P - 1 ? maskF : 0ull);
 		if (!mask) continue;
@@ -1090,7 +1121,7 @@ hostcost_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__
 	stage_tables<NT>(D, T, S, smem_raw, L);
 	const int P = D.P, nz = D.nz;
 	for (int i = threadIdx.x; i < P; i += NT) S.fvals[i] = D.nucf ? fT[i] : 0.0;
-	__syncthreads();
+	lds_sync();
 	for (int e = threadIdx.x; e < P * nz; e += NT) { const int i = e / nz, v = e % nz; if (D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = D.nucf ? S.wts[i] * dfT[e] : 0.0; }
 	for (int v = threadIdx.x; v <= nz; v += NT) { S.dfi[v] = D.nicf ? fdI[v] : 0.0; S.dff[v] = D.nfcf ? fdF[v] : 0.0; }
 	double gn2;
@@ -1162,8 +1193,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int memcap)
 	int p = 0;
 	const int npad = (D.nC + 1) & ~1;
 	L.rowv = p; p = align16(p + D.row_total * 8);
-	L.coli = p; p = align16(p + D.col_total * 2);
-	L.colq = p; p = align16(p + D.col_total);
+	L.colp = p; p = align16(p + D.col_total * 4);
 	L.chrow = p; p = align16(p + D.nclass * NTG_MAX_ORDER * 4);
 	L.chcol = p; p = align16(p + D.nclass * NTG_MAX_ORDER * 4);
 	L.off = p; p = align16(p + D.nclass * D.P * 4);

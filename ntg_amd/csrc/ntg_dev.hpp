@@ -59,10 +59,10 @@ struct NtgTables {
 	const int *csc_ptr, *csc_row; const double *csc_val;
 	const int *sinv_ptr, *sinv_col; const double *sinv_val;   // CSR of (A A')^-1
 	// rowv[chrow + q*P + bp]  = D^r B_{off(bp)+q}(bps[bp])      (by breakpoint: Z = M C, Jacobian rows)
-	// (coli, colq)[chcol + s*nc + cl] = breakpoint and block column of the s-th non-zero of column cl of
-	// the same matrix (value = rowv[chrow + colq*P + coli]); padding entries point at (P, 0) -> weight 0
+	// colp[chcol + cl*W + s] = packed (q*P+i)<<16 | i of the s-th non-zero of column cl of the same
+	// matrix: value = rowv[chrow + q*P + i], breakpoint i; padding entries are (P)<<16 | P -> weight 0
 	// chrow/chcol[class*NTG_MAX_ORDER + r] = channel offsets, -1 when no active variable uses D^r
-	const double *rowv; const unsigned short *coli; const unsigned char *colq; const int *chrow, *chcol;
+	const double *rowv; const unsigned int *colp; const int *chrow, *chcol;
 	const short *q_idx;    // [nC] row of coefficient c in the compact Q, or -1
 	const int *q_col;      // [q_nt][q_w]
 	const double *q_val;   // [q_nt][q_w], zero padded
@@ -70,7 +70,7 @@ struct NtgTables {
 
 // byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
 struct SmemLayout {
-	int rowv, coli, colq, chrow, chcol, off, bps, wts, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
+	int rowv, colp, chrow, chcol, off, bps, wts, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
 	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, q_idx, q_col, q_val, ls, total;
 };
 

@@ -216,7 +216,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	{
 		const u64 all = D.icost_mask | D.tcost_mask | D.fcost_mask | D.icon_mask | D.tcon_mask | D.fcon_mask;
 		std::vector<int> chrow((size_t)D.nclass * NTG_MAX_ORDER, -1), chcol((size_t)D.nclass * NTG_MAX_ORDER, -1);
-		std::vector<double> rowv; std::vector<unsigned short> coli; std::vector<unsigned char> colq;
+		std::vector<double> rowv; std::vector<unsigned int> colp;
 		if (s->nbps > 65535) { ntg_plan_destroy(p); return fail(NTG_E_UNSUPPORTED, "more than 65535 breakpoints"); }
 		for (int c = 0; c < D.nclass; c++) {
 			const int k = D.cls_k[c], dd = D.cls_d[c], P = s->nbps, nc = D.ncoef[rep[c]];
@@ -233,27 +233,27 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 				for (int o = 0; o < s->nout; o++) if (D.cls[o] == c && ((all >> (D.iz[o] + r)) & 1ull)) active = true;
 				if (!active) continue;
 				chrow[(size_t)c * NTG_MAX_ORDER + r] = (int)rowv.size();
-				chcol[(size_t)c * NTG_MAX_ORDER + r] = (int)coli.size();
+				chcol[(size_t)c * NTG_MAX_ORDER + r] = (int)colp.size();
 				for (int q = 0; q < k; q++) for (int i = 0; i < P; i++) rowv.push_back(blk[((size_t)i * k + q) * dd + r]);
-				const size_t base = coli.size();
-				// padding entries point at breakpoint index P (the always-zero tail of a dfz row), column 0
-				coli.resize(base + (size_t)W4 * nc, (unsigned short)P); colq.resize(base + (size_t)W4 * nc, 0);
+				const size_t base = colp.size();
+				// [cl][W4] packed (q*P+i)<<16 | i; padding = (P<<16)|P: rowv[ch+P] (finite) times the zero tail of a dfz row
+				if ((size_t)k * P >= 65536) { ntg_plan_destroy(p); return fail(NTG_E_UNSUPPORTED, "order*nbps exceeds the 16-bit packed column index"); }
+				colp.resize(base + (size_t)W4 * nc, ((unsigned int)P << 16) | (unsigned int)P);
 				std::vector<int> fill(nc, 0);
 				for (int i = 0; i < P; i++) for (int q = 0; q < k; q++) {
 					const int cl = off[i] + q, sidx = fill[cl]++;
-					coli[base + (size_t)sidx * nc + cl] = (unsigned short)i;
-					colq[base + (size_t)sidx * nc + cl] = (unsigned char)q;
+					colp[base + (size_t)cl * W4 + sidx] = ((unsigned int)(q * P + i) << 16) | (unsigned int)i;
 				}
 			}
 		}
-		D.row_total = (int)rowv.size() + 1; D.col_total = (int)coli.size();   // +1: padding entries read rowv[ch + P] (finite, times 0)
+		D.row_total = (int)rowv.size() + 1; D.col_total = (int)colp.size();   // +1: padding entries read rowv[ch + P] (finite, times 0)
 		rowv.push_back(0.0);
-		if (coli.empty()) { coli.push_back(0); colq.push_back(0); }
-		double *d_rowv = nullptr; unsigned short *d_coli = nullptr; unsigned char *d_colq = nullptr; int *d_chrow = nullptr, *d_chcol = nullptr;
-		if (dev_upload(&d_rowv, rowv.data(), rowv.size(), own) || dev_upload(&d_colq, colq.data(), colq.size(), own) ||
-		    dev_upload(&d_coli, coli.data(), coli.size(), own) || dev_upload(&d_chrow, chrow.data(), chrow.size(), own) ||
+		if (colp.empty()) colp.push_back(0);
+		double *d_rowv = nullptr; unsigned int *d_colp = nullptr; int *d_chrow = nullptr, *d_chcol = nullptr;
+		if (dev_upload(&d_rowv, rowv.data(), rowv.size(), own) || dev_upload(&d_colp, colp.data(), colp.size(), own) ||
+		    dev_upload(&d_chrow, chrow.data(), chrow.size(), own) ||
 		    dev_upload(&d_chcol, chcol.data(), chcol.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
-		T.rowv = d_rowv; T.colq = d_colq; T.coli = d_coli; T.chrow = d_chrow; T.chcol = d_chcol;
+		T.rowv = d_rowv; T.colp = d_colp; T.chrow = d_chrow; T.chcol = d_chcol;
 	}
 
 	// ---- linear constraint rows on the device, (A A')^-1 on the host ----
@@ -530,8 +530,13 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem tables exceed 160 KiB of LDS");
 	hipStream_t st = (hipStream_t)stream;
 	if (d_cjac && D.ncnln) HIPCHK(hipMemsetAsync(d_cjac, 0, (size_t)batch * D.ncnln * D.nC * 8, st)); // GcJac starts zeroed (ntg.c:217)
-	const int wg_per_cu = std::max(1, std::min(8, (160 * 1024) / std::max(L.total, 1)));
-	const int grid = std::min(batch, 256 * wg_per_cu);
+	// persistent grid = what is resident at once: LDS-limited workgroups per CU, capped by the waves a
+	// CU holds (32) and by the register budget the kernel was compiled for (NTG_EVAL_WAVES per SIMD is a
+	// lower bound; 8 workgroups of 128 threads = 4 waves per SIMD is the most that can ever be resident)
+	int ncu = 256;
+	{ hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
+	const int wg_per_cu = std::max(1, std::min(std::min(8, 32 / (nt / 64)), (160 * 1024) / std::max(L.total, 1)));
+	const int grid = std::min(batch, ncu * wg_per_cu);
 	HIPCHK(ntg_launch_eval(nt, D, p->T, L, grid, batch, mode, d_x, d_f, d_g, d_c, d_jband, d_cjac, st));
 	return 0;
 }

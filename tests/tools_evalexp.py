@@ -6,7 +6,7 @@ from ntg_amd import api, configs as cf
 spec = cf.config_M(); plan = api.Plan(spec, 0)
 nb = 1 << 18
 x = torch.randn((nb, spec.nC), dtype=torch.float64, device="cuda:0")
-for dbg, name in ((0, "full"), (1, "no gather"), (2, "no phase1"), (3, "no gather, no phase1"), (7, "neither, no block_sum")):
+for dbg, name in ((0, "full"), (1, "no gather"), (2, "no phase1"), (3, "no gather, no phase1"), (7, "neither, no block_sum"), (15, "+ no g store"), (23, "+ no x load"), (31, "+ neither")):
     api.lib().ntg_debug_set(dbg)
     for _ in range(2): plan.eval(x, 2)
     torch.cuda.synchronize()
