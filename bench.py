@@ -134,10 +134,28 @@ def main():
     }
     alg_bytes = nfev_total * spec.eval_bytes()
     ach = alg_bytes / (kern_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+    # gfx950 corrections applied; profiles/traffic.json says how) -- only for the exact workload they were taken on
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        key = f"sqp_kernel:{args.config}:{B}:fixed{args.iters}"
+        if key in tj:
+            traffic = tj[key]["hbm_bytes"]
+    except Exception:
+        pass
     res["roofline"] = {"bound": "hbm", "kernel": "sqp_kernel", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kern_ms,
+                       "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms,
                        "alg_bytes_per_launch": alg_bytes,
                        "alg_bytes_def": f"{spec.eval_bytes()} B per funobj evaluation (SURVEY 8d) x {nfev_total} evaluations"}
+    # the same launch priced with the quasi-Newton pair history counted as algorithmic traffic (full-memory BFGS
+    # reads every stored pair once per major and writes one pair per major: DESIGN.md section 5)
+    it_np = iters_np.astype(np.int64)
+    qn_bytes = int(((it_np * (it_np - 1) // 2) * (2 * spec.nC + 2) * 8 + it_np * (2 * spec.nC + 2) * 8).sum())
+    incl = alg_bytes + qn_bytes
+    res["roofline_with_qn_history"] = {"bound": "hbm", "achieved": incl / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": incl / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": incl,
+                                       "traffic_over_alg": (traffic / incl) if traffic else None}
 
     if rank == 0 and world == 1 and not args.no_extras:
         # ---- product default mode: preconditioned, to convergence ----

@@ -68,14 +68,85 @@ __device__ __forceinline__ double wave_sum(double v)
 	return __hiloint2double(hi, lo);
 }
 
+// exchange a double with the lane whose index differs in one bit (1, 2, 4, 8: DPP inside a row of
+// 16; 16: ds_swizzle; 32: bpermute)
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_mov(double v, double old)
+{
+	const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+	return __hiloint2double(hi, lo);
+}
+template <int BIT>
+__device__ __forceinline__ double lane_xchg(double v)
+{
+	if (BIT == 1) return dpp_mov<0xB1, 0xf>(v, 0.0);                       // quad_perm [1,0,3,2]
+	if (BIT == 2) return dpp_mov<0x4E, 0xf>(v, 0.0);                       // quad_perm [2,3,0,1]
+	if (BIT == 4) return dpp_mov<0x114, 0xA>(v, dpp_mov<0x104, 0x5>(v, 0.0)); // row_shl:4 into banks 0,2 ; row_shr:4 into banks 1,3
+	if (BIT == 8) return dpp_mov<0x128, 0xf>(v, 0.0);                      // row_ror:8
+	if (BIT == 16) {
+		const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+		return __hiloint2double(hi, lo);
+	}
+	return __shfl_xor(v, 32, 64);
+}
+
+// Sum KV (<= 16) per-lane values over the 64 lanes with the "halving" butterfly: at the step of
+// bit b a lane keeps the half of its values whose index has bit b equal to its own lane bit and
+// hands the other half to its partner, so the number of live values halves every step (15 exchanges
+// for 16 values instead of 16 x 6).  Afterwards lane L holds the wave total of value L & 15.
+template <int KV, int N, int BIT>
+__device__ __forceinline__ void halve_step(const double *in, double *out, int lane)
+{
+	const bool hi = (lane & BIT) != 0;
+#pragma unroll
+	for (int j = 0; j < N / 2; j++) {
+		// original indices covered by in[2j] / in[2j+1] start at (2j)*BIT and (2j+1)*BIT: skip all-padding pairs
+		if ((2 * j) * BIT >= KV) { out[j] = 0.0; continue; }
+		const double a = in[2 * j], b = ((2 * j + 1) * BIT < KV) ? in[2 * j + 1] : 0.0;
+		const double keep = hi ? b : a, send = hi ? a : b;
+		out[j] = keep + lane_xchg<BIT>(send);
+	}
+}
+template <int KV>
+__device__ __forceinline__ double wave_sum_many(const double *v, int lane)   // v has 16 slots, KV valid
+{
+	double a[8], b[4], c[2], d[1];
+	halve_step<KV, 16, 1>(v, a, lane);
+	halve_step<KV, 8, 2>(a, b, lane);
+	halve_step<KV, 4, 4>(b, c, lane);
+	halve_step<KV, 2, 8>(c, d, lane);
+	double t = d[0];
+	t += lane_xchg<16>(t);
+	t += lane_xchg<32>(t);
+	return t;
+}
+
 template <int NT, int K>
 __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 {
 	constexpr int NW = NT / 64;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (K >= 4) {
+		double w[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) w[k] = k < K ? v[k] : 0.0;
+		const double t = wave_sum_many<K>(w, lane);   // lane L: wave total of value L & 15
+		lds_sync(); // red[] may still be read by the previous call
+		if (lane < K) red[lane * NW + wave] = t;
+		lds_sync();
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			double s2 = red[k * NW];
+#pragma unroll
+			for (int w2 = 1; w2 < NW; w2++) s2 += red[k * NW + w2];
+			v[k] = s2;
+		}
+		return;
+	}
 #pragma unroll
 	for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
 	if (NW == 1) return;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	lds_sync(); // red[] may still be read by the previous call
 	if (lane == 0) {
 #pragma unroll
