@@ -128,8 +128,27 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
                     const double *d_knots, const double *d_bps, double *d_blk, int *d_off,
                     void *stream);
 
-/* NPSOL-facing callbacks of the single-problem drop-in (valid while ntg() is running, or
- * after ntg_set_current_plan()).  Host pointers, Fortran conventions (scalars by pointer),
+/* ntg_open(): everything ntg() does before it calls npsol_ (ntg.c:114-229), with ntg()'s own
+ * argument list minus initialguess, the bounds and the outputs; the problem stays current until
+ * ntg_close().  For external SQP/IPOPT drivers (Pending:9) that iterate on their own and only need
+ * the two callbacks below. */
+int ntg_open(
+	int nout, double *bps, int nbps, int *kninterv, double **knots, int *order, int *mult, int *max_deriv,
+	int nlic, double **lic, int nltc, double **ltc, int nlfc, double **lfc,
+	int nnlic, void (*nlicf)(int *, int *, double *, double **, double **),
+	int nnltc, void (*nltcf)(int *, int *, int *, double *, double **, double **),
+	int nnlfc, void (*nlfcf)(int *, int *, double *, double **, double **),
+	int ninitialconstrav, ntg_av *initialconstrav, int ntrajectoryconstrav, ntg_av *trajectoryconstrav,
+	int nfinalconstrav, ntg_av *finalconstrav,
+	int nicf, void (*icf)(int *, int *, double *, double *, double **),
+	int nucf, void (*ucf)(int *, int *, int *, double *, double *, double **),
+	int nfcf, void (*fcf)(int *, int *, double *, double *, double **),
+	int ninitialcostav, ntg_av *initialcostav, int ntrajectorycostav, ntg_av *trajectorycostav,
+	int nfinalcostav, ntg_av *finalcostav);
+void ntg_close(void);
+
+/* NPSOL-facing callbacks of the single-problem drop-in (valid while ntg() is running or between
+ * ntg_open() and ntg_close()).  Host pointers, Fortran conventions (scalars by pointer),
  * cJac column-major ldJ x n. */
 void npsolCostFunction(int *mode, int *n, double *x, double *f, double *g, int *nstate);
 void npsolConstraintFunction(int *mode, int *ncnln, int *n, int *ldJ, int *needc, double *x,

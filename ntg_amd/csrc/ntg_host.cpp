@@ -236,19 +236,21 @@ extern "C" void printNTGBanner(void)
 }
 
 // ---------------- the drop-in ----------------
-extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **knots, int *order, int *mult,
-                    int *maxderiv, double *initialguess,
-                    int nlic, double **lic, int nltc, double **ltc, int nlfc, double **lfc,
-                    int nnlic, nlic_t nlicf, int nnltc, nltc_t nltcf, int nnlfc, nlic_t nlfcf,
-                    int nicav, AV *icav, int ntcav, AV *tcav, int nfcav, AV *fcav,
-                    double *lowerb, double *upperb,
-                    int nicf, icf_t icf, int nucf, ucf_t ucf, int nfcf, icf_t fcf,
-                    int nicostav, AV *icostav, int ntcostav, AV *tcostav, int nfcostav, AV *fcostav,
-                    int *istate, double *clambda, double *R, int *inform, double *objective)
+#define NTG_PROBLEM_ARGS                                                                                     \
+	int nout, double *bps, int nbps, int *kninterv, double **knots, int *order, int *mult, int *maxderiv,        \
+	int nlic, double **lic, int nltc, double **ltc, int nlfc, double **lfc,                                      \
+	int nnlic, nlic_t nlicf, int nnltc, nltc_t nltcf, int nnlfc, nlic_t nlfcf,                                   \
+	int nicav, AV *icav, int ntcav, AV *tcav, int nfcav, AV *fcav,                                               \
+	int nicf, icf_t icf, int nucf, ucf_t ucf, int nfcf, icf_t fcf,                                               \
+	int nicostav, AV *icostav, int ntcostav, AV *tcostav, int nfcostav, AV *fcostav
+#define NTG_PROBLEM_PASS                                                                                     \
+	nout, bps, nbps, kninterv, knots, order, mult, maxderiv, nlic, lic, nltc, ltc, nlfc, lfc, nnlic, nlicf,      \
+	nnltc, nltcf, nnlfc, nlfcf, nicav, icav, ntcav, tcav, nfcav, fcav, nicf, icf, nucf, ucf, nfcf, fcf,          \
+	nicostav, icostav, ntcostav, tcostav, nfcostav, fcostav
+
+// what ntg() does before calling npsol_ (ntg.c:114-229): collocation, A, globals
+static HostProblem *open_host_problem(NTG_PROBLEM_ARGS)
 {
-	ensure_opts();
-	printNTGBanner();                                              // ntg.c:161
-	*inform = 9; *objective = 0.0;
 	int nz = 0;
 	for (int o = 0; o < nout; o++) nz += maxderiv[o];
 	auto flat = [&](double **m, int rows) { std::vector<double> v((size_t)rows * nz); for (int i = 0; i < rows; i++) std::copy(m[i], m[i] + nz, &v[(size_t)i * nz]); return v; };
@@ -265,15 +267,63 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 	s.nicostav = nicostav; s.ntcostav = ntcostav; s.nfcostav = nfcostav;
 	s.icostav = (const ntg_av *)icostav; s.tcostav = (const ntg_av *)tcostav; s.fcostav = (const ntg_av *)fcostav;
 
-	HostProblem hp;
+	HostProblem *hp = new HostProblem();
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	if (ntg_plan_create(&s, dev, &hp.plan) != 0) {
+	if (ntg_plan_create(&s, dev, &hp->plan) != 0) {
 		fprintf(stderr, "ntg (MI355X): cannot set the problem up: %s\n", ntg_last_error());
-		return;
+		delete hp;
+		return nullptr;
 	}
-	hp.icf = icf; hp.ucf = ucf; hp.fcf = fcf; hp.nlicf = nlicf; hp.nltcf = nltcf; hp.nlfcf = nlfcf;
-	if (!alloc_host_problem(hp)) { free_host_problem(hp); return; }
+	hp->icf = icf; hp->ucf = ucf; hp->fcf = fcf; hp->nlicf = nlicf; hp->nltcf = nltcf; hp->nlfcf = nlfcf;
+	if (!alloc_host_problem(*hp)) { free_host_problem(*hp); delete hp; return nullptr; }
+	return hp;
+}
+
+// ntg_open()/ntg_close(): set up a problem exactly like ntg() does and leave it current, so that an
+// external SQP/IPOPT driver can call npsolCostFunction / npsolConstraintFunction (include/ntg_amd.h)
+static HostProblem *g_opened = nullptr;
+extern "C" int ntg_open(
+	int nout, double *bps, int nbps, int *kninterv, double **knots, int *order, int *mult, int *maxderiv,
+	int nlic, double **lic, int nltc, double **ltc, int nlfc, double **lfc,
+	int nnlic, nlic_t nlicf, int nnltc, nltc_t nltcf, int nnlfc, nlic_t nlfcf,
+	int nicav, ntg_av *icav_, int ntcav, ntg_av *tcav_, int nfcav, ntg_av *fcav_,
+	int nicf, icf_t icf, int nucf, ucf_t ucf, int nfcf, icf_t fcf,
+	int nicostav, ntg_av *icostav_, int ntcostav, ntg_av *tcostav_, int nfcostav, ntg_av *fcostav_)
+{
+	if (g_opened) return NTG_E_BADARG;
+	AV *icav = (AV *)icav_, *tcav = (AV *)tcav_, *fcav = (AV *)fcav_;          // same layout (av.h:22-26)
+	AV *icostav = (AV *)icostav_, *tcostav = (AV *)tcostav_, *fcostav = (AV *)fcostav_;
+	HostProblem *hp = open_host_problem(NTG_PROBLEM_PASS);
+	if (!hp) return NTG_E_HIP;
+	g_opened = hp; g_cur = hp;
+	return 0;
+}
+extern "C" void ntg_close(void)
+{
+	if (!g_opened) return;
+	if (g_cur == g_opened) g_cur = nullptr;
+	free_host_problem(*g_opened);
+	delete g_opened;
+	g_opened = nullptr;
+}
+
+extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **knots, int *order, int *mult,
+                    int *maxderiv, double *initialguess,
+                    int nlic, double **lic, int nltc, double **ltc, int nlfc, double **lfc,
+                    int nnlic, nlic_t nlicf, int nnltc, nltc_t nltcf, int nnlfc, nlic_t nlfcf,
+                    int nicav, AV *icav, int ntcav, AV *tcav, int nfcav, AV *fcav,
+                    double *lowerb, double *upperb,
+                    int nicf, icf_t icf, int nucf, ucf_t ucf, int nfcf, icf_t fcf,
+                    int nicostav, AV *icostav, int ntcostav, AV *tcostav, int nfcostav, AV *fcostav,
+                    int *istate, double *clambda, double *R, int *inform, double *objective)
+{
+	ensure_opts();
+	printNTGBanner();                                              // ntg.c:161
+	*inform = 9; *objective = 0.0;
+	HostProblem *hpp = open_host_problem(NTG_PROBLEM_PASS);
+	if (!hpp) return;
+	HostProblem &hp = *hpp;
 	HostProblem *prev = g_cur;
 	g_cur = &hp;
 
@@ -389,6 +439,7 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 		printf(" Exit NTG/MI355X SQP - inform %d, majors %d, nfev %d, objective %.15g\n", info, iter, hp.nfev, F);
 	g_cur = prev;
 	free_host_problem(hp);
+	delete hpp;
 }
 
 // ---------------- SplineInterp (colloc.c:449-484): basis on the device, k-term dot on the host ----------------

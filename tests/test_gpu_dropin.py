@@ -45,3 +45,37 @@ def test_kincar_dropin(drv):
     np.testing.assert_allclose(coef, [0, 5, 10, 20, 30, 35, 40, -2, -2, -2, 0, 2, 2, 2], atol=1e-6)
     np.testing.assert_allclose(interp, [0, 8, 0, 40, 8, 0], atol=1e-7)
     assert istate == [3] * 12
+
+
+def test_exported_callbacks_all_slots_vs_oracle(tmp_path):
+    """npsolCostFunction / npsolConstraintFunction (exported NPfunobj / NPfuncon) with host callbacks in
+    all six slots, opened with ntg_open(): f, g, c and the dense column-major cJac against the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from ntg_amd import configs as cf
+    spec = cf.config_T()
+    exe = tmp_path / "callbacks_drv"
+    subprocess.check_call(["gcc", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "drivers", "callbacks_drv.c"),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "ntg_amd"), "-lntg_amd", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ntg_amd")])
+    x = np.random.default_rng(3).normal(size=spec.nC)
+    inp = tmp_path / "in.txt"
+    with open(inp, "w") as f:
+        for M in (spec.lic, spec.ltc, spec.lfc):
+            f.write(" ".join("%.17g" % v for v in M.ravel()) + "\n")
+        f.write(" ".join("%.17g" % v for v in x) + "\n")
+    out = subprocess.run([str(exe), str(inp)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    L = {l.split()[0]: np.array(l.split()[1:], dtype=float) for l in out.stdout.splitlines() if l.split() and l.split()[0] in ("F", "G", "C", "J", "F0", "INFORM", "BADMODE")}
+    ref = orc.eval_batch(spec, x[None], 2)
+    tol = lambda r: 1e-12 * np.abs(r).max()
+    assert abs(L["F"][0] - ref["f"][0]) <= 1e-12 * abs(ref["f"][0])
+    assert abs(L["F0"][0] - ref["f"][0]) <= 1e-12 * abs(ref["f"][0])
+    assert np.abs(L["G"] - ref["g"][0]).max() <= tol(ref["g"])
+    assert np.abs(L["C"] - ref["c"][0]).max() <= tol(ref["c"])
+    J = L["J"].reshape(spec.nC, spec.ncnln).T                     # column-major ldJ = ncnln
+    assert np.array_equal(J != 0, ref["cJac"][0] != 0)
+    assert np.abs(J - ref["cJac"][0]).max() <= tol(ref["cJac"])
+    assert int(L["INFORM"][0]) == 9                               # loud, not wrong
+    assert int(L["BADMODE"][0]) == -1                              # unknown mode: nstate = -1 (ntg.c:332-333)
