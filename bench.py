@@ -176,6 +176,29 @@ def main():
                                  "iters_mean": float(oo["iters"].float().mean().item()),
                                  "iters_max": int(oo["iters"].max().item())}
         del wc
+        # ---- BASELINE config C: receding-horizon MPC, 100 re-solves x batch 1024, kincar 2-output ----
+        specC = cf.config_B(); planC = api.Plan(specC, local)
+        nbC = 1024
+        loC, upC = cf.kincar_random_bounds(1, nbC)
+        loC0 = torch.tensor(loC, device=dev); upC0 = torch.tensor(upC, device=dev)
+        xC0 = torch.ones((nbC, specC.nC), dtype=torch.float64, device=dev)
+        wC = torch.empty(planC.workspace_bytes(nbC, oc), dtype=torch.uint8, device=dev)
+
+        def mpc_run(nres):
+            loC1, upC1, xC = loC0.clone(), upC0.clone(), xC0.clone()
+            bad = 0
+            for _ in range(nres):
+                o2 = planC.solve(loC1, upC1, xC, oc, work=wC)
+                planC.mpc_shift(xC, loC1, upC1, 5, 1)
+                bad = bad + (o2["inform"] != 0).sum()
+            return bad
+        mpc_run(5); torch.cuda.synchronize()
+        t1 = time.perf_counter(); bad = mpc_run(100); torch.cuda.synchronize()
+        dtm = time.perf_counter() - t1
+        res["mpc_config_C"] = {"value": nbC * 100 / dtm, "unit": "re-solves/s", "resolves": 100, "batch": nbC,
+                               "ms_per_resolve_batch": 1e3 * dtm / 100, "not_converged": int(bad.item()),
+                               "workload": "B:kincar-2out-k6-l20, advance one knot interval per re-solve, shift warm start"}
+        del wC
         # ---- standalone evaluation kernel streamed over a large batch ----
         nb = 1 << 18
         xe = torch.randn((nb, spec.nC), dtype=torch.float64, device=dev)

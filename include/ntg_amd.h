@@ -128,6 +128,13 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
                     const double *d_knots, const double *d_bps, double *d_blk, int *d_off,
                     void *stream);
 
+/* Receding-horizon step (the warm-start use NPSOL's istate/clambda/R were meant for, ntg.h:64-68):
+ * re-pin the linear initial-constraint bounds of every problem to the flat flag of its current
+ * solution at breakpoint shift_bp, and shift the coefficients by shift_knots knot intervals
+ * (tail = last coefficient) as the next initial guess.  d_x, d_lower, d_upper are updated in place. */
+int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, int shift_knots, double *d_x,
+                        double *d_lower, double *d_upper, void *stream);
+
 /* ntg_open(): everything ntg() does before it calls npsol_ (ntg.c:114-229), with ntg()'s own
  * argument list minus initialguess, the bounds and the outputs; the problem stays current until
  * ntg_close().  For external SQP/IPOPT drivers (Pending:9) that iterate on their own and only need

@@ -67,6 +67,7 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_longlong, C.c_void_p]
         L.ntg_basis_batch.argtypes = [C.c_int] * 6 + [C.c_void_p] * 5
+        L.ntg_batch_mpc_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -184,6 +185,11 @@ class Plan:
             if want_dense_jac:
                 out["cJac"] = cj.transpose(1, 2).contiguous()
         return out
+
+    def mpc_shift(self, x, lower, upper, shift_bp: int, shift_knots: int):
+        """Receding-horizon step in place: re-pin initial bounds to the solution's flag at breakpoint
+        shift_bp, shift the coefficients by shift_knots knot intervals."""
+        _check(lib().ntg_batch_mpc_shift(self.h, x.shape[0], shift_bp, shift_knots, _ptr(x), _ptr(lower), _ptr(upper), self._stream()))
 
     def workspace_bytes(self, batch: int, opts: Optional[SolveOpts] = None) -> int:
         return int(lib().ntg_batch_workspace_bytes(self.h, batch, C.byref(opts) if opts is not None else None))

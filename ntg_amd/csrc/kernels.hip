@@ -1254,6 +1254,59 @@ hipError_t ntg_launch_hostcon(const NtgDims &D, const NtgTables &T, const double
 }
 
 // ------------------------------------------------------------------------------------------
+// receding-horizon (MPC) shift, SURVEY.md §8f rank 2: after a solve, advance every problem to the
+// breakpoint `sbp` of its own solution: (1) the linear initial-constraint bounds are re-pinned to
+// the flat flag of the old solution at that breakpoint, b_r = sum_v lic[r][v] z_v(sbp) (the role
+// NPSOL's warm start arrays istate/clambda/R were meant for, ntg.h:64-68, never used by the
+// reference); (2) the coefficient vector is shifted by `sknot` knot intervals, C_new[j] =
+// C_old[j + sknot (k-m)], the tail holding the last coefficient -- the warm start of the next solve.
+// One workgroup per problem.
+// ------------------------------------------------------------------------------------------
+__global__ void mpc_shift_kernel(NtgDims D, NtgTables T, int batch, int sbp, int sknot, const double *__restrict__ lic,
+                                 double *__restrict__ x, double *__restrict__ lower, double *__restrict__ upper)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	double *sx = (double *)smem_raw, *z = sx + ((D.nC + 1) & ~1);
+	const int b = blockIdx.x, tid = threadIdx.x;
+	if (b >= batch) return;
+	for (int i = tid; i < D.nC; i += blockDim.x) sx[i] = x[(size_t)b * D.nC + i];
+	__syncthreads();
+	// flat flag of the old solution at breakpoint sbp (every derivative, Zvalue of colloc.c:318-326)
+	for (int v = tid; v < D.nz; v += blockDim.x) {
+		int o = 0;
+		while (o + 1 < D.nout && D.iz[o + 1] <= v) o++;
+		const int r = v - D.iz[o], k = D.order[o], d = D.d[o], c = D.cls[o];
+		const double *bq = T.blk + D.cls_blk[c] + (size_t)sbp * k * d;
+		const double *cx = sx + D.iC[o] + T.off[c * D.P + sbp];
+		double a = 0.0;
+		for (int q = 0; q < k; q++) a += bq[q * d + r] * cx[q];
+		z[v] = a;
+	}
+	__syncthreads();
+	for (int r = tid; r < D.nlic; r += blockDim.x) {
+		double a = 0.0;
+		for (int v = 0; v < D.nz; v++) a += lic[(size_t)r * D.nz + v] * z[v];
+		lower[(size_t)b * D.nbounds + r] = a;
+		upper[(size_t)b * D.nbounds + r] = a;
+	}
+	for (int c = tid; c < D.nC; c += blockDim.x) {
+		int o = 0;
+		while (o + 1 < D.nout && D.iC[o + 1] <= c) o++;
+		const int cl = c - D.iC[o], sh = sknot * (D.order[o] - D.mult[o]), src = cl + sh;
+		x[(size_t)b * D.nC + c] = sx[D.iC[o] + (src < D.ncoef[o] ? src : D.ncoef[o] - 1)];
+	}
+}
+
+hipError_t ntg_launch_mpc_shift(const NtgDims &D, const NtgTables &T, int batch, int sbp, int sknot, const double *lic,
+                                double *x, double *lower, double *upper, hipStream_t st)
+{
+	if (batch <= 0) return hipSuccess;
+	const size_t sm = (size_t)(((D.nC + 1) & ~1) + D.nz + 2) * 8;
+	hipLaunchKernelGGL(mpc_shift_kernel, dim3(batch), dim3(128), sm, st, D, T, batch, sbp, sknot, lic, x, lower, upper);
+	return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // launchers (called from plan.cpp)
 // ------------------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }

@@ -343,6 +343,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	} else {
 		p->lin_ok = true;
 	}
+	if (s->nlic > 0 && dev_upload(&p->d_lic, s->lic, (size_t)s->nlic * nz, own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 	// keep what the preconditioner build needs
 	p->tcostav.assign(s->tcostav, s->tcostav + s->ntcostav);
 	p->icostav.assign(s->icostav, s->icostav + s->nicostav);
@@ -584,5 +585,17 @@ extern "C" int ntg_debug_layout(const ntg_plan *p, const ntg_solve_opts *o, int 
 	if (lds_solve) *lds_solve = ntg_make_layout(p->D, nt, 5, sp.memcap).total;
 	if (lds_eval) *lds_eval = ntg_make_layout(p->D, (p->D.P <= 128 && p->D.nC <= 512) ? 128 : 256, 1, 0).total;
 	if (nt_solve) *nt_solve = nt;
+	return 0;
+}
+
+extern "C" int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, int shift_knots, double *d_x,
+                                   double *d_lower, double *d_upper, void *stream)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0) return 0;
+	if (!d_x || !d_lower || !d_upper) return fail(NTG_E_BADARG, "null argument");
+	if (shift_bp < 0 || shift_bp >= p->D.P || shift_knots < 0) return fail(NTG_E_BADARG, "shift out of range");
+	HIPCHK(hipSetDevice(p->device));
+	HIPCHK(ntg_launch_mpc_shift(p->D, p->T, batch, shift_bp, shift_knots, p->d_lic, d_x, d_lower, d_upper, (hipStream_t)stream));
 	return 0;
 }

@@ -14,6 +14,7 @@ struct ntg_plan {
 	std::vector<double> h_bps, h_blk, h_aband, h_Adense;
 	std::vector<int> h_off, h_rbp, class_rep;
 	std::vector<ntg_av> icostav, tcostav, fcostav;
+	double *d_lic = nullptr;                    // [nlic][nz] kept for the receding-horizon shift
 };
 
 void ntg_plan_dense_A(const ntg_plan *p, double *A);
@@ -38,3 +39,5 @@ hipError_t ntg_launch_hostcost(const NtgDims &D, const NtgTables &T, const SmemL
                                hipStream_t st);
 hipError_t ntg_launch_hostcon(const NtgDims &D, const NtgTables &T, const double *dc, double *jband, double *cjac,
                               hipStream_t st);
+hipError_t ntg_launch_mpc_shift(const NtgDims &D, const NtgTables &T, int batch, int sbp, int sknot, const double *lic,
+                                double *x, double *lower, double *upper, hipStream_t st);

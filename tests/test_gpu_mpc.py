@@ -1,0 +1,82 @@
+"""-m gpu: receding-horizon MPC (BASELINE config C): solve, advance one knot
+interval along the solution, re-pin the initial flag, shift-warm-start, re-solve -- against the same
+loop run with the CPU oracle and a numpy restatement of the shift."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from ntg_amd import api, configs as cf
+from gpu_common import plan_for, dev
+
+pytestmark = pytest.mark.gpu
+
+
+def shift_numpy(spec, tab, x, lo, up, sbp, sknot):
+    """numpy statement of ntg_batch_mpc_shift for one problem."""
+    P = spec.nbps
+    z = np.zeros(spec.nz); pos = 0; iC = 0; iz = 0
+    xn = x.copy()
+    for o in range(spec.nout):
+        k, d, n = spec.order[o], spec.maxderiv[o], spec.ncoef[o]
+        blk = tab["blk"][pos:pos + P * k * d].reshape(P, k, d); pos += P * k * d
+        off = tab["off"][o, sbp]
+        for r in range(d):
+            z[iz + r] = sum(blk[sbp, q, r] * x[iC + off + q] for q in range(k))
+        sh = sknot * (k - spec.mult[o])
+        for cl in range(n):
+            xn[iC + cl] = x[iC + min(cl + sh, n - 1)]
+        iC += n; iz += d
+    lo2, up2 = lo.copy(), up.copy()
+    lo2[:spec.nlic] = spec.lic @ z; up2[:spec.nlic] = spec.lic @ z
+    return xn, lo2, up2
+
+
+def test_mpc_loop_matches_oracle_loop():
+    spec = cf.config_B(); p = plan_for("B")
+    nb, nsteps, sknot = 6, 4, 1
+    sbp = 5 * sknot                                   # P = 5 l + 1: knot j is breakpoint 5 j
+    lo, up = cf.kincar_random_bounds(1, nb)
+    tab = orc.export_tables(spec)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    lo_d, up_d = dev(lo), dev(up)
+    opts = api.default_opts(hessian=1)
+    for step in range(nsteps):
+        # the oracle solves exactly the problem the GPU is about to solve (same re-pinned bounds, same warm start);
+        # two free-running loops would drift apart by the 1e-7 accuracy of each re-pinned initial flag
+        lo_h, up_h, x_h = lo_d.cpu().numpy(), up_d.cpu().numpy(), x.cpu().numpy()
+        out = p.solve(lo_d, up_d, x, opts)
+        ref = orc.solve_batch(spec, lo_h, up_h, x_h, orc.default_opts(hessian=1), nthreads=4)
+        assert (out["inform"].cpu().numpy() == 0).all() and (ref["inform"] == 0).all()
+        xg = x.cpu().numpy()
+        assert np.abs(xg - ref["x"]).max() <= 1e-6 * np.abs(ref["x"]).max(), step
+        assert np.abs(out["objective"].cpu().numpy() - ref["objective"]).max() <= 1e-9 * np.abs(ref["objective"]).max()
+        # shift: GPU kernel vs numpy statement on the same input
+        exp = [shift_numpy(spec, tab, xg[i], lo_h[i], up_h[i], sbp, sknot) for i in range(nb)]
+        p.mpc_shift(x, lo_d, up_d, sbp, sknot)
+        np.testing.assert_allclose(x.cpu().numpy(), np.stack([e[0] for e in exp]), rtol=0, atol=0)
+        np.testing.assert_allclose(lo_d.cpu().numpy(), np.stack([e[1] for e in exp]), rtol=1e-13, atol=1e-12)
+        assert torch.equal(lo_d, up_d)
+    # warm starts pay off: later re-solves need no more majors than the cold first one
+    assert int(out["iters"].max()) <= 5
+
+
+def test_mpc_full_config_C_properties():
+    """config C size (100 re-solves x 1024): every re-solve converges and stays feasible."""
+    spec = cf.config_B(); p = plan_for("B")
+    nb = 1024
+    lo, up = cf.kincar_random_bounds(1, nb)
+    lo_d, up_d = dev(lo), dev(up)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    A = dev(p.tables()["A"])
+    opts = api.default_opts(hessian=1)
+    work = torch.empty(p.workspace_bytes(nb, opts), dtype=torch.uint8, device="cuda:0")
+    worst_feas = 0.0; ninf = 0
+    for step in range(100):
+        out = p.solve(lo_d, up_d, x, opts, work=work)
+        ninf += int((out["inform"] != 0).sum().item())
+        if step % 25 == 0:
+            worst_feas = max(worst_feas, (x @ A.T - lo_d).abs().max().item())
+        p.mpc_shift(x, lo_d, up_d, 5, 1)
+    assert ninf == 0
+    assert worst_feas <= 1e-8
