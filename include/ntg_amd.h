@@ -37,10 +37,13 @@ extern "C" {
 #define NTG_E_HIP      (-3)
 #define NTG_E_UNSUPPORTED (-4)
 
+#define NTG_INF_BOUND 1e20   /* NPSOL's "infinite bound": use for one-sided constraints */
+
 /* problem families = device functors for the user callbacks of ntg.h:81-83,90-92 */
 #define NTG_FAM_KINCAR 0     /* examples/kincar.c:105-117 generalised to nout outputs */
 #define NTG_FAM_VANDERPOL 1  /* examples/vanderpol.c:206-241 */
 #define NTG_FAM_TESTFAM 2    /* synthetic, all six callback slots */
+#define NTG_FAM_OBSTACLE 3   /* kincar cost + circular-obstacle trajectory constraint (x-20)^2+(y-0.5)^2 >= r^2 */
 #define NTG_FAM_HOST (-1)    /* host function pointers (ntg() drop-in path only) */
 
 typedef struct { int output; int deriv; } ntg_av; /* == AV of av.h:22-26 */

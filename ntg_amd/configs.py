@@ -8,7 +8,7 @@
 """
 from __future__ import annotations
 import numpy as np
-from .spec import Spec, linspace_c, FAM_KINCAR, FAM_VANDERPOL, FAM_TESTFAM
+from .spec import Spec, linspace_c, FAM_KINCAR, FAM_VANDERPOL, FAM_TESTFAM, FAM_OBSTACLE
 
 SEED = 20261003
 WHEELBASE = 3.0  # kincar.c:43
@@ -113,3 +113,24 @@ def kincar_random_bounds(ncars: int, batch: int, seed: int = SEED):
             b[p, 6 * c:6 * c + 6] = zi.ravel()
             b[p, 3 * nout + 6 * c:3 * nout + 6 * c + 6] = zf.ravel()
     return b.copy(), b.copy()
+
+
+INF_BOUND = 1e20  # NPSOL's "infinite bound" 
+
+
+def config_O(ninterv: int = 20, order: int = 6) -> Spec:
+    """kincar (2 outputs) + circular-obstacle trajectory constraint (family 3): nonlinear inequality
+    (x-20)^2 + (y-0.5)^2 >= r^2 at every breakpoint, r^2 given through the bounds."""
+    s = _kincar_spec(1, order, 3, ninterv, 5 * ninterv + 1, 5.0, f"O:kincar-obstacle-k{order}-l{ninterv}")
+    s.family = FAM_OBSTACLE
+    s.nnltc = 1
+    s.tcav = [(0, 0), (1, 0)]
+    return s
+
+
+def obstacle_bounds(batch: int, radius: float = 3.0, seed: int = SEED):
+    """kincar bounds of kincar_random_bounds + [r^2, +inf) for the obstacle row."""
+    lo, up = kincar_random_bounds(1, batch, seed)
+    lo = np.concatenate([lo, np.full((batch, 1), radius * radius)], axis=1)
+    up = np.concatenate([up, np.full((batch, 1), INF_BOUND)], axis=1)
+    return lo, up

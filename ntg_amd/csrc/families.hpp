@@ -9,6 +9,7 @@
 //   NTG_FAM_KINCAR     f = sum_o (z_o'')^2                      examples/kincar.c:105-117
 //   NTG_FAM_VANDERPOL  f = (z^2 + z'^2 + u^2)/2, u = z''+z-(1-z^2)z'   examples/vanderpol.c:206-241
 //   NTG_FAM_TESTFAM    synthetic, every slot populated (mirrors oracle/families.c family 2)
+//   NTG_FAM_OBSTACLE   kincar cost (2 outputs) + trajectory constraint c = (x-20)^2 + (y-0.5)^2 (>= r^2 via bounds)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/ntg_amd.h"
@@ -108,5 +109,21 @@ template <> struct Family<NTG_FAM_TESTFAM> {
 		c[0] = z[2] * z[0] + z[3 * L + 1] * z[3 * L + 1];
 		for (int v = 0; v < nz; v++) dc[v] = 0.0;
 		dc[2] += z[0]; dc[0] += z[2]; dc[3 * L + 1] += 2.0 * z[3 * L + 1];
+	}
+};
+
+template <> struct Family<NTG_FAM_OBSTACLE> {
+	static constexpr int NNLIC = 0, NNLTC = 1, NNLFC = 0;
+	static __device__ __forceinline__ void ucf(int nout, int i, const double *z, double &f, double *df) { Family<NTG_FAM_KINCAR>::ucf(nout, i, z, f, df); }
+	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }
+	static __device__ __forceinline__ void fcf(int, const double *, double &f, double *) { f = 0.0; }
+	static __device__ __forceinline__ void nlicf(int, const double *, double *, double *) {}
+	static __device__ __forceinline__ void nlfcf(int, const double *, double *, double *) {}
+	static __device__ __forceinline__ void nltcf(int nout, int, const double *z, double *c, double *dc)
+	{
+		const double dx = z[0] - 20.0, dy = z[3] - 0.5;
+		c[0] = dx * dx + dy * dy;
+		for (int v = 0; v < 3 * nout; v++) dc[v] = 0.0;
+		dc[0] = 2.0 * dx; dc[3] = 2.0 * dy;
 	}
 };

@@ -503,37 +503,90 @@ __device__ __forceinline__ void make_coefmap(const NtgDims &D, const Smem &S, Co
 	}
 }
 
+// Augmented-Lagrangian state of one problem: with mu > 0 the evaluation returns
+//   F_A = F + sum_j (t_j^2 - lam_j^2)/(2 mu),  t_j = mu (v_j - clamp(v_j, bl_j, bu_j)),  v_j = c_j + lam_j/mu
+// and its gradient g + J' t; t (the next multiplier estimate) is written to tnew.  mu == 0: plain F.
+struct ALState {
+	double mu;
+	const double *lam;   // [ncnln] current multipliers (HBM)
+	double *tnew;        // [ncnln] multiplier estimates of the last evaluation (HBM)
+	const double *lo, *up; // this problem's rows of lowerb/upperb [nbounds]
+};
+
 // per-breakpoint cost functor pass: Z = M C, then ucf/icf/fcf -> fvals, dfz, dfi, dff in LDS
 template <int FAM, int NOUT, int K, int NT>
-__device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx)
+__device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx, const ALState &al,
+                                            double &psi, double &rv2)
 {
 	constexpr int NZ = NOUT > 0 ? 3 * NOUT : NTG_MAX_NZ;
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
 	using Fam = Family<FAM>;
+	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
+	constexpr int NI = Fam::NNLIC > 0 ? Fam::NNLIC : 1, NTc = Fam::NNLTC > 0 ? Fam::NNLTC : 1, NF = Fam::NNLFC > 0 ? Fam::NNLFC : 1;
+	const bool alon = HASCON && al.mu > 0.0;
+	const int b0 = D.nlic + D.nltc + D.nlfc;   // first nonlinear slot of lowerb/upperb
+	psi = 0.0; rv2 = 0.0;
+	// one constraint value -> AL term, violation, multiplier estimate; returns t
+	auto al_term = [&](double cj, int row, int slot) -> double {
+		const double lamj = al.lam[row], l = al.lo[slot], u = al.up[slot];
+		const double v = cj + lamj / al.mu;
+		const double pj = v < l ? l : (v > u ? u : v), cc = cj < l ? l : (cj > u ? u : cj);
+		const double t = al.mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
+		psi += (t * t - lamj * lamj) / (2.0 * al.mu);
+		rv2 += rj * rj;
+		al.tnew[row] = t;
+		return t;
+	};
 	lds_sync(); // sx complete, previous users of dfz/fvals done
-	if (D.nucf && !(g_ntg_dbg & 2)) {
+	if ((D.nucf || (alon && D.nnltc)) && !(g_ntg_dbg & 2)) {
+		const u64 zmask = alon ? (D.tcost_mask | D.tcon_mask) : D.tcost_mask;
 		for (int i = tid; i < P; i += NT) {                       // cost.c:103-109
-			double z[NZ], df[NZ], f;
-			compute_z<NOUT, K>(D, S, sx, i, D.tcost_mask, z);
-			Fam::ucf(nout, i, z, f, df);
+			double z[NZ], df[NZ], f = 0.0;
+			compute_z<NOUT, K>(D, S, sx, i, zmask, z);
+			if (D.nucf) Fam::ucf(nout, i, z, f, df);
+			else {
+#pragma unroll
+				for (int v = 0; v < NZ; v++) df[v] = 0.0;
+			}
 			S.fvals[i] = f;
 			const double w = S.wts[i];
 #pragma unroll
-			for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = w * df[v]; }
+			for (int v = 0; v < NZ; v++) df[v] *= w;
+			if (HASCON && alon && D.nnltc) {                      // constraints.c:148-155 folded into the same pass
+				double c[NTc], dc[NTc * NZ];
+				Fam::nltcf(nout, i, z, c, dc);
+				for (int j = 0; j < D.nnltc; j++) {
+					const double t = al_term(c[j], D.nnlic + j * P + i, b0 + D.nnlic + j);
+#pragma unroll
+					for (int v = 0; v < NZ; v++) { if (v < nz) df[v] += t * dc[j * nz + v]; }
+				}
+			}
+#pragma unroll
+			for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = df[v]; }
 		}
 	}
-	if (D.nicf && tid == 0) {                                     // cost.c:4-36
-		double z[NZ], df[NZ], f;
-		compute_z<NOUT, K>(D, S, sx, 0, D.icost_mask, z);
-		Fam::icf(nout, z, f, df);
+	if ((D.nicf || (alon && D.nnlic)) && tid == 0) {              // cost.c:4-36, constraints.c:88-117
+		double z[NZ], df[NZ], f = 0.0;
+		compute_z<NOUT, K>(D, S, sx, 0, alon ? (D.icost_mask | D.icon_mask) : D.icost_mask, z);
+		if (D.nicf) Fam::icf(nout, z, f, df); else for (int v = 0; v < nz; v++) df[v] = 0.0;
+		if (HASCON && alon && D.nnlic) {
+			double c[NI], dc[NI * NZ];
+			Fam::nlicf(nout, z, c, dc);
+			for (int j = 0; j < D.nnlic; j++) { const double t = al_term(c[j], j, b0 + j); for (int v = 0; v < nz; v++) df[v] += t * dc[j * nz + v]; }
+		}
 		for (int v = 0; v < nz; v++) S.dfi[v] = df[v];
 		S.dfi[nz] = f;
 	}
-	if (D.nfcf && tid == (NT > 64 ? 64 : 0)) {                    // cost.c:141-174
-		double z[NZ], df[NZ], f;
-		compute_z<NOUT, K>(D, S, sx, P - 1, D.fcost_mask, z);
-		Fam::fcf(nout, z, f, df);
+	if ((D.nfcf || (alon && D.nnlfc)) && tid == (NT > 64 ? 64 : 0)) {   // cost.c:141-174, constraints.c:165-195
+		double z[NZ], df[NZ], f = 0.0;
+		compute_z<NOUT, K>(D, S, sx, P - 1, alon ? (D.fcost_mask | D.fcon_mask) : D.fcost_mask, z);
+		if (D.nfcf) Fam::fcf(nout, z, f, df); else for (int v = 0; v < nz; v++) df[v] = 0.0;
+		if (HASCON && alon && D.nnlfc) {
+			double c[NF], dc[NF * NZ];
+			Fam::nlfcf(nout, z, c, dc);
+			for (int j = 0; j < D.nnlfc; j++) { const double t = al_term(c[j], D.nnlic + D.nnltc * P + j, b0 + D.nnlic + D.nnltc + j); for (int v = 0; v < nz; v++) df[v] += t * dc[j * nz + v]; }
+		}
 		for (int v = 0; v < nz; v++) S.dff[v] = df[v];
 		S.dff[nz] = f;
 	}
@@ -542,14 +595,15 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 // quadrature + banded gradient assembly from the per-breakpoint values in LDS (fvals, dfz,
 // dfi, dff); shared by the device-functor path and the host-callback path of ntg()
 template <int NOUT, int K, int NT>
-__device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<4> &cm)
+__device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<4> &cm,
+                                              bool hasI, bool hasF, double psi, double rv2, double *Fpure, double *rv2_out)
 {
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
 	lds_sync();
 	// trapezoid of the running cost (integrator.c:21-24); per-interval terms across the lanes,
 	// wavefront reduction
-	double acc[2] = {0.0, 0.0};
+	double acc[4] = {0.0, 0.0, psi, rv2};
 	if (D.nucf)
 		for (int i = tid; i < P - 1; i += NT)
 			acc[0] += (S.bps[i + 1] - S.bps[i]) * (S.fvals[i + 1] + S.fvals[i]) / 2;
@@ -559,7 +613,7 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 	// sum node-wise, g[c] = sum_s colv[c][s] * (w_i df_i)[coli[c][s]], over the non-zeros of column c
 	// of the collocation matrix only.  The column form is s-major ([s][cl]): lanes with consecutive
 	// coefficients read consecutive LDS words.
-	if (NOUT > 0 && !D.nicf && !D.nfcf) {
+	if (NOUT > 0 && !hasI && !hasF) {
 		// all (breakpoint, block column) pairs of a column are read first, then all values and
 		// weighted gradients, then the FMAs: two LDS round trips per coefficient, independent of W
 		auto gather = [&](auto Wtag) {
@@ -615,14 +669,14 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 			double dI = 0.0, dIn = 0.0, dF = 0.0;
 			for (int r = 0; r < d; r++) {
 				const int row = S.tavrow[iz + r], chc = S.chcol[chb + r], chr = S.chrow[chb + r];
-				if (D.nucf && row >= 0 && chc >= 0) {
+				if (row >= 0 && chc >= 0) {
 					const unsigned int *cp = S.colp + chc + cl * W4; const double *wdf = S.dfz + row * (P + 1);
 					for (int s = 0; s < W4; s++) { const unsigned int pe = cp[s]; dIn += S.rowv[chr + (pe >> 16)] * wdf[pe & 0xffffu]; }
 				}
 				if (chr >= 0) {
-					if (D.nicf && cl < k) dI += S.dfi[iz + r] * S.rowv[chr + cl * P];             // colloc.c:243-260 (block 0)
+					if (hasI && cl < k) dI += S.dfi[iz + r] * S.rowv[chr + cl * P];                // colloc.c:243-260 (block 0)
 					const int ol = coff[P - 1];
-					if (D.nfcf && cl >= ol && cl < ol + k) dF += S.dff[iz + r] * S.rowv[chr + (cl - ol) * P + P - 1];   // colloc.c:287-316
+					if (hasF && cl >= ol && cl < ol + k) dF += S.dff[iz + r] * S.rowv[chr + (cl - ol) * P + P - 1];   // colloc.c:287-316
 				}
 			}
 			const double g = dI + dIn + dF;                       // Vector3Add (matrix.c:177)
@@ -630,23 +684,32 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 			acc[1] += g * g;
 		}
 	}
-	if (!(dbg & 4)) block_sum<NT, 2>(acc, S.red);
+	if (!(dbg & 4)) block_sum<NT, 4>(acc, S.red);
 	const double I = D.nicf ? S.dfi[nz] : 0.0, Ff = D.nfcf ? S.dff[nz] : 0.0;
 	*gnorm2 = acc[1];
-	return I + acc[0] + Ff;                                       // ntg.c:328
+	const double Fp = I + acc[0] + Ff;                            // ntg.c:328
+	if (Fpure) *Fpure = Fp;
+	if (rv2_out) *rv2_out = acc[3];
+	return Fp + acc[2];
 }
 
 // NPfunobj (ntg.c:274-335): F and the full gradient into LDS vector sg.  Returns F; *gnorm2
 // receives |g|^2.  Every lane of the workgroup must call it (it contains barriers).
 template <int FAM, int NOUT, int K, int NT>
 __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
-                                            const CoefMap<4> &cm, unsigned long long *tk = nullptr)
+                                            const CoefMap<4> &cm, const ALState &al, double *Fpure = nullptr,
+                                            double *rv2_out = nullptr, unsigned long long *tk = nullptr)
 {
+	using Fam = Family<FAM>;
+	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
+	const bool alon = HASCON && al.mu > 0.0;
 	unsigned long long t0 = 0;
 	if (tk) t0 = __builtin_amdgcn_s_memtime();
-	cost_phase1<FAM, NOUT, K, NT>(D, S, sx);
+	double psi, rv2;
+	cost_phase1<FAM, NOUT, K, NT>(D, S, sx, al, psi, rv2);
 	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
-	const double F = cost_phase2<NOUT, K, NT>(D, S, sg, gnorm2, cm);
+	const double F = cost_phase2<NOUT, K, NT>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
+	                                          psi, rv2, Fpure, rv2_out);
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
 }
@@ -747,7 +810,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 			for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
 		}
 		double gn2;
-		const double F = eval_cost<FAM, NOUT, K, NT>(D, S, S.x, sg, &gn2, cm);
+		const double F = eval_cost<FAM, NOUT, K, NT>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr});
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
 		if (g && mode != 0 && !(dbgk & 8))
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
@@ -925,7 +988,8 @@ __global__ void __launch_bounds__(NT, NTG_SQP_WAVES)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
            double *__restrict__ objective, int *__restrict__ inform_out, int *__restrict__ iters_out,
-           int *__restrict__ nfev_out, double *__restrict__ clambda, double *__restrict__ hist_all)
+           int *__restrict__ nfev_out, double *__restrict__ clambda, double *__restrict__ hist_all,
+           double *__restrict__ al_all)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	Smem S(smem_raw, L, D, T);
@@ -942,7 +1006,13 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	CoefMap<4> cm;
 	if (NOUT > 0) make_coefmap<NT, 4>(D, S, cm);
 
-	enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3 };
+	enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3, ST_REEVAL = 4 };
+	using Fam = Family<FAM>;
+	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
+	const int ncn = D.ncnln;
+	// augmented-Lagrangian state (nonlinear constraints): multipliers and their estimates live in HBM
+	double *al_lam = al_all + (size_t)b * 2 * ncn, *al_t = al_lam + ncn;
+	ALState al{(HASCON && ncn > 0) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
 	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
 	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history / rest
 	unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
@@ -951,15 +1021,20 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	// ---- scope check (uniform): linear equalities only ----
 	{
 		double bad[1] = {0.0};
-		for (int s = tid; s < D.nbounds; s += NT)
+		for (int s = tid; s < D.nlic + D.nltc + D.nlfc; s += NT)      // linear rows must be equalities
 			if (lower[(size_t)b * D.nbounds + s] != upper[(size_t)b * D.nbounds + s]) bad[0] += 1.0;
 		block_sum<NT, 1>(bad, S.red);
-		if (bad[0] != 0.0 || D.ncnln > 0) inform = 9;
+		if (bad[0] != 0.0 || (ncn > 0 && (!HASCON || sp.fixed_iters))) inform = 9;
 	}
-	double F = 0.0, gn2 = 0.0, alpha = 0.0, pnorm = 0.0;
+	double F = 0.0, Fp = 0.0, gn2 = 0.0, rv2 = 0.0, alpha = 0.0, pnorm = 0.0;
+	double sri = sp.sr, rvprev = HUGE_VAL;   // inner tolerance and best violation so far (AL outer loop)
+	int outer = 0, inner_inform = 4;
+	bool at_x = true;
 	if (inform != 9) {
 		// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
-		if (m > 0) {
+		auto make_feasible = [&]() {
+			if (m <= 0) return;
+			lds_sync();
 			for (int r = tid; r < m; r += NT) {
 				int s;
 				if (r < D.nlic) s = r;
@@ -982,8 +1057,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				sx[c] += s;
 			}
 			lds_sync();
-		}
+		};
+		make_feasible();
 		for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+		if (al.mu > 0.0) {
+			for (int j = tid; j < ncn; j += NT) al_lam[j] = 0.0;
+			sri = fmax(sp.sr, 1e-3);
+			__syncthreads();   // multipliers cross lanes through HBM: full barrier
+		}
 		NTG_STAMP(0);
 
 		// line-search state lives in LDS (17 doubles would otherwise sit in every lane's registers);
@@ -993,8 +1074,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		bool finished = false;
 		for (;;) {
 			// ================= the one evaluation site =================
-			double gn2n;
-			const double Fn = eval_cost<FAM, NOUT, K, NT>(D, S, sxt, sg, &gn2n, cm, sp.stamps ? tk : nullptr);
+			double gn2n, Fpn, rv2n;
+			const double Fn = eval_cost<FAM, NOUT, K, NT>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr);
 			NTG_STAMP(1);
 			if (state == ST_FINAL) {
 				// multipliers estimate lam = (AA')^-1 A g at the final point
@@ -1014,11 +1095,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				break;
 			}
 			nfev++;
+			bool new_major = false;
+			if (state == ST_REEVAL) {   // constraint values and multiplier estimates refreshed at x
+				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
+			} else {
 			project<NT>(D, S, sg, sgpt, tmp);
 			NTG_STAMP(2);
-			bool new_major = false;
 			if (state == ST_INIT) {
-				F = Fn; gn2 = gn2n;
+				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
 				apply_w0<NT>(D, T, sp.hessian, sgp, sd);
 				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
@@ -1046,9 +1130,20 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					continue;
 				}
 				if (rc != 1) {
-					const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
-					inform = (sqrt(r4[3]) <= tolg) ? 0 : 6;
-					finished = true;
+					const double tolg = sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+					if (npairs > 0 && sqrt(r4[3]) > tolg) {
+						// line search failed with a non-trivial W: drop the pairs and retry from the same point with W0
+						npairs = 0;
+						apply_w0<NT>(D, T, sp.hessian, sgp, sd);
+						double r2[2] = {0, 0};
+						for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
+						block_sum<NT, 2>(r2, S.red);
+						r4[0] = r2[0]; r4[1] = r2[1];
+						new_major = true;
+					} else {
+						inner_inform = (sqrt(r4[3]) <= tolg) ? 0 : 6;
+						finished = true; at_x = false;
+					}
 				} else {
 					alpha = lsm->a;
 					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
@@ -1084,21 +1179,22 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					__threadfence_block();
 					__syncthreads();   // rho/c2 of the new pair go through HBM/L2: needs the full barrier (vmcnt(0))
 					block_sum<NT, 4>(r4, S.red);
-					F = Fn; gn2 = gn2n;
+					F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n;
 					iter++;
-					if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r4[2])) &&
-					    sqrt(r4[3]) <= sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inform = 0; finished = true; }
+					if (!sp.fixed_iters && alpha * pnorm <= sri * (1.0 + sqrt(r4[2])) &&
+					    sqrt(r4[3]) <= sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inner_inform = 0; finished = true; }
 					else new_major = true;
 				}
 			}
+			}
 			if (new_major) {
 				// ---- start of a major iteration at (sx, sgp, sd) ----
-				if (iter >= sp.itlim) { inform = 4; finished = true; }
+				if (iter >= sp.itlim) { inner_inform = 4; finished = true; }
 				else {
 					double dphi0 = -r4[0];
 					pnorm = sqrt(r4[1]);
 					const double xnorm = sqrt(r4[2]), gpnorm = sqrt(r4[3]);
-					const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+					const double tolg = sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
 					if (pnorm == 0.0 || !(dphi0 < 0.0)) {
 						if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
 							npairs = 0;
@@ -1109,9 +1205,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 							r4[0] = r2[0]; r4[1] = r2[1];
 							dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
 						}
-						if (pnorm == 0.0 || !(dphi0 < 0.0)) { inform = (gpnorm <= tolg) ? 0 : 6; finished = true; }
+						if (pnorm == 0.0 || !(dphi0 < 0.0)) { inner_inform = (gpnorm <= tolg) ? 0 : 6; finished = true; }
 					}
-					if (!finished && !sp.fixed_iters && gpnorm <= 1e-3 * tolg) { inform = 0; finished = true; }
+					if (!finished && !sp.fixed_iters && gpnorm <= 1e-3 * tolg) { inner_inform = 0; finished = true; }
 					if (!finished) {
 						const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
 						const double a = amax < 1.0 ? amax : 1.0;
@@ -1125,6 +1221,36 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			NTG_STAMP(5);
 			if (finished) {
+				if (al.mu > 0.0) {
+					// ---- multiplier / penalty update of the augmented Lagrangian ----
+					if (!at_x) {   // inner solve ended on a rejected trial: refresh c, t at x first
+						state = ST_REEVAL;
+						lds_sync();
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+						continue;
+					}
+					const double rv = sqrt(rv2);
+					bool done_al = false;
+					bool take = false;
+					if (inner_inform == 6) { inform = 6; done_al = true; }
+					else if (rv <= 1e-8 && sri <= sp.sr && inner_inform == 0) { take = true; inform = 0; done_al = true; }
+					else if (inner_inform == 4) { inform = 4; done_al = true; }
+					else {
+						if (rv <= 0.25 * rvprev) { take = true; rvprev = rv; }
+						else al.mu *= 10.0;
+						outer++;
+						if (outer >= 30) { inform = 3; done_al = true; }
+					}
+					if (take) for (int j = tid; j < ncn; j += NT) al_lam[j] = al_t[j];
+					__syncthreads();   // multipliers cross lanes through HBM: full barrier
+					if (!done_al) {
+						sri = fmax(sp.sr, fmin(1e-3, 0.1 * rvprev));
+						npairs = 0; finished = false; inner_inform = 4; state = ST_INIT;
+						make_feasible();   // steps stay in null(A) only to rounding: re-project before every further pass
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+						continue;
+					}
+				} else inform = inner_inform;
 				if (clambda && D.q_use && m > 0) {   // one more pass for the multipliers (the Q form does not produce them)
 					state = ST_FINAL;
 					lds_sync();
@@ -1141,12 +1267,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	if (clambda) {
 		const int ntot = n + m + D.ncnln;
 		for (int i = tid; i < ntot; i += NT)
-			clambda[(size_t)b * ntot + i] = (inform != 9 && i >= n && i < n + m) ? S.lam[i - n] : 0.0;
+			clambda[(size_t)b * ntot + i] = (inform == 9 || i < n) ? 0.0 : (i < n + m ? S.lam[i - n] : (al.mu > 0.0 ? -al_lam[i - n - m] : 0.0));
 		if (sp.stamps && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
 	}
 #undef NTG_STAMP
 	if (tid == 0) {
-		if (objective) objective[b] = F;
+		if (objective) objective[b] = Fp;
 		if (inform_out) inform_out[b] = inform;
 		if (iters_out) iters_out[b] = iter;
 		if (nfev_out) nfev_out[b] = nfev;
@@ -1196,7 +1322,7 @@ hostcost_kernel(NtgDims D, NtgTables T, SmemLayout L, const double *__restrict__
 	for (int e = threadIdx.x; e < P * nz; e += NT) { const int i = e / nz, v = e % nz; if (D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = D.nucf ? S.wts[i] * dfT[e] : 0.0; }
 	for (int v = threadIdx.x; v <= nz; v += NT) { S.dfi[v] = D.nicf ? fdI[v] : 0.0; S.dff[v] = D.nfcf ? fdF[v] : 0.0; }
 	double gn2;
-	const double val = cost_phase2<0, 0, NT>(D, S, S.vecs, &gn2, CoefMap<4>());
+	const double val = cost_phase2<0, 0, NT>(D, S, S.vecs, &gn2, CoefMap<4>(), D.nicf != 0, D.nfcf != 0, 0.0, 0.0, nullptr, nullptr);
 	if (threadIdx.x == 0) *F = val;
 	for (int i = threadIdx.x; i < D.nC; i += NT) g[i] = S.vecs[i];
 }
@@ -1377,13 +1503,13 @@ static hipError_t launch_eval_nt(int nt, const NtgDims &D, const NtgTables &T, c
 template <int FAM, int NOUT, int K>
 static hipError_t launch_sqp_nt(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L,
                                 const SolveParams &sp, int batch, const double *lo, const double *up, double *x,
-                                double *obj, int *inf, int *it, int *nf, double *cl, double *hist, hipStream_t st)
+                                double *obj, int *inf, int *it, int *nf, double *cl, double *hist, double *alw, hipStream_t st)
 {
 #define NTG_SQ(NTV)                                                                                         \
 	{                                                                                                       \
 		auto kfn = sqp_kernel<FAM, NOUT, K, NTV>;                                                           \
 		if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total); \
-		hipLaunchKernelGGL(kfn, dim3(batch), dim3(NTV), L.total, st, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist); \
+		hipLaunchKernelGGL(kfn, dim3(batch), dim3(NTV), L.total, st, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist, alw); \
 	}
 	if (nt == 128) NTG_SQ(128) else NTG_SQ(256)
 #undef NTG_SQ
@@ -1404,6 +1530,8 @@ static hipError_t launch_sqp_nt(int nt, const NtgDims &D, const NtgTables &T, co
 	if (D.family == NTG_FAM_VANDERPOL) return CALL(NTG_FAM_VANDERPOL, 0, 0);                      \
 	if (D.family == NTG_FAM_TESTFAM && d3 && D.nout == 3 && D.nC <= 4 * nt) return CALL(NTG_FAM_TESTFAM, 3, 0); \
 	if (D.family == NTG_FAM_TESTFAM) return CALL(NTG_FAM_TESTFAM, 0, 0);                          \
+	if (D.family == NTG_FAM_OBSTACLE && d3 && D.nout == 2 && ku == 6) return CALL(NTG_FAM_OBSTACLE, 2, 6); \
+	if (D.family == NTG_FAM_OBSTACLE) return CALL(NTG_FAM_OBSTACLE, 0, 0);                        \
 	return hipErrorInvalidValue;
 
 hipError_t ntg_launch_eval(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, int grid, int batch,
@@ -1417,9 +1545,9 @@ hipError_t ntg_launch_eval(int nt, const NtgDims &D, const NtgTables &T, const S
 
 hipError_t ntg_launch_sqp(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp,
                           int batch, const double *lo, const double *up, double *x, double *obj, int *inf, int *it,
-                          int *nf, double *cl, double *hist, hipStream_t st)
+                          int *nf, double *cl, double *hist, double *alw, hipStream_t st)
 {
-#define CALL(F, N, KV) launch_sqp_nt<F, N, KV>(nt, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist, st)
+#define CALL(F, N, KV) launch_sqp_nt<F, N, KV>(nt, D, T, L, sp, batch, lo, up, x, obj, inf, it, nf, cl, hist, alw, st)
 	NTG_DISPATCH(CALL)
 #undef CALL
 }

@@ -373,8 +373,9 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 		project(g, gp);
 		d = gp;
 		double alpha = 0, pnorm = 0;
+		int nupd = 0;
 		LineSearch ls;
-		for (iter = 0; okc && iter < itlim; iter++) {
+		for (iter = 0; okc && iter < itlim;) {
 			for (int i = 0; i < n; i++) p[i] = -d[i];
 			double dphi0 = dot(gp, p);
 			pnorm = nrm2(p);
@@ -405,7 +406,15 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 					rc = okc ? 1 : -1; break;
 				}
 			}
-			if (rc != 1) { info = (okc && nrm2(gp) <= tolg) ? 0 : 6; break; }
+			if (rc != 1) {
+				if (okc && nupd > 0 && nrm2(gp) > tolg) {   // retry from the same point with W0
+					nupd = 0;
+					std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
+					d = gp;
+					continue;
+				}
+				info = (okc && nrm2(gp) <= tolg) ? 0 : 6; break;
+			}
 			alpha = ls.a;
 			for (int i = 0; i < n; i++) { sv[i] = alpha * p[i]; y[i] = gpn[i] - gp[i]; }
 			x = xt;
@@ -415,12 +424,14 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 			if (sy > 1e-12 * nrm2(sv) * nrm2(y)) {
 				const double rho = 1.0 / sy, c2 = rho * (1.0 + rho * dot(y, u));
 				for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) W[(size_t)i * n + j] += -rho * (sv[i] * u[j] + u[i] * sv[j]) + c2 * sv[i] * sv[j];
+				nupd++;
 				const double a1 = dot(sv, gpn), a2 = dot(u, gpn);
 				for (int i = 0; i < n; i++) d[i] = t[i] - rho * (sv[i] * a2 + u[i] * a1) + c2 * sv[i] * a1;
 			} else d = t;
 			F = Fn; g = gn; gp = gpn;
 			if (g_opt.print_level >= 5) printf("  maj %3d  F=%.15g |Zg|=%.3e alpha=%.3e nf=%d\n", iter, F, nrm2(gp), alpha, ls.nfev);
-			if (alpha * pnorm <= sr * (1.0 + nrm2(x)) && nrm2(gp) <= sr * (1.0 + std::max(1.0 + std::fabs(F), nrm2(g)))) { info = 0; iter++; break; }
+			iter++;
+			if (alpha * pnorm <= sr * (1.0 + nrm2(x)) && nrm2(gp) <= sr * (1.0 + std::max(1.0 + std::fabs(F), nrm2(g)))) { info = 0; break; }
 		}
 		if (!okc) info = 9;
 		std::copy(x.begin(), x.end(), initialguess);                 // ntg.c:109: solution overwrites the guess

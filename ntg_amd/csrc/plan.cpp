@@ -116,7 +116,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	D.nclin = s->nlic + s->nltc * s->nbps + s->nlfc;           // ntg.c:156
 	D.ncnln = s->nnlic + s->nnltc * s->nbps + s->nnlfc;        // ntg.c:157
 	D.nbounds = s->nlic + s->nltc + s->nlfc + s->nnlic + s->nnltc + s->nnlfc;
-	if (s->family != NTG_FAM_KINCAR && s->family != NTG_FAM_VANDERPOL && s->family != NTG_FAM_TESTFAM && s->family != NTG_FAM_HOST) {
+	if (s->family != NTG_FAM_KINCAR && s->family != NTG_FAM_VANDERPOL && s->family != NTG_FAM_TESTFAM && s->family != NTG_FAM_OBSTACLE && s->family != NTG_FAM_HOST) {
 		delete p; return fail(NTG_E_BADARG, "unknown problem family");
 	}
 	if (s->family != NTG_FAM_HOST)
@@ -125,6 +125,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	if (s->family == NTG_FAM_VANDERPOL && s->nout != 1) { delete p; return fail(NTG_E_BADARG, "vanderpol family has one output"); }
 	if (s->family == NTG_FAM_TESTFAM && (s->nnlic > 1 || s->nnltc > 2 || s->nnlfc > 1)) { delete p; return fail(NTG_E_BADARG, "testfam has 1/2/1 nonlinear constraints"); }
 	if ((s->family == NTG_FAM_KINCAR || s->family == NTG_FAM_VANDERPOL) && D.ncnln > 0) { delete p; return fail(NTG_E_BADARG, "family has no nonlinear constraints"); }
+	if (s->family == NTG_FAM_OBSTACLE && (s->nout != 2 || s->nnlic || s->nnlfc || s->nnltc > 1)) { delete p; return fail(NTG_E_BADARG, "obstacle family: 2 outputs, at most one trajectory constraint"); }
 
 	bool ok = true;
 	D.icost_mask = av_mask(D, s->icostav, s->nicostav, &ok);
@@ -140,7 +141,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	D.ntav = 0;
 	for (int v = 0; v < NTG_MAX_NZ; v++) D.tav_row[v] = -1;
 	for (int v = 0; v < nz; v++)
-		if (s->family == NTG_FAM_HOST || ((D.tcost_mask >> v) & 1ull)) D.tav_row[v] = (signed char)D.ntav++;
+		if (s->family == NTG_FAM_HOST || (((D.tcost_mask | D.tcon_mask) >> v) & 1ull)) D.tav_row[v] = (signed char)D.ntav++;
 
 	// ---- basis classes: outputs with identical (knots, order, mult, maxderiv) share a table ----
 	p->h_knots.resize(s->nout);
@@ -503,7 +504,7 @@ extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, con
 	if (!p) return 0;
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
-	return (long long)batch * sp.memcap * (2 * p->D.nC + 2) * 8 + 256;
+	return (long long)batch * sp.memcap * (2 * p->D.nC + 2) * 8 + (long long)batch * 2 * p->D.ncnln * 8 + 256;
 }
 
 extern "C" int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
@@ -560,8 +561,9 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	if (sp.hessian == 1 && !p->T.n0) { int rc = build_precond(p); if (rc) return rc; }
 	SmemLayout L = ntg_make_layout(p->D, nt, 5, sp.memcap);
 	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
+	double *alw = (double *)d_work + (size_t)batch * sp.memcap * (2 * p->D.nC + 2);   // [batch][2][ncnln] multipliers, estimates
 	HIPCHK(ntg_launch_sqp(nt, p->D, p->T, L, sp, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev,
-	                      d_clambda, (double *)d_work, (hipStream_t)stream));
+	                      d_clambda, (double *)d_work, alw, (hipStream_t)stream));
 	return 0;
 }
 

@@ -25,7 +25,7 @@ hipError_t ntg_launch_eval(int nt, const NtgDims &D, const NtgTables &T, const S
                            hipStream_t st);
 hipError_t ntg_launch_sqp(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp,
                           int batch, const double *lo, const double *up, double *x, double *obj, int *inf, int *it,
-                          int *nf, double *cl, double *hist, hipStream_t st);
+                          int *nf, double *cl, double *hist, double *alw, hipStream_t st);
 hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,
                             long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st);
 hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,

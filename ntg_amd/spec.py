@@ -14,6 +14,7 @@ AV = Tuple[int, int]  # (output, deriv)  -- reference av.h:22-26
 FAM_KINCAR = 0
 FAM_VANDERPOL = 1
 FAM_TESTFAM = 2
+FAM_OBSTACLE = 3
 
 
 def linspace_c(d0: float, d1: float, n: int) -> np.ndarray:

@@ -11,6 +11,10 @@
  *   family 2  testfam    synthetic: every callback slot (initial/trajectory/final cost and
  *                        nonlinear constraints) populated with smooth nonlinear functions,
  *                        used only to exercise constraints.c/cost.c row orders.
+ *   family 3  obstacle   kincar running cost (2 outputs x, y) + one nonlinear trajectory constraint
+ *                        c = (x - 20)^2 + (y - 0.5)^2  (>= r^2 through the bounds): a circular obstacle on the
+ *                        lane-change path -- build-defined (BASELINE configs D/E are, too), used to exercise
+ *                        the nonlinear-constraint path of NPfuncon / npsol_ end to end.
  * All families assume maxderiv == 3 for every output (flat index iz[o] = 3*o).
  */
 #include <stdlib.h>
@@ -91,11 +95,21 @@ static void tf_nlfcf(int *mode, int *nstate, double *c, double **dc, double **zp
 	if (*mode == 1 || *mode == 2) { for (v = 0; v < 3 * fam_nout; v++) dc[0][v] = 0; dc[0][2] += zp[0][0]; dc[0][0] += zp[0][2]; dc[0][3 * L + 1] += 2.0 * zp[L][1]; }
 }
 
-orc_ucf_t orc_family_ucf(int fam) { return fam == 0 ? kincar_ucf : fam == 1 ? vdp_ucf : fam == 2 ? tf_ucf : NULL; }
+/* ---- family 3 ---- */
+#define OBS_X 20.0
+#define OBS_Y 0.5
+static void obs_nltcf(int *mode, int *nstate, int *i, double *c, double **dc, double **zp)
+{
+	const double dx = zp[0][0] - OBS_X, dy = zp[1][0] - OBS_Y; int v; (void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) c[0] = dx * dx + dy * dy;
+	if (*mode == 1 || *mode == 2) { for (v = 0; v < 6; v++) dc[0][v] = 0; dc[0][0] = 2.0 * dx; dc[0][3] = 2.0 * dy; }
+}
+
+orc_ucf_t orc_family_ucf(int fam) { return (fam == 0 || fam == 3) ? kincar_ucf : fam == 1 ? vdp_ucf : fam == 2 ? tf_ucf : NULL; }
 orc_icf_t orc_family_icf(int fam) { return fam == 2 ? tf_icf : NULL; }
 orc_icf_t orc_family_fcf(int fam) { return fam == 2 ? tf_fcf : NULL; }
 orc_nlic_t orc_family_nlicf(int fam) { return fam == 2 ? tf_nlicf : NULL; }
-orc_nltc_t orc_family_nltcf(int fam) { return fam == 2 ? tf_nltcf : NULL; }
+orc_nltc_t orc_family_nltcf(int fam) { return fam == 2 ? tf_nltcf : fam == 3 ? obs_nltcf : NULL; }
 orc_nlic_t orc_family_nlfcf(int fam) { return fam == 2 ? tf_nlfcf : NULL; }
 
 /* ---------------- batched CPU driver ---------------- */

@@ -280,22 +280,60 @@ static void project(const proj_t *pj, const double *g, double *gp, double *lam_o
 	if (lam_out) memcpy(lam_out, pj->tmpm, m * sizeof(double));
 }
 
+/* F_A and its gradient: the objective (orc_funobj) plus, when nonlinear constraints are present,
+ * the Powell-Hestenes-Rockafellar augmented-Lagrangian terms of  bl <= c(x) <= bu :
+ *   v = c + lam/mu,  p = clamp(v, bl, bu),  t = mu (v - p)   (= next multiplier estimate)
+ *   F_A = F + sum_j (t_j^2 - lam_j^2) / (2 mu),   grad F_A = g + J' t
+ * Also returns the relative violation  rv = sqrt( sum_j ((c_j - clamp(c_j))/(1+|c_j|))^2 ). */
+typedef struct {
+	orc_problem *p; int n, nc; double mu; double *lam, *tnew, *c; int nfev;
+} al_t;
+static double al_eval(al_t *a, const double *x, double *g, double *rv_out, double *gnorm_f)
+{
+	orc_problem *p = a->p;
+	int mode = 2, nstate = 0, n = a->n, nc = a->nc, i, j;
+	double F;
+	orc_funobj(p, &mode, x, &F, g, &nstate);
+	a->nfev++;
+	if (gnorm_f) *gnorm_f = nrm2_(g, n);
+	if (nc > 0) {
+		const double *bl = p->bl + n + p->nclin, *bu = p->bu + n + p->nclin;
+		double rv2 = 0.0, pen = 0.0;
+		mode = 2;
+		orc_funcon(p, &mode, x, a->c, NULL, &nstate);
+		for (j = 0; j < nc; j++) {
+			const double cj = a->c[j], v = cj + a->lam[j] / a->mu;
+			const double pj = v < bl[j] ? bl[j] : (v > bu[j] ? bu[j] : v);
+			const double cc = cj < bl[j] ? bl[j] : (cj > bu[j] ? bu[j] : cj);
+			const double tj = a->mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
+			a->tnew[j] = tj;
+			pen += (tj * tj - a->lam[j] * a->lam[j]) / (2.0 * a->mu);
+			rv2 += rj * rj;
+		}
+		F += pen;
+		for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < nc; j++) sum += M_(p->cJac, nc, j, i) * a->tnew[j]; g[i] += sum; }
+		if (rv_out) *rv_out = sqrt(rv2);
+	} else if (rv_out) *rv_out = 0.0;
+	return F;
+}
+
 void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_result *res,
                    double *clambda, int *istate, double *R, double *trace, int trace_cap)
 {
 	const orc_colloc *cc = p->cc;
-	int n = cc->nC, m = p->nclin, i, j, iter = 0, mode, nstate = 1, nfev = 0, inform = 4;
-	int itlim = o->itlim > 0 ? o->itlim : (50 > 3 * (n + m) + 10 * p->ncnln ? 50 : 3 * (n + m) + 10 * p->ncnln);
-	double r = o->opttol > 0 ? o->opttol : pow(DBL_EPSILON, 0.8), sr = sqrt(r);
+	int n = cc->nC, m = p->nclin, nc = p->ncnln, i, j, iter = 0, inform = 4, outer;
+	int itlim = o->itlim > 0 ? o->itlim : (50 > 3 * (n + m) + 10 * nc ? 50 : 3 * (n + m) + 10 * nc);
+	double r = o->opttol > 0 ? o->opttol : pow(DBL_EPSILON, 0.8), sr = sqrt(r), ftol = 1e-8;
 	double *W, *W0 = NULL, *g, *gp, *gn, *gpn, *d, *pdir, *xt, *s, *y, *u, *t, *lam;
-	double F = 0, Fn = 0, alpha = 0, pnorm = 0;
+	double F = 0, Fn = 0, alpha = 0, pnorm = 0, gnf = 0, gnfn = 0, rv = 0, rvn = 0, rv_prev = HUGE_VAL;
 	proj_t pj;
 	ls_t ls;
+	al_t al;
 
 	memset(res, 0, sizeof(*res));
-	/* scope check: linear equalities only (SURVEY.md §8 f.1 is "next") */
-	if (p->ncnln > 0) { res->inform = 9; return; }
+	/* scope: linear rows must be equalities (lower == upper); nonlinear rows may be anything */
 	for (i = 0; i < m; i++) if (p->bl[n + i] != p->bu[n + i]) { res->inform = 9; return; }
+	if (nc > 0 && o->fixed_iters) { res->inform = 9; return; }
 
 	W = malloc((size_t)n * n * sizeof(double));
 	g = malloc(n * sizeof(double)); gp = malloc(n * sizeof(double)); gn = malloc(n * sizeof(double));
@@ -303,6 +341,8 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	xt = malloc(n * sizeof(double)); s = malloc(n * sizeof(double)); y = malloc(n * sizeof(double));
 	u = malloc(n * sizeof(double)); t = malloc(n * sizeof(double)); lam = calloc(m + 1, sizeof(double));
 	pj.p = p; pj.n = n; pj.m = m; pj.S = NULL; pj.tmpm = malloc((m + 1) * sizeof(double));
+	al.p = p; al.n = n; al.nc = nc; al.mu = 10.0; al.nfev = 0;
+	al.lam = calloc(nc + 1, sizeof(double)); al.tnew = calloc(nc + 1, sizeof(double)); al.c = calloc(nc + 1, sizeof(double));
 	if (m > 0) {
 		pj.S = malloc((size_t)m * m * sizeof(double));
 		for (i = 0; i < m; i++) for (j = 0; j < m; j++) {
@@ -319,86 +359,138 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 		W0 = malloc((size_t)n * n * sizeof(double));
 		if (build_colloc_W0(p, W0)) { free(W0); W0 = NULL; }
 	}
-	if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
-	else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
 
-	mode = 2; orc_funobj(p, &mode, x, &F, g, &nstate); nfev++; nstate = 0;
-	project(&pj, g, gp, lam);
-	for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
-
-	for (iter = 0; iter < itlim; iter++) {
-		double dphi0, xnorm, amax, a1, sy, yu, rho, cc2;
-		int rc;
-		for (i = 0; i < n; i++) pdir[i] = -d[i];
-		dphi0 = dot_(gp, pdir, n);
-		pnorm = nrm2_(pdir, n); xnorm = nrm2_(x, n);
-		if (pnorm == 0.0 || !(dphi0 < 0.0)) {
-			/* already stationary in null(A) (or W lost definiteness numerically: restart once) */
-			if (pnorm != 0.0) {
-				if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
-				else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
-				for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; pdir[i] = -sum; }
-				dphi0 = dot_(gp, pdir, n); pnorm = nrm2_(pdir, n);
-			}
-			if (pnorm == 0.0 || !(dphi0 < 0.0)) { inform = (nrm2_(gp, n) <= sr * (1 + fmax(1 + fabs(F), nrm2_(g, n)))) ? 0 : 6; break; }
+	/* outer loop: one pass when there are no nonlinear constraints; otherwise the multiplier /
+	 * penalty iteration of the augmented Lagrangian (at most 30 passes) */
+	for (outer = 0; outer < (nc > 0 ? 30 : 1); outer++) {
+		/* inner tolerance: NPSOL's for the last passes, looser while the constraints are far off */
+		const double sri = nc > 0 ? fmax(sr, fmin(1e-3, 0.1 * rv_prev)) : sr;
+		int inner_inform = 4, stop = 0, at_x = 1, nupd = 0;
+		if (outer > 0 && m > 0) {
+			/* steps stay in null(A) only to rounding; hundreds of majors per pass can drift: re-apply
+			 * x += A'(AA')^-1 (b - A x) before every further pass */
+			for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(p->A, m, i, j) * x[j]; pj.tmpm[i] = p->bl[n + i] - sum; }
+			chol_solve_(pj.S, m, pj.tmpm);
+			for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(p->A, m, i, j) * pj.tmpm[i]; x[j] += sum; }
 		}
-		/* already stationary to rounding level: a line search could only fail */
-		if (!o->fixed_iters && nrm2_(gp, n) <= 1e-3 * sr * (1.0 + fmax(1.0 + fabs(F), nrm2_(g, n)))) { inform = 0; break; }
-		amax = o->steplimit * (1.0 + xnorm) / pnorm;
-		a1 = amax < 1.0 ? amax : 1.0;
-		ls_init(&ls, F, dphi0, a1, amax, o->ls_mu, o->ls_eta, o->ls_maxfev);
+		if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
+		else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
+		F = al_eval(&al, x, g, &rv, &gnf);
+		project(&pj, g, gp, lam);
+		for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
+
 		for (;;) {
-			double dphi;
-			for (i = 0; i < n; i++) xt[i] = x[i] + ls.a * pdir[i];
-			mode = 2; orc_funobj(p, &mode, xt, &Fn, gn, &nstate); nfev++;
-			project(&pj, gn, gpn, lam);
-			dphi = dot_(gpn, pdir, n);
-			rc = ls_step(&ls, Fn, dphi);
-			if (rc == 1 || rc == -1) break;
-			if (rc == 2) {
-				for (i = 0; i < n; i++) xt[i] = x[i] + ls.a * pdir[i];
-				mode = 2; orc_funobj(p, &mode, xt, &Fn, gn, &nstate); nfev++;
-				project(&pj, gn, gpn, lam);
-				rc = 1; break;
+			double dphi0, xnorm, amax, a1, sy, yu, rho, cc2, tolg;
+			int rc;
+			if (iter >= itlim) { inner_inform = 4; stop = 1; break; }
+			for (i = 0; i < n; i++) pdir[i] = -d[i];
+			dphi0 = dot_(gp, pdir, n);
+			pnorm = nrm2_(pdir, n); xnorm = nrm2_(x, n);
+			tolg = sri * (1.0 + fmax(1.0 + fabs(F), gnf));
+			if (pnorm == 0.0 || !(dphi0 < 0.0)) {
+				/* already stationary in null(A) (or W lost definiteness numerically: restart once) */
+				if (pnorm != 0.0) {
+					nupd = 0;
+					if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
+					else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
+					for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; pdir[i] = -sum; }
+					dphi0 = dot_(gp, pdir, n); pnorm = nrm2_(pdir, n);
+				}
+				if (pnorm == 0.0 || !(dphi0 < 0.0)) { inner_inform = (nrm2_(gp, n) <= tolg) ? 0 : 6; break; }
 			}
+			/* already stationary to rounding level: a line search could only fail */
+			if (!o->fixed_iters && nrm2_(gp, n) <= 1e-3 * tolg) { inner_inform = 0; break; }
+			amax = o->steplimit * (1.0 + xnorm) / pnorm;
+			a1 = amax < 1.0 ? amax : 1.0;
+			ls_init(&ls, F, dphi0, a1, amax, o->ls_mu, o->ls_eta, o->ls_maxfev);
+			for (;;) {
+				double dphi;
+				for (i = 0; i < n; i++) xt[i] = x[i] + ls.a * pdir[i];
+				Fn = al_eval(&al, xt, gn, &rvn, &gnfn);
+				project(&pj, gn, gpn, lam);
+				dphi = dot_(gpn, pdir, n);
+				rc = ls_step(&ls, Fn, dphi);
+				if (rc == 1 || rc == -1) break;
+				if (rc == 2) {
+					for (i = 0; i < n; i++) xt[i] = x[i] + ls.a * pdir[i];
+					Fn = al_eval(&al, xt, gn, &rvn, &gnfn);
+					project(&pj, gn, gpn, lam);
+					rc = 1; break;
+				}
+			}
+			if (rc != 1) {
+				/* line search failed: if the quasi-Newton matrix carries updates, drop them and retry from
+				 * the same point with W0 (a poor W is the usual cause); fail only if W0 itself fails */
+				if (nupd > 0 && nrm2_(gp, n) > tolg) {
+					nupd = 0;
+					if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
+					else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
+					for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
+					continue;
+				}
+				inner_inform = (nrm2_(gp, n) <= tolg) ? 0 : 6; at_x = 0; break;
+			}
+			alpha = ls.a;
+			for (i = 0; i < n; i++) { s[i] = alpha * pdir[i]; y[i] = gpn[i] - gp[i]; }
+			memcpy(x, xt, n * sizeof(double));
+			/* t = W gp+,  u = W y = t - d */
+			for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gpn[j]; t[i] = sum; }
+			for (i = 0; i < n; i++) u[i] = t[i] - d[i];
+			sy = dot_(s, y, n);
+			if (sy > 1e-12 * nrm2_(s, n) * nrm2_(y, n)) {
+				double a1s, a2u;
+				yu = dot_(y, u, n); rho = 1.0 / sy; cc2 = rho * (1.0 + rho * yu);
+				for (j = 0; j < n; j++) for (i = 0; i < n; i++)
+					M_(W, n, i, j) += -rho * (s[i] * u[j] + u[i] * s[j]) + cc2 * s[i] * s[j];
+				nupd++;
+				a1s = dot_(s, gpn, n); a2u = dot_(u, gpn, n);
+				for (i = 0; i < n; i++) d[i] = t[i] - rho * (s[i] * a2u + u[i] * a1s) + cc2 * s[i] * a1s;
+			} else {
+				memcpy(d, t, n * sizeof(double));
+			}
+			F = Fn; gnf = gnfn; rv = rvn; memcpy(g, gn, n * sizeof(double)); memcpy(gp, gpn, n * sizeof(double));
+			if (trace && iter < trace_cap) {
+				trace[4 * iter + 0] = F; trace[4 * iter + 1] = nrm2_(gp, n); trace[4 * iter + 2] = alpha; trace[4 * iter + 3] = (double)ls.nfev;
+			}
+			if (o->verbose) fprintf(stderr, "  maj %3d  F=%.15g |Zg|=%.3e alpha=%.3e nf=%d rv=%.2e mu=%g\n", iter, F, nrm2_(gp, n), alpha, ls.nfev, rv, al.mu);
+			iter++;
+			if (!o->fixed_iters &&
+			    alpha * pnorm <= sri * (1.0 + nrm2_(x, n)) &&
+			    nrm2_(gp, n) <= sri * (1.0 + fmax(1.0 + fabs(F), gnf))) { inner_inform = 0; break; }
 		}
-		if (rc != 1) { inform = (nrm2_(gp, n) <= sr * (1.0 + fmax(1.0 + fabs(F), nrm2_(g, n)))) ? 0 : 6; break; }
-		alpha = ls.a;
-		for (i = 0; i < n; i++) { s[i] = alpha * pdir[i]; y[i] = gpn[i] - gp[i]; }
-		memcpy(x, xt, n * sizeof(double));
-		/* t = W gp+,  u = W y = t - d */
-		for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gpn[j]; t[i] = sum; }
-		for (i = 0; i < n; i++) u[i] = t[i] - d[i];
-		sy = dot_(s, y, n);
-		if (sy > 1e-12 * nrm2_(s, n) * nrm2_(y, n)) {
-			double a1s, a2u;
-			yu = dot_(y, u, n); rho = 1.0 / sy; cc2 = rho * (1.0 + rho * yu);
-			for (j = 0; j < n; j++) for (i = 0; i < n; i++)
-				M_(W, n, i, j) += -rho * (s[i] * u[j] + u[i] * s[j]) + cc2 * s[i] * s[j];
-			a1s = dot_(s, gpn, n); a2u = dot_(u, gpn, n);
-			for (i = 0; i < n; i++) d[i] = t[i] - rho * (s[i] * a2u + u[i] * a1s) + cc2 * s[i] * a1s;
-		} else {
-			memcpy(d, t, n * sizeof(double));
-		}
-		F = Fn; memcpy(g, gn, n * sizeof(double)); memcpy(gp, gpn, n * sizeof(double));
-		if (trace && iter < trace_cap) {
-			trace[4 * iter + 0] = F; trace[4 * iter + 1] = nrm2_(gp, n); trace[4 * iter + 2] = alpha; trace[4 * iter + 3] = (double)ls.nfev;
-		}
-		if (o->verbose) fprintf(stderr, "  maj %3d  F=%.15g |Zg|=%.3e alpha=%.3e nf=%d\n", iter, F, nrm2_(gp, n), alpha, ls.nfev);
-		if (!o->fixed_iters &&
-		    alpha * pnorm <= sr * (1.0 + nrm2_(x, n)) &&
-		    nrm2_(gp, n) <= sr * (1.0 + fmax(1.0 + fabs(F), nrm2_(g, n)))) { inform = 0; iter++; break; }
+		if (nc == 0) { inform = inner_inform; break; }
+		/* ---- multiplier / penalty update from the constraint values AT x: if the inner solve ended on a
+		 *      rejected line-search trial, the last evaluation was elsewhere -> evaluate once more at x ---- */
+		if (!at_x) { F = al_eval(&al, x, g, &rv, &gnf); at_x = 1; }
+		if (inner_inform == 6) { inform = 6; break; }
+		if (rv <= ftol && sri <= sr && inner_inform == 0) { memcpy(al.lam, al.tnew, nc * sizeof(double)); inform = 0; break; }
+		if (stop) { inform = 4; break; }
+		if (rv <= 0.25 * rv_prev) { memcpy(al.lam, al.tnew, nc * sizeof(double)); rv_prev = rv; }
+		else al.mu *= 10.0;
+		if (outer == 29) inform = 3;   /* nonlinear constraints not satisfied to tolerance */
 	}
 done:
-	res->inform = inform; res->iters = iter; res->nfev = nfev; res->objective = F;
+	res->inform = inform; res->iters = iter; res->nfev = al.nfev;
+	/* objective WITHOUT the penalty terms (what NPSOL reports) */
+	if (inform != 9) {
+		if (nc > 0) { int mode = 0, nstate = 0; orc_funobj(p, &mode, x, &F, NULL, &nstate); }
+		res->objective = F;
+	}
 	res->pg_norm = (inform == 9) ? 0.0 : nrm2_(gp, n);
-	{ /* linear feasibility */
+	{ /* linear feasibility (and relative nonlinear violation) */
 		double worst = 0.0;
 		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(p->A, m, i, j) * x[j]; worst = fmax(worst, fabs(sum - p->bl[n + i])); }
-		res->feas = worst;
+		res->feas = fmax(worst, nc > 0 && inform != 9 ? rv : 0.0);
 	}
-	if (clambda) { for (i = 0; i < n; i++) clambda[i] = 0.0; for (i = 0; i < m; i++) clambda[n + i] = lam[i]; }
-	if (istate) { for (i = 0; i < n; i++) istate[i] = 0; for (i = 0; i < m; i++) istate[n + i] = 3; }
+	if (clambda) { for (i = 0; i < n; i++) clambda[i] = 0.0; for (i = 0; i < m; i++) clambda[n + i] = lam[i]; for (i = 0; i < nc; i++) clambda[n + m + i] = -al.lam[i]; /* NPSOL sign: grad F = A' lam_lin + J' lam_nl */ }
+	if (istate) {
+		for (i = 0; i < n; i++) istate[i] = 0;
+		for (i = 0; i < m; i++) istate[n + i] = 3;
+		for (i = 0; i < nc; i++) {
+			const double bl = p->bl[n + m + i], bu = p->bu[n + m + i], cv = al.c[i];
+			istate[n + m + i] = (bl == bu) ? 3 : (al.lam[i] != 0.0 ? (fabs(cv - bl) <= fabs(cv - bu) ? 1 : 2) : 0);
+		}
+	}
 	if (R && inform != 9) {
 		/* R'R = (W + A'(AA')^-1 A)^-1 when W0 is rank-deficient; W itself otherwise */
 		double *Hf = malloc((size_t)n * n * sizeof(double)), *col = malloc(n * sizeof(double));
@@ -410,8 +502,6 @@ done:
 			free(X);
 		}
 		if (!chol_(Hf, n)) {
-			/* Hf = L L' = W  =>  H = L^-T L^-1 ; R = L^-1 is lower; NPSOL's R is upper: use
-			 * the reverse ordering trick is not needed for a test oracle -- report chol(H) upper */
 			double *Hinv = calloc((size_t)n * n, sizeof(double));
 			for (j = 0; j < n; j++) { memset(col, 0, n * sizeof(double)); col[j] = 1.0; chol_solve_(Hf, n, col); for (i = 0; i < n; i++) M_(Hinv, n, i, j) = col[i]; }
 			if (!chol_(Hinv, n)) { /* Hinv = L2 L2' ; R = L2' (upper) */
@@ -424,4 +514,5 @@ done:
 	}
 	free(W); free(W0); free(g); free(gp); free(gn); free(gpn); free(d); free(pdir); free(xt);
 	free(s); free(y); free(u); free(t); free(lam); free(pj.S); free(pj.tmpm);
+	free(al.lam); free(al.tnew); free(al.c);
 }

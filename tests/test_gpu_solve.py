@@ -100,9 +100,6 @@ def test_unsupported_inputs_are_loud_not_wrong():
     x, out = solve("K0", np.stack([lo, lo]), np.stack([up, up2]), np.ones((2, spec.nC)))
     assert out["inform"][0] == 0 and out["inform"][1] == 9       # inequality: flagged, per problem
     assert np.array_equal(x[1], np.ones(spec.nC))                 # and left untouched
-    T = plan_for("T").spec
-    xt, ot = solve("T", np.zeros((1, T.nbounds)), np.zeros((1, T.nbounds)), np.ones((1, T.nC)))
-    assert ot["inform"][0] == 9
 
 
 def test_iteration_limit_and_ragged_batch():

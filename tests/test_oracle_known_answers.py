@@ -99,12 +99,36 @@ def test_fixed_iteration_mode_and_limits():
 
 def test_unsupported_inputs_are_loud():
     spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
-    up2 = up.copy(); up2[0] += 1.0                         # a linear inequality: not in v1 scope
+    up2 = up.copy(); up2[0] += 1.0                         # a LINEAR inequality row: not in scope yet
     r = orc.solve_one(spec, lo, up2, np.ones(spec.nC))
     assert r["inform"] == 9
-    T = cf.config_T()
-    r = orc.solve_one(T, np.zeros(T.nbounds), np.zeros(T.nbounds), np.ones(T.nC))
-    assert r["inform"] == 9                                # nonlinear constraints: next round
+    O = cf.config_O(10); lo, up = cf.obstacle_bounds(1)
+    r = orc.solve_one(O, lo[0], up[0], np.ones(O.nC), orc.default_opts(itlim=50, fixed_iters=1))
+    assert r["inform"] == 9                                # fixed-work mode is defined for ncnln == 0 only
+
+
+@pytest.mark.parametrize("hessian", [0, 1])
+def test_obstacle_nonlinear_inequality_kkt(hessian):
+    """Nonlinear trajectory inequality (family 3) through the augmented-Lagrangian outer loop: KKT conditions
+    at the returned point, checked independently of the solver (NPSOL sign convention of clambda)."""
+    spec = cf.config_O(10)
+    lo, up = cf.obstacle_bounds(6)
+    nact = 0
+    for p in range(6):
+        r = orc.solve_one(spec, lo[p], up[p], np.ones(spec.nC), orc.default_opts(hessian=hessian))
+        assert r["inform"] == 0
+        ev = orc.eval_batch(spec, r["x"][None], 2)
+        g, J, c = ev["g"][0], ev["cJac"][0], ev["c"][0]
+        A = orc.export_tables(spec, lo[p], up[p])["A"]
+        lam = r["clambda"]; ll, ln = lam[spec.nC:spec.nC + spec.nclin], lam[spec.nC + spec.nclin:]
+        assert np.abs(g - A.T @ ll - J.T @ ln).max() <= 2e-6 * np.abs(g).max()      # stationarity
+        assert np.abs(A @ r["x"] - lo[p][:spec.nclin]).max() <= 1e-8                # linear feasibility
+        assert (c - 9.0).min() >= -1e-7 * 9.0                                        # c >= r^2
+        assert ln.min() >= -1e-9                                                      # dual feasibility
+        assert np.abs(ln * (c - 9.0)).max() <= 1e-5 * max(1.0, np.abs(ln).max())     # complementarity
+        nact += int((ln > 1e-9).sum())
+        assert list(r["istate"][spec.nC:spec.nC + spec.nclin]) == [3] * spec.nclin
+    assert nact >= 3                                       # the obstacle really is active in this sample
 
 
 def test_R_factor_is_cholesky_of_hessian_estimate():
