@@ -533,7 +533,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 		const double v = cj + lamj / al.mu;
 		const double pj = v < l ? l : (v > u ? u : v), cc = cj < l ? l : (cj > u ? u : cj);
 		const double t = al.mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
-		psi += (t * t - lamj * lamj) / (2.0 * al.mu);
+		psi += (t - lamj) * (t + lamj) / (2.0 * al.mu);   // factored: no cancellation when c is tiny
 		rv2 += rj * rj;
 		al.tnew[row] = t;
 		return t;
@@ -1029,7 +1029,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	double F = 0.0, Fp = 0.0, gn2 = 0.0, rv2 = 0.0, alpha = 0.0, pnorm = 0.0;
 	double sri = sp.sr, rvprev = HUGE_VAL;   // inner tolerance and best violation so far (AL outer loop)
 	int outer = 0, inner_inform = 4;
-	bool at_x = true;
+	bool at_x = true, weak = false;
 	if (inform != 9) {
 		// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
 		auto make_feasible = [&]() {
@@ -1048,12 +1048,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			for (int r = tid; r < m; r += NT) {
 				double a = 0.0;
 				for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
-				S.lam[r] = a;
+				tmp[m + r] = a;   // not S.lam: that holds the multiplier estimate reported in clambda
 			}
 			lds_sync();
 			for (int c = tid; c < n; c += NT) {
 				double s = 0.0;
-				for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * S.lam[S.csc_row[e]];
+				for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * tmp[m + S.csc_row[e]];
 				sx[c] += s;
 			}
 			lds_sync();
@@ -1141,7 +1141,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						r4[0] = r2[0]; r4[1] = r2[1];
 						new_major = true;
 					} else {
-						inner_inform = (sqrt(r4[3]) <= tolg) ? 0 : 6;
+						// no further decrease obtainable: converged within tolerance, or "optimal but not to the
+						// requested accuracy" (NPSOL inform 1) within 10^3 of it, else failure (6)
+						const double gpn0 = sqrt(r4[3]);
+						if (gpn0 <= tolg) inner_inform = 0;
+						else if (gpn0 <= 1e3 * tolg) { inner_inform = 0; weak = true; }
+						else inner_inform = 6;
 						finished = true; at_x = false;
 					}
 				} else {
@@ -1233,7 +1238,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					bool done_al = false;
 					bool take = false;
 					if (inner_inform == 6) { inform = 6; done_al = true; }
-					else if (rv <= 1e-8 && sri <= sp.sr && inner_inform == 0) { take = true; inform = 0; done_al = true; }
+					else if (rv <= 1e-8 && sri <= sp.sr && inner_inform == 0) { take = true; inform = weak ? 1 : 0; done_al = true; }
 					else if (inner_inform == 4) { inform = 4; done_al = true; }
 					else {
 						if (rv <= 0.25 * rvprev) { take = true; rvprev = rv; }
@@ -1245,12 +1250,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					__syncthreads();   // multipliers cross lanes through HBM: full barrier
 					if (!done_al) {
 						sri = fmax(sp.sr, fmin(1e-3, 0.1 * rvprev));
-						npairs = 0; finished = false; inner_inform = 4; state = ST_INIT;
+						npairs = 0; finished = false; inner_inform = 4; state = ST_INIT; weak = false;
 						make_feasible();   // steps stay in null(A) only to rounding: re-project before every further pass
 						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 						continue;
 					}
-				} else inform = inner_inform;
+				} else inform = (inner_inform == 0 && weak) ? 1 : inner_inform;
 				if (clambda && D.q_use && m > 0) {   // one more pass for the multipliers (the Q form does not produce them)
 					state = ST_FINAL;
 					lds_sync();
@@ -1260,6 +1265,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				break;
 			}
 		}
+		// many hundreds of majors under a large penalty let x drift off A x = b by rounding: restore it
+		if (al.mu > 0.0) make_feasible();
 	}
 	lds_sync();
 	for (int i = tid; i < n; i += NT) xio[(size_t)b * n + i] = sx[i];

@@ -340,10 +340,13 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 		if (r < nlic) si = r; else if (r < nlic + nltc * nbps) si = nlic + (r - nlic) / nbps; else si = nlic + nltc + (r - nlic - nltc * nbps);
 		bl[r] = lowerb[si]; bu[r] = upperb[si];
 	}
-	bool supported = D.ncnln == 0 && hp.plan->lin_ok;
+	const int nc = D.ncnln;
+	bool supported = hp.plan->lin_ok;
 	for (int r = 0; r < m; r++) if (bl[r] != bu[r]) supported = false;
+	std::vector<double> allam(nc, 0.0);          // augmented-Lagrangian multipliers of the nonlinear rows
+	std::vector<double> cval(nc, 0.0);
 	if (!supported) {
-		fprintf(stderr, "ntg (MI355X): inequality / nonlinear constraints are not solved by this build (inform 9);\n"
+		fprintf(stderr, "ntg (MI355X): linear INEQUALITY rows (lower != upper) are not solved by this build (inform 9);\n"
 		                "              npsolCostFunction/npsolConstraintFunction remain usable with an external SQP driver\n");
 		info = 9;
 	} else {
@@ -358,86 +361,146 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 			chol_solve(S, m, lam.data());
 			for (int c = 0; c < n; c++) { double a = 0; for (int i = 0; i < m; i++) a += A[(size_t)i * n + c] * lam[i]; gp[c] -= a; }
 		};
-		if (m) { // linear feasibility phase
+		auto make_feasible = [&]() { // linear feasibility phase
+			if (!m) return;
 			std::vector<double> r(m);
 			for (int i = 0; i < m; i++) { double a = 0; for (int c = 0; c < n; c++) a += A[(size_t)i * n + c] * x[c]; r[i] = bl[i] - a; }
 			chol_solve(S, m, r.data());
 			for (int c = 0; c < n; c++) { double a = 0; for (int i = 0; i < m; i++) a += A[(size_t)i * n + c] * r[i]; x[c] += a; }
-		}
+		};
+		make_feasible();
 		const ntg_solve_opts &o = g_opt.o;
-		const int itlim = o.itlim > 0 ? o.itlim : std::max(50, 3 * (n + m));
+		const int itlim = o.itlim > 0 ? o.itlim : std::max(50, 3 * (n + m) + 10 * nc);
 		const double sr = std::sqrt(o.opttol > 0 ? o.opttol : std::pow(DBL_EPSILON, 0.8));
+		// expanded bounds of the nonlinear rows (constraints.c:24-30)
+		std::vector<double> nbl(nc), nbu(nc);
+		{
+			const int b0 = nlic + nltc + nlfc;
+			for (int r = 0; r < nc; r++) {
+				int si;
+				if (r < nnlic) si = b0 + r; else if (r < nnlic + nnltc * nbps) si = b0 + nnlic + (r - nnlic) / nbps; else si = b0 + nnlic + nnltc + (r - nnlic - nnltc * nbps);
+				nbl[r] = lowerb[si]; nbu[r] = upperb[si];
+			}
+		}
+		std::vector<double> tnew(nc, 0.0), J((size_t)nc * n, 0.0);
+		double mu = 10.0, Fp = 0.0;
+		bool okc = true;
+		// F_A = F + sum (t^2 - lam^2)/(2 mu), grad = g + J't  (DESIGN.md section 4b); rv = relative violation
+		auto al_eval = [&](const std::vector<double> &xx, std::vector<double> &gg, double &rv, double &gnf, double &Fpure) -> double {
+			double Fv = 0.0;
+			if (!host_funobj(hp, 2, xx.data(), &Fv, gg.data(), &nstate)) { okc = false; return 0.0; }
+			nstate = 0;
+			gnf = nrm2(gg); Fpure = Fv; rv = 0.0;
+			if (nc > 0) {
+				if (!host_funcon(hp, 2, xx.data(), cval.data(), J.data(), nc, &nstate)) { okc = false; return 0.0; }
+				double pen = 0.0, rv2 = 0.0;
+				for (int j = 0; j < nc; j++) {
+					const double cj = cval[j], v = cj + allam[j] / mu;
+					const double pj = v < nbl[j] ? nbl[j] : (v > nbu[j] ? nbu[j] : v), cc = cj < nbl[j] ? nbl[j] : (cj > nbu[j] ? nbu[j] : cj);
+					const double tj = mu * (v - pj), rj = (cj - cc) / (1.0 + std::fabs(cj));
+					tnew[j] = tj; pen += (tj - allam[j]) * (tj + allam[j]) / (2.0 * mu); rv2 += rj * rj;
+				}
+				Fv += pen;
+				for (int c = 0; c < n; c++) { double a = 0.0; for (int j = 0; j < nc; j++) a += J[(size_t)c * nc + j] * tnew[j]; gg[c] += a; }
+				rv = std::sqrt(rv2);
+			}
+			return Fv;
+		};
 		std::vector<double> g(n), gp(n), gn(n), gpn(n), d(n), p(n), xt(n), sv(n), y(n), u(n), t(n);
-		for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
-		bool okc = host_funobj(hp, 2, x.data(), &F, g.data(), &nstate); nstate = 0;
-		project(g, gp);
-		d = gp;
-		double alpha = 0, pnorm = 0;
-		int nupd = 0;
+		double alpha = 0, pnorm = 0, gnf = 0, gnfn = 0, rv = 0, rvn = 0, rvprev = HUGE_VAL, Fpn = 0;
 		LineSearch ls;
-		for (iter = 0; okc && iter < itlim;) {
-			for (int i = 0; i < n; i++) p[i] = -d[i];
-			double dphi0 = dot(gp, p);
-			pnorm = nrm2(p);
-			const double tolg = sr * (1.0 + std::max(1.0 + std::fabs(F), nrm2(g)));
-			if (pnorm == 0.0 || !(dphi0 < 0.0)) {
-				if (pnorm != 0.0) {
-					std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
-					d = gp; for (int i = 0; i < n; i++) p[i] = -d[i];
-					dphi0 = dot(gp, p); pnorm = nrm2(p);
-				}
-				if (pnorm == 0.0 || !(dphi0 < 0.0)) { info = nrm2(gp) <= tolg ? 0 : 6; break; }
-			}
-			if (nrm2(gp) <= 1e-3 * tolg) { info = 0; break; }
-			const double amax = (o.steplimit > 0 ? o.steplimit : 2.0) * (1.0 + nrm2(x)) / pnorm;
-			ls.init(F, dphi0, amax < 1.0 ? amax : 1.0, amax, o.ls_mu, o.ls_eta, o.ls_maxfev);
-			double Fn = 0; int rc;
+		for (int outer = 0; okc && outer < (nc > 0 ? 30 : 1); outer++) {
+			const double sri = nc > 0 ? std::max(sr, std::min(1e-3, 0.1 * rvprev)) : sr;
+			int inner = 4, nupd = 0; bool stop = false, at_x = true, weak = false;
+			if (outer > 0) make_feasible();
+			std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
+			F = al_eval(x, g, rv, gnf, Fp);
+			if (!okc) break;
+			project(g, gp);
+			d = gp;
 			for (;;) {
-				for (int i = 0; i < n; i++) xt[i] = x[i] + ls.a * p[i];
-				okc = host_funobj(hp, 2, xt.data(), &Fn, gn.data(), &nstate);
-				if (!okc) { rc = -1; break; }
-				project(gn, gpn);
-				rc = ls.step(Fn, dot(gpn, p));
-				if (rc == 1 || rc == -1) break;
-				if (rc == 2) {
+				if (iter >= itlim) { inner = 4; stop = true; break; }
+				for (int i = 0; i < n; i++) p[i] = -d[i];
+				double dphi0 = dot(gp, p);
+				pnorm = nrm2(p);
+				const double tolg = sri * (1.0 + std::max(1.0 + std::fabs(F), gnf));
+				if (pnorm == 0.0 || !(dphi0 < 0.0)) {
+					if (pnorm != 0.0) {
+						nupd = 0;
+						std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
+						d = gp; for (int i = 0; i < n; i++) p[i] = -d[i];
+						dphi0 = dot(gp, p); pnorm = nrm2(p);
+					}
+					if (pnorm == 0.0 || !(dphi0 < 0.0)) { inner = nrm2(gp) <= tolg ? 0 : 6; break; }
+				}
+				if (nrm2(gp) <= 1e-3 * tolg) { inner = 0; break; }
+				const double amax = (o.steplimit > 0 ? o.steplimit : 2.0) * (1.0 + nrm2(x)) / pnorm;
+				ls.init(F, dphi0, amax < 1.0 ? amax : 1.0, amax, o.ls_mu, o.ls_eta, o.ls_maxfev);
+				double Fn = 0; int rc;
+				for (;;) {
 					for (int i = 0; i < n; i++) xt[i] = x[i] + ls.a * p[i];
-					okc = host_funobj(hp, 2, xt.data(), &Fn, gn.data(), &nstate);
+					Fn = al_eval(xt, gn, rvn, gnfn, Fpn);
+					if (!okc) { rc = -1; break; }
 					project(gn, gpn);
-					rc = okc ? 1 : -1; break;
+					rc = ls.step(Fn, dot(gpn, p));
+					if (rc == 1 || rc == -1) break;
+					if (rc == 2) {
+						for (int i = 0; i < n; i++) xt[i] = x[i] + ls.a * p[i];
+						Fn = al_eval(xt, gn, rvn, gnfn, Fpn);
+						project(gn, gpn);
+						rc = okc ? 1 : -1; break;
+					}
 				}
-			}
-			if (rc != 1) {
-				if (okc && nupd > 0 && nrm2(gp) > tolg) {   // retry from the same point with W0
-					nupd = 0;
-					std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
-					d = gp;
-					continue;
+				if (!okc) break;
+				if (rc != 1) {
+					if (nupd > 0 && nrm2(gp) > tolg) {   // retry from the same point with W0
+						nupd = 0;
+						std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
+						d = gp;
+						continue;
+					}
+					if (nrm2(gp) <= tolg) inner = 0; else if (nrm2(gp) <= 1e3 * tolg) { inner = 0; weak = true; } else inner = 6;
+					at_x = false; break;
 				}
-				info = (okc && nrm2(gp) <= tolg) ? 0 : 6; break;
+				alpha = ls.a;
+				for (int i = 0; i < n; i++) { sv[i] = alpha * p[i]; y[i] = gpn[i] - gp[i]; }
+				x = xt;
+				for (int i = 0; i < n; i++) { double a = 0; for (int j = 0; j < n; j++) a += W[(size_t)i * n + j] * gpn[j]; t[i] = a; }
+				for (int i = 0; i < n; i++) u[i] = t[i] - d[i];
+				const double sy = dot(sv, y);
+				if (sy > 1e-12 * nrm2(sv) * nrm2(y)) {
+					const double rho = 1.0 / sy, c2 = rho * (1.0 + rho * dot(y, u));
+					for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) W[(size_t)i * n + j] += -rho * (sv[i] * u[j] + u[i] * sv[j]) + c2 * sv[i] * sv[j];
+					nupd++;
+					const double a1 = dot(sv, gpn), a2 = dot(u, gpn);
+					for (int i = 0; i < n; i++) d[i] = t[i] - rho * (sv[i] * a2 + u[i] * a1) + c2 * sv[i] * a1;
+				} else d = t;
+				F = Fn; Fp = Fpn; gnf = gnfn; rv = rvn; g = gn; gp = gpn;
+				if (g_opt.print_level >= 5) printf("  maj %3d  F=%.15g |Zg|=%.3e alpha=%.3e nf=%d rv=%.2e mu=%g\n", iter, F, nrm2(gp), alpha, ls.nfev, rv, mu);
+				iter++;
+				if (alpha * pnorm <= sri * (1.0 + nrm2(x)) && nrm2(gp) <= sri * (1.0 + std::max(1.0 + std::fabs(F), gnf))) { inner = 0; break; }
 			}
-			alpha = ls.a;
-			for (int i = 0; i < n; i++) { sv[i] = alpha * p[i]; y[i] = gpn[i] - gp[i]; }
-			x = xt;
-			for (int i = 0; i < n; i++) { double a = 0; for (int j = 0; j < n; j++) a += W[(size_t)i * n + j] * gpn[j]; t[i] = a; }
-			for (int i = 0; i < n; i++) u[i] = t[i] - d[i];
-			const double sy = dot(sv, y);
-			if (sy > 1e-12 * nrm2(sv) * nrm2(y)) {
-				const double rho = 1.0 / sy, c2 = rho * (1.0 + rho * dot(y, u));
-				for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) W[(size_t)i * n + j] += -rho * (sv[i] * u[j] + u[i] * sv[j]) + c2 * sv[i] * sv[j];
-				nupd++;
-				const double a1 = dot(sv, gpn), a2 = dot(u, gpn);
-				for (int i = 0; i < n; i++) d[i] = t[i] - rho * (sv[i] * a2 + u[i] * a1) + c2 * sv[i] * a1;
-			} else d = t;
-			F = Fn; g = gn; gp = gpn;
-			if (g_opt.print_level >= 5) printf("  maj %3d  F=%.15g |Zg|=%.3e alpha=%.3e nf=%d\n", iter, F, nrm2(gp), alpha, ls.nfev);
-			iter++;
-			if (alpha * pnorm <= sr * (1.0 + nrm2(x)) && nrm2(gp) <= sr * (1.0 + std::max(1.0 + std::fabs(F), nrm2(g)))) { info = 0; break; }
+			if (!okc) break;
+			if (nc == 0) { info = (inner == 0 && weak) ? 1 : inner; break; }
+			if (!at_x) { F = al_eval(x, g, rv, gnf, Fp); if (!okc) break; }
+			if (inner == 6) { info = 6; break; }
+			if (rv <= 1e-8 && sri <= sr && inner == 0) { allam = tnew; info = weak ? 1 : 0; break; }
+			if (stop) { info = 4; break; }
+			if (rv <= 0.25 * rvprev) { allam = tnew; rvprev = rv; }
+			else mu *= 10.0;
+			if (outer == 29) info = 3;
 		}
 		if (!okc) info = 9;
+		if (nc > 0 && okc) make_feasible();                           // undo rounding drift off A x = b
+		F = Fp;                                                       // objective without the penalty terms
 		std::copy(x.begin(), x.end(), initialguess);                 // ntg.c:109: solution overwrites the guess
 	}
 	*inform = info; *objective = F;
-	if (clambda) { std::fill(clambda, clambda + ntot, 0.0); for (int i = 0; i < m && info != 9; i++) clambda[n + i] = lam[i]; }
+	if (clambda) {
+		std::fill(clambda, clambda + ntot, 0.0);
+		for (int i = 0; i < m && info != 9; i++) clambda[n + i] = lam[i];
+		for (int j = 0; j < nc && info != 9; j++) clambda[n + m + j] = -allam[j];   // NPSOL sign: grad F = A' lam_lin + J' lam_nl
+	}
 	if (istate) { std::fill(istate, istate + ntot, 0); for (int i = 0; i < m; i++) istate[n + i] = 3; }
 	if (R && info != 9) { // R'R = W^-1 (upper triangular, ld = n, column-major like NPSOL's R)
 		std::vector<double> Wc = W, H((size_t)n * n, 0.0), col(n);

@@ -307,7 +307,7 @@ static double al_eval(al_t *a, const double *x, double *g, double *rv_out, doubl
 			const double cc = cj < bl[j] ? bl[j] : (cj > bu[j] ? bu[j] : cj);
 			const double tj = a->mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
 			a->tnew[j] = tj;
-			pen += (tj * tj - a->lam[j] * a->lam[j]) / (2.0 * a->mu);
+			pen += (tj - a->lam[j]) * (tj + a->lam[j]) / (2.0 * a->mu);   /* factored: no cancellation when c is tiny */
 			rv2 += rj * rj;
 		}
 		F += pen;
@@ -326,6 +326,7 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	double r = o->opttol > 0 ? o->opttol : pow(DBL_EPSILON, 0.8), sr = sqrt(r), ftol = 1e-8;
 	double *W, *W0 = NULL, *g, *gp, *gn, *gpn, *d, *pdir, *xt, *s, *y, *u, *t, *lam;
 	double F = 0, Fn = 0, alpha = 0, pnorm = 0, gnf = 0, gnfn = 0, rv = 0, rvn = 0, rv_prev = HUGE_VAL;
+	int weak = 0;
 	proj_t pj;
 	ls_t ls;
 	al_t al;
@@ -366,6 +367,7 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 		/* inner tolerance: NPSOL's for the last passes, looser while the constraints are far off */
 		const double sri = nc > 0 ? fmax(sr, fmin(1e-3, 0.1 * rv_prev)) : sr;
 		int inner_inform = 4, stop = 0, at_x = 1, nupd = 0;
+		weak = 0;
 		if (outer > 0 && m > 0) {
 			/* steps stay in null(A) only to rounding; hundreds of majors per pass can drift: re-apply
 			 * x += A'(AA')^-1 (b - A x) before every further pass */
@@ -428,7 +430,13 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 					for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
 					continue;
 				}
-				inner_inform = (nrm2_(gp, n) <= tolg) ? 0 : 6; at_x = 0; break;
+				/* no further decrease obtainable along a descent direction: converged if the projected gradient
+				 * meets the tolerance, "optimal but not to the requested accuracy" (NPSOL inform 1) if it is
+				 * within 10^3 of it (function values at rounding level), failure (6) otherwise */
+				if (nrm2_(gp, n) <= tolg) inner_inform = 0;
+				else if (nrm2_(gp, n) <= 1e3 * tolg) { inner_inform = 0; weak = 1; }
+				else inner_inform = 6;
+				at_x = 0; break;
 			}
 			alpha = ls.a;
 			for (i = 0; i < n; i++) { s[i] = alpha * pdir[i]; y[i] = gpn[i] - gp[i]; }
@@ -458,16 +466,22 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			    alpha * pnorm <= sri * (1.0 + nrm2_(x, n)) &&
 			    nrm2_(gp, n) <= sri * (1.0 + fmax(1.0 + fabs(F), gnf))) { inner_inform = 0; break; }
 		}
-		if (nc == 0) { inform = inner_inform; break; }
+		if (nc == 0) { inform = (inner_inform == 0 && weak) ? 1 : inner_inform; break; }
 		/* ---- multiplier / penalty update from the constraint values AT x: if the inner solve ended on a
 		 *      rejected line-search trial, the last evaluation was elsewhere -> evaluate once more at x ---- */
 		if (!at_x) { F = al_eval(&al, x, g, &rv, &gnf); at_x = 1; }
 		if (inner_inform == 6) { inform = 6; break; }
-		if (rv <= ftol && sri <= sr && inner_inform == 0) { memcpy(al.lam, al.tnew, nc * sizeof(double)); inform = 0; break; }
+		if (rv <= ftol && sri <= sr && inner_inform == 0) { memcpy(al.lam, al.tnew, nc * sizeof(double)); inform = weak ? 1 : 0; break; }
 		if (stop) { inform = 4; break; }
 		if (rv <= 0.25 * rv_prev) { memcpy(al.lam, al.tnew, nc * sizeof(double)); rv_prev = rv; }
 		else al.mu *= 10.0;
 		if (outer == 29) inform = 3;   /* nonlinear constraints not satisfied to tolerance */
+	}
+	if (nc > 0 && m > 0 && inform != 9) {
+		/* many hundreds of majors under a large penalty let x drift off A x = b by rounding: restore it */
+		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(p->A, m, i, j) * x[j]; pj.tmpm[i] = p->bl[n + i] - sum; }
+		chol_solve_(pj.S, m, pj.tmpm);
+		for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(p->A, m, i, j) * pj.tmpm[i]; x[j] += sum; }
 	}
 done:
 	res->inform = inform; res->iters = iter; res->nfev = al.nfev;

@@ -4,7 +4,9 @@
  * The problem DATA are those of examples/vanderpol.c:17-21,160-169 and
  * examples/kincar.c:133-137,319-339 (sizes, orders, boundary values); the callbacks are
  * written here from the problem statements (vanderpol.txt; kincar cost = xdd^2 + ydd^2).
- * Usage: dropin_drv vanderpol|kincar   -> prints "RESULT inform objective c0 c1 ..."
+ * "obstacle": the kincar lane change with order-6 splines on 10 intervals and the nonlinear trajectory
+ * inequality (x-20)^2 + (y-0.5)^2 >= 9 (host callback) -- exercises the nonlinear-constraint path of ntg().
+ * Usage: dropin_drv vanderpol|kincar|obstacle   -> prints "RESULT inform objective c0 c1 ..."
  */
 #include <math.h>
 #include "ntg.h"
@@ -23,13 +25,22 @@ static void car_cost(int *mode, int *nstate, int *i, double *f, double *df, doub
 	if (*mode == 1 || *mode == 2) { df[0] = df[1] = df[3] = df[4] = 0; df[2] = 2 * zp[0][2]; df[5] = 2 * zp[1][2]; }
 }
 
+static void obs_con(int *mode, int *nstate, int *i, double *c, double **dc, double **zp)
+{
+	double dx = zp[0][0] - 20.0, dy = zp[1][0] - 0.5; int v; (void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) c[0] = dx * dx + dy * dy;
+	if (*mode == 1 || *mode == 2) { for (v = 0; v < 6; v++) dc[0][v] = 0; dc[0][0] = 2 * dx; dc[0][3] = 2 * dy; }
+}
+static int g_obstacle = 0;
+
 static int run(int nout, int order_, int mult_, int ninterv_, int nbps, int nlic, double **lic, int nlfc, double **lfc,
                double *lowerb, double *upperb, void (*ucf)(int *, int *, int *, double *, double *, double **),
                int ntav, AV *tav)
 {
 	int order[2] = {order_, order_}, mult[2] = {mult_, mult_}, nint[2] = {ninterv_, ninterv_}, md[2] = {3, 3};
 	double *knots[2], *bps = calloc(nbps, sizeof(double));
-	int ncoef = nout * (ninterv_ * (order_ - mult_) + mult_), nc = nlic + nlfc, i, inform;
+	int ncoef = nout * (ninterv_ * (order_ - mult_) + mult_), nc = nlic + nlfc + (g_obstacle ? nbps : 0), i, inform;
+	static AV ctav[2] = {{0, 0}, {1, 0}};
 	double *coef = calloc(ncoef, sizeof(double)), objective;
 	int *istate = calloc(ncoef + nc, sizeof(int));
 	double *clambda = calloc(ncoef + nc, sizeof(double)), *R = calloc((ncoef + 1) * (ncoef + 1), sizeof(double));
@@ -38,8 +49,10 @@ static int run(int nout, int order_, int mult_, int ninterv_, int nbps, int nlic
 	linspace(bps, 0, 5, nbps);
 	npsoloption("nolist");
 	npsoloption("summary file = 0");
+	if (g_obstacle) npsoloption("print level 0");
 	ntg(nout, bps, nbps, nint, knots, order, mult, md, coef,
-	    nlic, lic, 0, NULL, nlfc, lfc, 0, NULL, 0, NULL, 0, NULL, 0, NULL, 0, NULL, 0, NULL,
+	    nlic, lic, 0, NULL, nlfc, lfc, 0, NULL, g_obstacle ? 1 : 0, g_obstacle ? obs_con : NULL, 0, NULL,
+	    0, NULL, g_obstacle ? 2 : 0, g_obstacle ? ctav : NULL, 0, NULL,
 	    lowerb, upperb, 0, NULL, 1, ucf, 0, NULL, 0, NULL, ntav, tav, 0, NULL,
 	    istate, clambda, R, &inform, &objective);
 	printf("RESULT %d %.17g", inform, objective);
@@ -69,9 +82,13 @@ int main(int argc, char **argv)
 	} else {
 		static AV tav[2] = {{0, 2}, {1, 2}};
 		Matrix *lic = MakeMatrix(6, 6), *lfc = MakeMatrix(6, 6);
-		double lo[12], up[12], zi[6] = {0, 8, 0, -2, 0, 0}, zf[6] = {40, 8, 0, 2, 0, 0};
+		double lo[13], up[13], zi[6] = {0, 8, 0, -2, 0, 0}, zf[6] = {40, 8, 0, 2, 0, 0};
 		int i;
 		for (i = 0; i < 6; i++) { lic->elements[i][i] = 1.0; lfc->elements[i][i] = 1.0; lo[i] = up[i] = zi[i]; lo[6 + i] = up[6 + i] = zf[i]; }
+		if (argc > 1 && !strcmp(argv[1], "obstacle")) {
+			g_obstacle = 1; lo[12] = 9.0; up[12] = 1e20;
+			return run(2, 6, 3, 10, 51, 6, lic->elements, 6, lfc->elements, lo, up, car_cost, 2, tav);
+		}
 		return run(2, 5, 3, 2, 20, 6, lic->elements, 6, lfc->elements, lo, up, car_cost, 2, tav);
 	}
 }

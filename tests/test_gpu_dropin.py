@@ -79,3 +79,23 @@ def test_exported_callbacks_all_slots_vs_oracle(tmp_path):
     assert np.abs(J - ref["cJac"][0]).max() <= tol(ref["cJac"])
     assert int(L["INFORM"][0]) == 9                               # loud, not wrong
     assert int(L["BADMODE"][0]) == -1                              # unknown mode: nstate = -1 (ntg.c:332-333)
+
+
+def test_obstacle_dropin_nonlinear_inequality(drv):
+    """ntg() with a HOST nonlinear trajectory inequality callback: augmented-Lagrangian path of the drop-in
+    against the oracle solving the same problem (family 3 == the driver's callback)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from ntg_amd import configs as cf
+    inform, obj, coef, interp, istate = run(drv, "obstacle")
+    spec = cf.config_O(10)
+    zi = cf.kincar_flat_forward([0.0, -2.0, 0.0], [8.0, 0.0]).ravel(); zf = cf.kincar_flat_forward([40.0, 2.0, 0.0], [8.0, 0.0]).ravel()
+    lo = np.concatenate([zi, zf, [9.0]]); up = np.concatenate([zi, zf, [1e20]])
+    ref = orc.solve_one(spec, lo, up, np.ones(spec.nC))
+    assert inform == 0 and ref["inform"] == 0
+    assert abs(obj - ref["objective"]) <= 1e-6 * abs(ref["objective"])
+    assert np.abs(coef - ref["x"]).max() <= 1e-4 * np.abs(ref["x"]).max()
+    c = orc.eval_batch(spec, coef[None], 0)["c"][0]
+    assert c.min() >= 9.0 * (1 - 1e-7)                             # stays outside the obstacle
+    assert obj > 2.457581141950512                                 # and pays for it relative to the free lane change
