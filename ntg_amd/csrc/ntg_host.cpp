@@ -332,7 +332,7 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 	std::vector<double> x(initialguess, initialguess + n);
 	int info = 4, iter = 0, nstate = 1;
 	double F = 0.0;
-	std::vector<double> lam(m, 0.0), W((size_t)n * n, 0.0);
+	std::vector<double> W((size_t)n * n, 0.0);
 	// expanded bounds (constraints.c:5-33) for the linear rows
 	std::vector<double> bl(m), bu(m);
 	for (int r = 0; r < m; r++) {
@@ -341,34 +341,37 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 		bl[r] = lowerb[si]; bu[r] = upperb[si];
 	}
 	const int nc = D.ncnln;
-	bool supported = hp.plan->lin_ok;
-	for (int r = 0; r < m; r++) if (bl[r] != bu[r]) supported = false;
-	std::vector<double> allam(nc, 0.0);          // augmented-Lagrangian multipliers of the nonlinear rows
-	std::vector<double> cval(nc, 0.0);
-	if (!supported) {
-		fprintf(stderr, "ntg (MI355X): linear INEQUALITY rows (lower != upper) are not solved by this build (inform 9);\n"
-		                "              npsolCostFunction/npsolConstraintFunction remain usable with an external SQP driver\n");
-		info = 9;
-	} else {
-		const std::vector<double> &A = hp.plan->h_Adense;            // row-major m x n
-		std::vector<double> S((size_t)m * m, 0.0);
-		for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) { double a = 0; for (int c = 0; c < n; c++) a += A[(size_t)i * n + c] * A[(size_t)j * n + c]; S[(size_t)i * m + j] = a; }
-		if (m) chol_lower(S, m);
+	// linear rows with lower == upper are kept satisfied by projection (E); the others (I) join the nonlinear rows
+	// in the augmented Lagrangian as constraints with a constant Jacobian row
+	std::vector<int> erow, irow;
+	for (int r = 0; r < m; r++) (bl[r] == bu[r] ? erow : irow).push_back(r);
+	const int mE = (int)erow.size(), nI = (int)irow.size(), nal = nc + nI;
+	std::vector<double> allam(nal, 0.0);         // augmented-Lagrangian multipliers: nonlinear rows, then rows I
+	std::vector<double> cval(nal, 0.0);
+	std::vector<double> lamE(mE, 0.0);
+	{
+		const std::vector<double> &A = hp.plan->h_Adense;            // row-major m x n, all linear rows
+		std::vector<double> AE((size_t)mE * n), bE(mE);
+		for (int i = 0; i < mE; i++) { bE[i] = bl[erow[i]]; std::copy(&A[(size_t)erow[i] * n], &A[(size_t)erow[i] * n] + n, &AE[(size_t)i * n]); }
+		std::vector<double> S((size_t)mE * mE, 0.0);
+		for (int i = 0; i < mE; i++) for (int j = 0; j < mE; j++) { double a = 0; for (int c = 0; c < n; c++) a += AE[(size_t)i * n + c] * AE[(size_t)j * n + c]; S[(size_t)i * mE + j] = a; }
+		bool lin_ok = mE == 0 || chol_lower(S, mE);
+		if (!lin_ok) fprintf(stderr, "ntg (MI355X): the linear equality rows are rank deficient (inform 9)\n");
 		auto project = [&](const std::vector<double> &g, std::vector<double> &gp) {
 			gp = g;
-			if (!m) return;
-			for (int i = 0; i < m; i++) { double a = 0; for (int c = 0; c < n; c++) a += A[(size_t)i * n + c] * g[c]; lam[i] = a; }
-			chol_solve(S, m, lam.data());
-			for (int c = 0; c < n; c++) { double a = 0; for (int i = 0; i < m; i++) a += A[(size_t)i * n + c] * lam[i]; gp[c] -= a; }
+			if (!mE) return;
+			for (int i = 0; i < mE; i++) { double a = 0; for (int c = 0; c < n; c++) a += AE[(size_t)i * n + c] * g[c]; lamE[i] = a; }
+			chol_solve(S, mE, lamE.data());
+			for (int c = 0; c < n; c++) { double a = 0; for (int i = 0; i < mE; i++) a += AE[(size_t)i * n + c] * lamE[i]; gp[c] -= a; }
 		};
 		auto make_feasible = [&]() { // linear feasibility phase
-			if (!m) return;
-			std::vector<double> r(m);
-			for (int i = 0; i < m; i++) { double a = 0; for (int c = 0; c < n; c++) a += A[(size_t)i * n + c] * x[c]; r[i] = bl[i] - a; }
-			chol_solve(S, m, r.data());
-			for (int c = 0; c < n; c++) { double a = 0; for (int i = 0; i < m; i++) a += A[(size_t)i * n + c] * r[i]; x[c] += a; }
+			if (!mE) return;
+			std::vector<double> r(mE);
+			for (int i = 0; i < mE; i++) { double a = 0; for (int c = 0; c < n; c++) a += AE[(size_t)i * n + c] * x[c]; r[i] = bE[i] - a; }
+			chol_solve(S, mE, r.data());
+			for (int c = 0; c < n; c++) { double a = 0; for (int i = 0; i < mE; i++) a += AE[(size_t)i * n + c] * r[i]; x[c] += a; }
 		};
-		make_feasible();
+		if (lin_ok) make_feasible();
 		const ntg_solve_opts &o = g_opt.o;
 		const int itlim = o.itlim > 0 ? o.itlim : std::max(50, 3 * (n + m) + 10 * nc);
 		const double sr = std::sqrt(o.opttol > 0 ? o.opttol : std::pow(DBL_EPSILON, 0.8));
@@ -382,7 +385,8 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 				nbl[r] = lowerb[si]; nbu[r] = upperb[si];
 			}
 		}
-		std::vector<double> tnew(nc, 0.0), J((size_t)nc * n, 0.0);
+		std::vector<double> tnew(nal, 0.0), J((size_t)std::max(nc, 1) * n, 0.0);
+		for (int j = 0; j < nI; j++) { nbl.push_back(bl[irow[j]]); nbu.push_back(bu[irow[j]]); }
 		double mu = 10.0, Fp = 0.0;
 		bool okc = true;
 		// F_A = F + sum (t^2 - lam^2)/(2 mu), grad = g + J't  (DESIGN.md section 4b); rv = relative violation
@@ -391,17 +395,19 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 			if (!host_funobj(hp, 2, xx.data(), &Fv, gg.data(), &nstate)) { okc = false; return 0.0; }
 			nstate = 0;
 			gnf = nrm2(gg); Fpure = Fv; rv = 0.0;
-			if (nc > 0) {
-				if (!host_funcon(hp, 2, xx.data(), cval.data(), J.data(), nc, &nstate)) { okc = false; return 0.0; }
+			if (nc > 0 && !host_funcon(hp, 2, xx.data(), cval.data(), J.data(), nc, &nstate)) { okc = false; return 0.0; }
+			for (int j = 0; j < nI; j++) { double a = 0.0; const double *row = &A[(size_t)irow[j] * n]; for (int c = 0; c < n; c++) a += row[c] * xx[c]; cval[nc + j] = a; }
+			if (nal > 0) {
 				double pen = 0.0, rv2 = 0.0;
-				for (int j = 0; j < nc; j++) {
+				for (int j = 0; j < nal; j++) {
 					const double cj = cval[j], v = cj + allam[j] / mu;
 					const double pj = v < nbl[j] ? nbl[j] : (v > nbu[j] ? nbu[j] : v), cc = cj < nbl[j] ? nbl[j] : (cj > nbu[j] ? nbu[j] : cj);
 					const double tj = mu * (v - pj), rj = (cj - cc) / (1.0 + std::fabs(cj));
 					tnew[j] = tj; pen += (tj - allam[j]) * (tj + allam[j]) / (2.0 * mu); rv2 += rj * rj;
 				}
 				Fv += pen;
-				for (int c = 0; c < n; c++) { double a = 0.0; for (int j = 0; j < nc; j++) a += J[(size_t)c * nc + j] * tnew[j]; gg[c] += a; }
+				if (nc > 0) for (int c = 0; c < n; c++) { double a = 0.0; for (int j = 0; j < nc; j++) a += J[(size_t)c * nc + j] * tnew[j]; gg[c] += a; }
+				for (int j = 0; j < nI; j++) { const double *row = &A[(size_t)irow[j] * n]; for (int c = 0; c < n; c++) gg[c] += row[c] * tnew[nc + j]; }
 				rv = std::sqrt(rv2);
 			}
 			return Fv;
@@ -409,8 +415,9 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 		std::vector<double> g(n), gp(n), gn(n), gpn(n), d(n), p(n), xt(n), sv(n), y(n), u(n), t(n);
 		double alpha = 0, pnorm = 0, gnf = 0, gnfn = 0, rv = 0, rvn = 0, rvprev = HUGE_VAL, Fpn = 0;
 		LineSearch ls;
-		for (int outer = 0; okc && outer < (nc > 0 ? 30 : 1); outer++) {
-			const double sri = nc > 0 ? std::max(sr, std::min(1e-3, 0.1 * rvprev)) : sr;
+		if (!lin_ok) { okc = true; info = 9; }
+		for (int outer = 0; lin_ok && okc && outer < (nal > 0 ? 30 : 1); outer++) {
+			const double sri = nal > 0 ? std::max(sr, std::min(1e-3, 0.1 * rvprev)) : sr;
 			int inner = 4, nupd = 0; bool stop = false, at_x = true, weak = false;
 			if (outer > 0) make_feasible();
 			std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
@@ -481,7 +488,7 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 				if (alpha * pnorm <= sri * (1.0 + nrm2(x)) && nrm2(gp) <= sri * (1.0 + std::max(1.0 + std::fabs(F), gnf))) { inner = 0; break; }
 			}
 			if (!okc) break;
-			if (nc == 0) { info = (inner == 0 && weak) ? 1 : inner; break; }
+			if (nal == 0) { info = (inner == 0 && weak) ? 1 : inner; break; }
 			if (!at_x) { F = al_eval(x, g, rv, gnf, Fp); if (!okc) break; }
 			if (inner == 6) { info = 6; break; }
 			if (rv <= 1e-8 && sri <= sr && inner == 0) { allam = tnew; info = weak ? 1 : 0; break; }
@@ -491,17 +498,32 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 			if (outer == 29) info = 3;
 		}
 		if (!okc) info = 9;
-		if (nc > 0 && okc) make_feasible();                           // undo rounding drift off A x = b
+		if (nal > 0 && okc && lin_ok) make_feasible();                // undo rounding drift off A x = b
 		F = Fp;                                                       // objective without the penalty terms
 		std::copy(x.begin(), x.end(), initialguess);                 // ntg.c:109: solution overwrites the guess
 	}
 	*inform = info; *objective = F;
-	if (clambda) {
+	if (clambda) {   // NPSOL sign: grad F = A' lam_lin + J' lam_nl
 		std::fill(clambda, clambda + ntot, 0.0);
-		for (int i = 0; i < m && info != 9; i++) clambda[n + i] = lam[i];
-		for (int j = 0; j < nc && info != 9; j++) clambda[n + m + j] = -allam[j];   // NPSOL sign: grad F = A' lam_lin + J' lam_nl
+		for (int i = 0; i < mE && info != 9; i++) clambda[n + erow[i]] = lamE[i];
+		for (int j = 0; j < nI && info != 9; j++) clambda[n + irow[j]] = -allam[nc + j];
+		for (int j = 0; j < nc && info != 9; j++) clambda[n + m + j] = -allam[j];
 	}
-	if (istate) { std::fill(istate, istate + ntot, 0); for (int i = 0; i < m; i++) istate[n + i] = 3; }
+	if (istate) {   // 3 equality, 1/2 at lower/upper bound, 0 inactive (NPSOL's istate codes)
+		std::fill(istate, istate + ntot, 0);
+		for (int i = 0; i < mE; i++) istate[n + erow[i]] = 3;
+		for (int j = 0; j < nal && info != 9; j++) {
+			const int slot = j < nc ? n + m + j : n + irow[j - nc];
+			int si2;
+			double lo2, up2;
+			if (j < nc) {
+				const int b0 = nlic + nltc + nlfc;
+				if (j < nnlic) si2 = b0 + j; else if (j < nnlic + nnltc * nbps) si2 = b0 + nnlic + (j - nnlic) / nbps; else si2 = b0 + nnlic + nnltc + (j - nnlic - nnltc * nbps);
+				lo2 = lowerb[si2]; up2 = upperb[si2];
+			} else { lo2 = bl[irow[j - nc]]; up2 = bu[irow[j - nc]]; }
+			istate[slot] = (lo2 == up2) ? 3 : (allam[j] != 0.0 ? (std::fabs(cval[j] - lo2) <= std::fabs(cval[j] - up2) ? 1 : 2) : 0);
+		}
+	}
 	if (R && info != 9) { // R'R = W^-1 (upper triangular, ld = n, column-major like NPSOL's R)
 		std::vector<double> Wc = W, H((size_t)n * n, 0.0), col(n);
 		if (chol_lower(Wc, n)) {

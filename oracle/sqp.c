@@ -202,10 +202,10 @@ static void qr_full_q(const double *A, int m, int n, double *Q)
 	free(R); free(v);
 }
 /* returns 0 and fills W0 (n x n) on success */
-static int build_colloc_W0(const orc_problem *p, double *W0)
+static int build_colloc_W0(const orc_problem *p, const double *AE, int m, double *W0)
 {
 	const orc_colloc *cc = p->cc;
-	int n = cc->nC, m = p->nclin, nr = n - m, i, j, k, P = cc->nbps, rc;
+	int n = cc->nC, nr = n - m, i, j, k, P = cc->nbps, rc;
 	double *H0 = calloc((size_t)n * n, sizeof(double)), *Q, *Hr, *T, tr = 0.0;
 	if (nr <= 0) { free(H0); return 1; }
 	for (i = 0; i < P; i++) {   /* trapezoid weight of breakpoint i */
@@ -217,7 +217,7 @@ static int build_colloc_W0(const orc_problem *p, double *W0)
 	if (p->nicf) add_av_terms(H0, n, cc, p->icostav, p->nicostav, 0, 1.0);
 	if (p->nfcf) add_av_terms(H0, n, cc, p->fcostav, p->nfcostav, P - 1, 1.0);
 	Q = malloc((size_t)n * n * sizeof(double));
-	if (m > 0) qr_full_q(p->A, m, n, Q);
+	if (m > 0) qr_full_q(AE, m, n, Q);
 	else { memset(Q, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(Q, n, i, i) = 1.0; }
 	/* Z = Q[:, m:],  T = H0 Z (n x nr),  Hr = Z' T */
 	T = malloc((size_t)n * nr * sizeof(double)); Hr = malloc((size_t)nr * nr * sizeof(double));
@@ -264,14 +264,14 @@ static int build_colloc_W0(const orc_problem *p, double *W0)
 
 /* ---------------- the solver ---------------- */
 typedef struct {
-	orc_problem *p; int n, m;
+	const double *A; int n, m;   /* A: the EQUALITY rows, m x n column-major */
 	double *S;   /* chol(A A') lower, m x m */
 	double *tmpm;
 } proj_t;
 static void project(const proj_t *pj, const double *g, double *gp, double *lam_out)
 {
 	int n = pj->n, m = pj->m, i, j;
-	const double *A = pj->p->A;
+	const double *A = pj->A;
 	memcpy(gp, g, n * sizeof(double));
 	if (m == 0) return;
 	for (i = 0; i < m; i++) { double s = 0.0; for (j = 0; j < n; j++) s += M_(A, m, i, j) * g[j]; pj->tmpm[i] = s; }
@@ -287,33 +287,45 @@ static void project(const proj_t *pj, const double *g, double *gp, double *lam_o
  * Also returns the relative violation  rv = sqrt( sum_j ((c_j - clamp(c_j))/(1+|c_j|))^2 ). */
 typedef struct {
 	orc_problem *p; int n, nc; double mu; double *lam, *tnew, *c; int nfev;
+	int nI; const int *irow;   /* linear INEQUALITY rows (indices into A): treated like constraints with a constant Jacobian */
 } al_t;
 static double al_eval(al_t *a, const double *x, double *g, double *rv_out, double *gnorm_f)
 {
 	orc_problem *p = a->p;
-	int mode = 2, nstate = 0, n = a->n, nc = a->nc, i, j;
-	double F;
+	int mode = 2, nstate = 0, n = a->n, nc = a->nc, nI = a->nI, i, j, m = p->nclin;
+	double F, rv2 = 0.0, pen = 0.0;
 	orc_funobj(p, &mode, x, &F, g, &nstate);
 	a->nfev++;
 	if (gnorm_f) *gnorm_f = nrm2_(g, n);
 	if (nc > 0) {
-		const double *bl = p->bl + n + p->nclin, *bu = p->bu + n + p->nclin;
-		double rv2 = 0.0, pen = 0.0;
 		mode = 2;
 		orc_funcon(p, &mode, x, a->c, NULL, &nstate);
-		for (j = 0; j < nc; j++) {
-			const double cj = a->c[j], v = cj + a->lam[j] / a->mu;
-			const double pj = v < bl[j] ? bl[j] : (v > bu[j] ? bu[j] : v);
-			const double cc = cj < bl[j] ? bl[j] : (cj > bu[j] ? bu[j] : cj);
+	}
+	for (j = 0; j < nc + nI; j++) {
+		/* nonlinear rows first, then the linear inequality rows (c = A_r x) */
+		double bl, bu, cj;
+		if (j < nc) { bl = p->bl[n + m + j]; bu = p->bu[n + m + j]; cj = a->c[j]; }
+		else {
+			const int r = a->irow[j - nc];
+			bl = p->bl[n + r]; bu = p->bu[n + r];
+			cj = 0.0; for (i = 0; i < n; i++) cj += M_(p->A, m, r, i) * x[i];
+			a->c[j] = cj;
+		}
+		{
+			const double v = cj + a->lam[j] / a->mu;
+			const double pj = v < bl ? bl : (v > bu ? bu : v);
+			const double cc = cj < bl ? bl : (cj > bu ? bu : cj);
 			const double tj = a->mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
 			a->tnew[j] = tj;
 			pen += (tj - a->lam[j]) * (tj + a->lam[j]) / (2.0 * a->mu);   /* factored: no cancellation when c is tiny */
 			rv2 += rj * rj;
 		}
-		F += pen;
+	}
+	F += pen;
+	if (nc > 0)
 		for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < nc; j++) sum += M_(p->cJac, nc, j, i) * a->tnew[j]; g[i] += sum; }
-		if (rv_out) *rv_out = sqrt(rv2);
-	} else if (rv_out) *rv_out = 0.0;
+	for (j = 0; j < nI; j++) { const int r = a->irow[j]; for (i = 0; i < n; i++) g[i] += M_(p->A, m, r, i) * a->tnew[nc + j]; }
+	if (rv_out) *rv_out = sqrt(rv2);
 	return F;
 }
 
@@ -321,8 +333,10 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
                    double *clambda, int *istate, double *R, double *trace, int trace_cap)
 {
 	const orc_colloc *cc = p->cc;
-	int n = cc->nC, m = p->nclin, nc = p->ncnln, i, j, iter = 0, inform = 4, outer;
-	int itlim = o->itlim > 0 ? o->itlim : (50 > 3 * (n + m) + 10 * nc ? 50 : 3 * (n + m) + 10 * nc);
+	int n = cc->nC, mall = p->nclin, m = 0, nI = 0, nc = p->ncnln, i, j, iter = 0, inform = 4, outer, nal;
+	int itlim = o->itlim > 0 ? o->itlim : (50 > 3 * (n + mall) + 10 * nc ? 50 : 3 * (n + mall) + 10 * nc);
+	int *erow = malloc((mall + 1) * sizeof(int)), *irow = malloc((mall + 1) * sizeof(int));
+	double *AE = NULL, *bE = NULL;
 	double r = o->opttol > 0 ? o->opttol : pow(DBL_EPSILON, 0.8), sr = sqrt(r), ftol = 1e-8;
 	double *W, *W0 = NULL, *g, *gp, *gn, *gpn, *d, *pdir, *xt, *s, *y, *u, *t, *lam;
 	double F = 0, Fn = 0, alpha = 0, pnorm = 0, gnf = 0, gnfn = 0, rv = 0, rvn = 0, rv_prev = HUGE_VAL;
@@ -332,48 +346,52 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	al_t al;
 
 	memset(res, 0, sizeof(*res));
-	/* scope: linear rows must be equalities (lower == upper); nonlinear rows may be anything */
-	for (i = 0; i < m; i++) if (p->bl[n + i] != p->bu[n + i]) { res->inform = 9; return; }
-	if (nc > 0 && o->fixed_iters) { res->inform = 9; return; }
+	/* linear rows with lower == upper are kept satisfied by projection; the others join the nonlinear rows
+	 * in the augmented Lagrangian */
+	for (i = 0; i < mall; i++) { if (p->bl[n + i] == p->bu[n + i]) erow[m++] = i; else irow[nI++] = i; }
+	nal = nc + nI;
+	if (nal > 0 && o->fixed_iters) { res->inform = 9; free(erow); free(irow); return; }
+	AE = malloc((size_t)(m + 1) * n * sizeof(double)); bE = malloc((m + 1) * sizeof(double));
+	for (i = 0; i < m; i++) { bE[i] = p->bl[n + erow[i]]; for (j = 0; j < n; j++) M_(AE, m, i, j) = M_(p->A, mall, erow[i], j); }
 
 	W = malloc((size_t)n * n * sizeof(double));
 	g = malloc(n * sizeof(double)); gp = malloc(n * sizeof(double)); gn = malloc(n * sizeof(double));
 	gpn = malloc(n * sizeof(double)); d = malloc(n * sizeof(double)); pdir = malloc(n * sizeof(double));
 	xt = malloc(n * sizeof(double)); s = malloc(n * sizeof(double)); y = malloc(n * sizeof(double));
 	u = malloc(n * sizeof(double)); t = malloc(n * sizeof(double)); lam = calloc(m + 1, sizeof(double));
-	pj.p = p; pj.n = n; pj.m = m; pj.S = NULL; pj.tmpm = malloc((m + 1) * sizeof(double));
-	al.p = p; al.n = n; al.nc = nc; al.mu = 10.0; al.nfev = 0;
-	al.lam = calloc(nc + 1, sizeof(double)); al.tnew = calloc(nc + 1, sizeof(double)); al.c = calloc(nc + 1, sizeof(double));
+	pj.A = AE; pj.n = n; pj.m = m; pj.S = NULL; pj.tmpm = malloc((m + 1) * sizeof(double));
+	al.p = p; al.n = n; al.nc = nc; al.mu = 10.0; al.nfev = 0; al.nI = nI; al.irow = irow;
+	al.lam = calloc(nal + 1, sizeof(double)); al.tnew = calloc(nal + 1, sizeof(double)); al.c = calloc(nal + 1, sizeof(double));
 	if (m > 0) {
 		pj.S = malloc((size_t)m * m * sizeof(double));
 		for (i = 0; i < m; i++) for (j = 0; j < m; j++) {
-			double sum = 0.0; int k; for (k = 0; k < n; k++) sum += M_(p->A, m, i, k) * M_(p->A, m, j, k);
+			double sum = 0.0; int k; for (k = 0; k < n; k++) sum += M_(AE, m, i, k) * M_(AE, m, j, k);
 			M_(pj.S, m, i, j) = sum;
 		}
 		if (chol_(pj.S, m)) { inform = 9; goto done; } /* rank-deficient A */
 		/* feasibility: x += A' (AA')^-1 (b - A x) */
-		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(p->A, m, i, j) * x[j]; pj.tmpm[i] = p->bl[n + i] - sum; }
+		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(AE, m, i, j) * x[j]; pj.tmpm[i] = bE[i] - sum; }
 		chol_solve_(pj.S, m, pj.tmpm);
-		for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(p->A, m, i, j) * pj.tmpm[i]; x[j] += sum; }
+		for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(AE, m, i, j) * pj.tmpm[i]; x[j] += sum; }
 	}
 	if (o->hessian == 1) {
 		W0 = malloc((size_t)n * n * sizeof(double));
-		if (build_colloc_W0(p, W0)) { free(W0); W0 = NULL; }
+		if (build_colloc_W0(p, AE, m, W0)) { free(W0); W0 = NULL; }
 	}
 
 	/* outer loop: one pass when there are no nonlinear constraints; otherwise the multiplier /
 	 * penalty iteration of the augmented Lagrangian (at most 30 passes) */
-	for (outer = 0; outer < (nc > 0 ? 30 : 1); outer++) {
+	for (outer = 0; outer < (nal > 0 ? 30 : 1); outer++) {
 		/* inner tolerance: NPSOL's for the last passes, looser while the constraints are far off */
-		const double sri = nc > 0 ? fmax(sr, fmin(1e-3, 0.1 * rv_prev)) : sr;
+		const double sri = nal > 0 ? fmax(sr, fmin(1e-3, 0.1 * rv_prev)) : sr;
 		int inner_inform = 4, stop = 0, at_x = 1, nupd = 0;
 		weak = 0;
 		if (outer > 0 && m > 0) {
 			/* steps stay in null(A) only to rounding; hundreds of majors per pass can drift: re-apply
 			 * x += A'(AA')^-1 (b - A x) before every further pass */
-			for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(p->A, m, i, j) * x[j]; pj.tmpm[i] = p->bl[n + i] - sum; }
+			for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(AE, m, i, j) * x[j]; pj.tmpm[i] = bE[i] - sum; }
 			chol_solve_(pj.S, m, pj.tmpm);
-			for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(p->A, m, i, j) * pj.tmpm[i]; x[j] += sum; }
+			for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(AE, m, i, j) * pj.tmpm[i]; x[j] += sum; }
 		}
 		if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
 		else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
@@ -466,43 +484,49 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			    alpha * pnorm <= sri * (1.0 + nrm2_(x, n)) &&
 			    nrm2_(gp, n) <= sri * (1.0 + fmax(1.0 + fabs(F), gnf))) { inner_inform = 0; break; }
 		}
-		if (nc == 0) { inform = (inner_inform == 0 && weak) ? 1 : inner_inform; break; }
+		if (nal == 0) { inform = (inner_inform == 0 && weak) ? 1 : inner_inform; break; }
 		/* ---- multiplier / penalty update from the constraint values AT x: if the inner solve ended on a
 		 *      rejected line-search trial, the last evaluation was elsewhere -> evaluate once more at x ---- */
 		if (!at_x) { F = al_eval(&al, x, g, &rv, &gnf); at_x = 1; }
 		if (inner_inform == 6) { inform = 6; break; }
-		if (rv <= ftol && sri <= sr && inner_inform == 0) { memcpy(al.lam, al.tnew, nc * sizeof(double)); inform = weak ? 1 : 0; break; }
+		if (rv <= ftol && sri <= sr && inner_inform == 0) { memcpy(al.lam, al.tnew, nal * sizeof(double)); inform = weak ? 1 : 0; break; }
 		if (stop) { inform = 4; break; }
-		if (rv <= 0.25 * rv_prev) { memcpy(al.lam, al.tnew, nc * sizeof(double)); rv_prev = rv; }
+		if (rv <= 0.25 * rv_prev) { memcpy(al.lam, al.tnew, nal * sizeof(double)); rv_prev = rv; }
 		else al.mu *= 10.0;
 		if (outer == 29) inform = 3;   /* nonlinear constraints not satisfied to tolerance */
 	}
-	if (nc > 0 && m > 0 && inform != 9) {
+	if (nal > 0 && m > 0 && inform != 9) {
 		/* many hundreds of majors under a large penalty let x drift off A x = b by rounding: restore it */
-		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(p->A, m, i, j) * x[j]; pj.tmpm[i] = p->bl[n + i] - sum; }
+		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(AE, m, i, j) * x[j]; pj.tmpm[i] = bE[i] - sum; }
 		chol_solve_(pj.S, m, pj.tmpm);
-		for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(p->A, m, i, j) * pj.tmpm[i]; x[j] += sum; }
+		for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(AE, m, i, j) * pj.tmpm[i]; x[j] += sum; }
 	}
 done:
 	res->inform = inform; res->iters = iter; res->nfev = al.nfev;
 	/* objective WITHOUT the penalty terms (what NPSOL reports) */
 	if (inform != 9) {
-		if (nc > 0) { int mode = 0, nstate = 0; orc_funobj(p, &mode, x, &F, NULL, &nstate); }
+		if (nal > 0) { int mode = 0, nstate = 0; orc_funobj(p, &mode, x, &F, NULL, &nstate); }
 		res->objective = F;
 	}
 	res->pg_norm = (inform == 9) ? 0.0 : nrm2_(gp, n);
-	{ /* linear feasibility (and relative nonlinear violation) */
+	{ /* linear feasibility of the equality rows (and relative violation of everything in the AL) */
 		double worst = 0.0;
-		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(p->A, m, i, j) * x[j]; worst = fmax(worst, fabs(sum - p->bl[n + i])); }
-		res->feas = fmax(worst, nc > 0 && inform != 9 ? rv : 0.0);
+		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(AE, m, i, j) * x[j]; worst = fmax(worst, fabs(sum - bE[i])); }
+		res->feas = fmax(worst, nal > 0 && inform != 9 ? rv : 0.0);
 	}
-	if (clambda) { for (i = 0; i < n; i++) clambda[i] = 0.0; for (i = 0; i < m; i++) clambda[n + i] = lam[i]; for (i = 0; i < nc; i++) clambda[n + m + i] = -al.lam[i]; /* NPSOL sign: grad F = A' lam_lin + J' lam_nl */ }
+	if (clambda) {
+		for (i = 0; i < n + mall + nc; i++) clambda[i] = 0.0;
+		for (i = 0; i < m; i++) clambda[n + erow[i]] = lam[i];
+		for (i = 0; i < nI; i++) clambda[n + irow[i]] = -al.lam[nc + i];
+		for (i = 0; i < nc; i++) clambda[n + mall + i] = -al.lam[i]; /* NPSOL sign: grad F = A' lam_lin + J' lam_nl */
+	}
 	if (istate) {
 		for (i = 0; i < n; i++) istate[i] = 0;
-		for (i = 0; i < m; i++) istate[n + i] = 3;
-		for (i = 0; i < nc; i++) {
-			const double bl = p->bl[n + m + i], bu = p->bu[n + m + i], cv = al.c[i];
-			istate[n + m + i] = (bl == bu) ? 3 : (al.lam[i] != 0.0 ? (fabs(cv - bl) <= fabs(cv - bu) ? 1 : 2) : 0);
+		for (i = 0; i < m; i++) istate[n + erow[i]] = 3;
+		for (i = 0; i < nal; i++) {
+			const int slot = i < nc ? n + mall + i : n + irow[i - nc];
+			const double bl = p->bl[slot], bu = p->bu[slot], cv = al.c[i];
+			istate[slot] = (bl == bu) ? 3 : (al.lam[i] != 0.0 ? (fabs(cv - bl) <= fabs(cv - bu) ? 1 : 2) : 0);
 		}
 	}
 	if (R && inform != 9) {
@@ -511,8 +535,8 @@ done:
 		memcpy(Hf, W, (size_t)n * n * sizeof(double));
 		if (W0 && m > 0) {
 			double *X = malloc((size_t)m * n * sizeof(double));
-			for (j = 0; j < n; j++) { for (i = 0; i < m; i++) M_(X, m, i, j) = M_(p->A, m, i, j); chol_solve_(pj.S, m, &M_(X, m, 0, j)); }
-			for (j = 0; j < n; j++) for (i = 0; i < n; i++) { double sum = 0.0; int k; for (k = 0; k < m; k++) sum += M_(p->A, m, k, i) * M_(X, m, k, j); M_(Hf, n, i, j) += sum; }
+			for (j = 0; j < n; j++) { for (i = 0; i < m; i++) M_(X, m, i, j) = M_(AE, m, i, j); chol_solve_(pj.S, m, &M_(X, m, 0, j)); }
+			for (j = 0; j < n; j++) for (i = 0; i < n; i++) { double sum = 0.0; int k; for (k = 0; k < m; k++) sum += M_(AE, m, k, i) * M_(X, m, k, j); M_(Hf, n, i, j) += sum; }
 			free(X);
 		}
 		if (!chol_(Hf, n)) {
@@ -528,5 +552,5 @@ done:
 	}
 	free(W); free(W0); free(g); free(gp); free(gn); free(gpn); free(d); free(pdir); free(xt);
 	free(s); free(y); free(u); free(t); free(lam); free(pj.S); free(pj.tmpm);
-	free(al.lam); free(al.tnew); free(al.c);
+	free(al.lam); free(al.tnew); free(al.c); free(erow); free(irow); free(AE); free(bE);
 }

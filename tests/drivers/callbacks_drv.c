@@ -103,7 +103,7 @@ int main(int argc, char **argv)
 		m = 7; npsolCostFunction(&m, &n, g_xtest, &F, g, &nstate); printf("BADMODE %d\n", nstate);
 	}
 	ntg_close();
-	/* the same problem through ntg(): inequality + nonlinear constraints are outside this build's solver */
+	/* the same problem through ntg(): linear inequality rows and nonlinear rows of all three kinds, bounds [-1, 1] */
 	npsoloption("print level 0");
 	ntg(NOUT, bps, nbps, nint, knots, order, mult, md, coef,
 	    nlic, lic, nltc, ltc, nlfc, lfc, 1, nlicf, 2, nltcf, 1, nlfcf, 2, icav, 4, tcav, 3, fcav,

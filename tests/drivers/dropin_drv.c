@@ -6,7 +6,8 @@
  * written here from the problem statements (vanderpol.txt; kincar cost = xdd^2 + ydd^2).
  * "obstacle": the kincar lane change with order-6 splines on 10 intervals and the nonlinear trajectory
  * inequality (x-20)^2 + (y-0.5)^2 >= 9 (host callback) -- exercises the nonlinear-constraint path of ntg().
- * Usage: dropin_drv vanderpol|kincar|obstacle   -> prints "RESULT inform objective c0 c1 ..."
+ * "ineq": the shipped kincar problem with two final-flag rows relaxed to ranges (linear inequality rows).
+ * Usage: dropin_drv vanderpol|kincar|obstacle|ineq   -> prints "RESULT inform objective c0 c1 ..."
  */
 #include <math.h>
 #include "ntg.h"
@@ -85,6 +86,10 @@ int main(int argc, char **argv)
 		double lo[13], up[13], zi[6] = {0, 8, 0, -2, 0, 0}, zf[6] = {40, 8, 0, 2, 0, 0};
 		int i;
 		for (i = 0; i < 6; i++) { lic->elements[i][i] = 1.0; lfc->elements[i][i] = 1.0; lo[i] = up[i] = zi[i]; lo[6 + i] = up[6 + i] = zf[i]; }
+		if (argc > 1 && !strcmp(argv[1], "ineq")) {   /* linear inequality rows: y(T) in [-1,1], y''(T) in [-0.5,0.5] */
+			lo[6 + 3] = -1.0; up[6 + 3] = 1.0; lo[6 + 5] = -0.5; up[6 + 5] = 0.5;
+			return run(2, 5, 3, 2, 20, 6, lic->elements, 6, lfc->elements, lo, up, car_cost, 2, tav);
+		}
 		if (argc > 1 && !strcmp(argv[1], "obstacle")) {
 			g_obstacle = 1; lo[12] = 9.0; up[12] = 1e20;
 			return run(2, 6, 3, 10, 51, 6, lic->elements, 6, lfc->elements, lo, up, car_cost, 2, tav);

@@ -98,13 +98,47 @@ def test_fixed_iteration_mode_and_limits():
 
 
 def test_unsupported_inputs_are_loud():
-    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
-    up2 = up.copy(); up2[0] += 1.0                         # a LINEAR inequality row: not in scope yet
-    r = orc.solve_one(spec, lo, up2, np.ones(spec.nC))
-    assert r["inform"] == 9
     O = cf.config_O(10); lo, up = cf.obstacle_bounds(1)
     r = orc.solve_one(O, lo[0], up[0], np.ones(O.nC), orc.default_opts(itlim=50, fixed_iters=1))
-    assert r["inform"] == 9                                # fixed-work mode is defined for ncnln == 0 only
+    assert r["inform"] == 9                                # fixed-work mode is defined without AL rows only
+
+
+def test_linear_inequality_rows_vs_scipy():
+    """Linear rows with lower < upper (here: final lateral position anywhere in [-1, 1], final heading rate in
+    [-0.5, 0.5]) join the augmented Lagrangian; the problem stays a convex QP, so scipy's SLSQP is an independent
+    reference for the optimum."""
+    import scipy.optimize as so
+    spec = cf.config_K0(); lo, up = cf.bounds_K0_shipped()
+    lo = lo.copy(); up = up.copy()
+    lo[6 + 3], up[6 + 3] = -1.0, 1.0          # y(T)   in [-1, 1]   (row of output 1, derivative 0)
+    lo[6 + 5], up[6 + 5] = -0.5, 0.5          # y''(T) in [-0.5, 0.5]
+    xs, fs = kkt_kincar(spec, cf.bounds_K0_shipped()[0])   # reuse H from the helper via a second call below
+    tab = orc.export_tables(spec)
+    A = tab["A"]
+    P = spec.nbps; w = np.zeros(P); dt = np.diff(spec.bps); w[:-1] += dt / 2; w[1:] += dt / 2
+    H = np.zeros((spec.nC, spec.nC)); pos = 0; base = 0
+    for o in range(2):
+        k, d, no = spec.order[o], 3, spec.ncoef[o]
+        blk = tab["blk"][pos:pos + P * k * d].reshape(P, k, d); pos += P * k * d
+        D2 = np.zeros((P, no))
+        for i in range(P):
+            D2[i, tab["off"][o, i]:tab["off"][o, i] + k] = blk[i, :, 2]
+        H[base:base + no, base:base + no] = 2 * D2.T @ (w[:, None] * D2); base += no
+    eq = [i for i in range(12) if lo[i] == up[i]]; iq = [i for i in range(12) if lo[i] != up[i]]
+    cons = [{"type": "eq", "fun": lambda x: A[eq] @ x - lo[eq], "jac": lambda x: A[eq]},
+            {"type": "ineq", "fun": lambda x: A[iq] @ x - lo[iq], "jac": lambda x: A[iq]},
+            {"type": "ineq", "fun": lambda x: up[iq] - A[iq] @ x, "jac": lambda x: -A[iq]}]
+    ref = so.minimize(lambda x: 0.5 * x @ H @ x, xs, jac=lambda x: H @ x, constraints=cons, method="SLSQP",
+                      options=dict(ftol=1e-15, maxiter=500))
+    for h in (0, 1):
+        r = orc.solve_one(spec, lo, up, np.ones(spec.nC), orc.default_opts(hessian=h))
+        assert r["inform"] in (0, 1)
+        assert abs(r["objective"] - ref.fun) <= 1e-7 * max(1.0, ref.fun)
+        assert np.abs(r["x"] - ref.x).max() <= 1e-5 * np.abs(ref.x).max()
+        Ax = A @ r["x"]
+        assert np.abs(Ax[eq] - lo[eq]).max() <= 1e-8 and (Ax[iq] >= lo[iq] - 1e-7).all() and (Ax[iq] <= up[iq] + 1e-7).all()
+        assert list(r["istate"][spec.nC + np.array(eq)]) == [3] * len(eq)
+    assert ref.fun < 2.457581141950512                     # relaxing the final flag can only lower the cost
 
 
 @pytest.mark.parametrize("hessian", [0, 1])
