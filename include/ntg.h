@@ -56,8 +56,8 @@ void SplineInterp(double *f, double x, double *knots, int ninterv, double *coeff
 
 /* reference ntg.h:72-99 (ntg.c:54-267).  Same argument meaning, ownership and outputs:
  * initialguess[nC] is in/out; istate/clambda have nC + nclin + ncnln entries; R >= nC*nC;
- * *inform uses NPSOL's codes (0 optimal, 4 iteration limit, 6 no further progress,
- * 9 invalid or unsupported input). */
+ * *inform uses NPSOL's codes (0 optimal, 1 optimal but not to the requested accuracy, 3 nonlinear
+ * constraints not satisfied, 4 iteration limit, 6 no further progress, 9 invalid input / no GPU). */
 void ntg(
 	int nout, double *bps, int nbps, int *kninterv, double **knots,
 	int *order, int *mult, int *max_deriv,
