@@ -44,6 +44,8 @@ extern "C" {
 #define NTG_FAM_VANDERPOL 1  /* examples/vanderpol.c:206-241 */
 #define NTG_FAM_TESTFAM 2    /* synthetic, all six callback slots */
 #define NTG_FAM_OBSTACLE 3   /* kincar cost + circular-obstacle trajectory constraint (x-20)^2+(y-0.5)^2 >= r^2 */
+#define NTG_FAM_QUADROTOR 4  /* 4 outputs x,y,z,yaw, maxderiv 5: snap^2 + yaw''^2; rows: thrust^2 = x''^2+y''^2+(z''+g)^2, speed^2 */
+#define NTG_FAM_MANIP 5      /* 3 joints per planar arm, maxderiv 3: sum q''^2; one tip-height row sin(qa)+sin(qa+qb)+sin(qa+qb+qc) per arm */
 #define NTG_FAM_HOST (-1)    /* host function pointers (ntg() drop-in path only) */
 
 typedef struct { int output; int deriv; } ntg_av; /* == AV of av.h:22-26 */

@@ -7,8 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libntg_amd.so")
-SOURCES = ["kernels.hip", "plan.cpp", "ntg_host.cpp"]
-HEADERS = ["ntg_dev.hpp", "families.hpp", "linesearch.hpp", "plan.hpp", "../../include/ntg_amd.h", "../../include/ntg.h"]
+SOURCES = ["kernels.hip", "fam_kincar.hip", "fam_vanderpol.hip", "fam_testfam.hip", "fam_obstacle.hip", "fam_quadrotor.hip",
+           "fam_manip.hip", "plan.cpp", "ntg_host.cpp"]
+HEADERS = ["ntg_dev.hpp", "solve_impl.hpp", "families.hpp", "linesearch.hpp", "plan.hpp", "../../include/ntg_amd.h", "../../include/ntg.h"]
 
 
 def _stale() -> bool:
@@ -22,18 +23,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for src in SOURCES:
+    objs, procs = [], []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, f)) for f in HEADERS if os.path.exists(os.path.join(CSRC, f)))
+    for src in SOURCES:   # one hipcc per translation unit, all at once (the family units are independent)
         path = os.path.join(CSRC, src)
-        if not os.path.exists(path):
-            continue
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), hdr_t):
+            continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", path, "-o", obj,
-               "-I", os.path.join(HERE, "..", "include"), "-Wno-unused-result", "-Wno-unused-value"]
+               "-I", os.path.join(HERE, "..", "include"), "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        log = open(obj + ".log", "w")
+        procs.append((src, obj, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
+    failed = []
+    for src, obj, pr, log in procs:
+        rc = pr.wait()
+        log.close()
+        if rc != 0:
+            failed.append(src)
+            sys.stderr.write(open(obj + ".log").read())
+    if failed:
+        raise RuntimeError("hipcc failed for " + ", ".join(failed))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 

@@ -5,10 +5,13 @@
   B   kincar 2 outputs, order 6, mult 3, 20 intervals, P = 5l+1 = 101
   M   headline: 6 flat outputs (three cars stacked), same splines
   T   testfam: every callback slot populated (exercises cost.c / constraints.c row orders)
+  O   kincar + circular obstacle (one nonlinear trajectory inequality)
+  D   quadrotor: 4 outputs, order 8, mult 4, 40 intervals, maxderiv 5, P = 201, 2 nonlinear trajectory rows
+  E   manipulator: 12 outputs, order 6, mult 3, 60 intervals, P = 301, 4 nonlinear trajectory inequalities
 """
 from __future__ import annotations
 import numpy as np
-from .spec import Spec, linspace_c, FAM_KINCAR, FAM_VANDERPOL, FAM_TESTFAM, FAM_OBSTACLE
+from .spec import Spec, linspace_c, FAM_KINCAR, FAM_VANDERPOL, FAM_TESTFAM, FAM_OBSTACLE, FAM_QUADROTOR, FAM_MANIP
 
 SEED = 20261003
 WHEELBASE = 3.0  # kincar.c:43
@@ -133,4 +136,79 @@ def obstacle_bounds(batch: int, radius: float = 3.0, seed: int = SEED):
     lo, up = kincar_random_bounds(1, batch, seed)
     lo = np.concatenate([lo, np.full((batch, 1), radius * radius)], axis=1)
     up = np.concatenate([up, np.full((batch, 1), INF_BOUND)], axis=1)
+    return lo, up
+
+
+QUAD_G = 9.81
+
+
+def config_D(ninterv: int = 40, order: int = 8, mult: int = 4, T: float = 5.0) -> Spec:
+    """Quadrotor flat outputs (x, y, z, yaw), family 4: snap^2 + yaw-acceleration^2 running cost, the whole flag
+    pinned at both ends (rest to rest), thrust^2 and speed^2 bounded at every breakpoint."""
+    nout, d = 4, 5
+    nz = nout * d
+    nbps = 5 * ninterv + 1
+    eye = np.eye(nz)
+    return Spec(
+        nout=nout, bps=linspace_c(0.0, T, nbps), kninterv=[ninterv] * nout,
+        knots=[linspace_c(0.0, T, ninterv + 1) for _ in range(nout)],
+        order=[order] * nout, mult=[mult] * nout, maxderiv=[d] * nout, family=FAM_QUADROTOR,
+        lic=eye.copy(), lfc=eye.copy(), ltc=np.zeros((0, nz)),
+        nnltc=2, tcav=[(0, 1), (1, 1), (2, 1), (0, 2), (1, 2), (2, 2)],
+        nucf=1, tcostav=[(0, 4), (1, 4), (2, 4), (3, 2)], name=f"D:quadrotor-4out-k{order}-l{ninterv}")
+
+
+def quadrotor_bounds(batch: int, vmax: float = 6.0, seed: int = SEED):
+    """Rest-to-rest flights: start p0, yaw0 -> p0 + U(8,22) m along a random direction, yaw0 + U(-1,1).
+    Rows: [lic (20); lfc (20); thrust^2 in [(0.5 g)^2, (1.8 g)^2]; speed^2 in (-inf, vmax^2]]."""
+    rng = np.random.default_rng(seed)
+    lo = np.zeros((batch, 42)); up = np.zeros((batch, 42))
+    for p in range(batch):
+        p0 = np.array([rng.uniform(-5, 5), rng.uniform(-5, 5), rng.uniform(2, 6)])
+        yaw0 = rng.uniform(-0.5, 0.5)
+        dirv = rng.normal(size=3); dirv[2] *= 0.3; dirv /= np.linalg.norm(dirv)
+        pf = p0 + dirv * rng.uniform(8, 22)
+        yawf = yaw0 + rng.uniform(-1, 1)
+        zi = np.zeros((4, 5)); zf = np.zeros((4, 5))
+        zi[:3, 0] = p0; zi[3, 0] = yaw0; zf[:3, 0] = pf; zf[3, 0] = yawf
+        lo[p, :20] = zi.ravel(); lo[p, 20:40] = zf.ravel()
+        up[p, :40] = lo[p, :40]
+        lo[p, 40] = (0.5 * QUAD_G) ** 2; up[p, 40] = (1.8 * QUAD_G) ** 2
+        lo[p, 41] = -INF_BOUND; up[p, 41] = vmax * vmax
+    return lo, up
+
+
+def config_E(ninterv: int = 60, order: int = 6, mult: int = 3, narms: int = 4, T: float = 5.0) -> Spec:
+    """narms planar 3-link arms (family 5): joint-acceleration^2 running cost, the whole flag pinned at both ends,
+    one tip-height ceiling (nonlinear inequality) per arm at every breakpoint."""
+    nout = 3 * narms
+    nz = 3 * nout
+    nbps = 5 * ninterv + 1
+    eye = np.eye(nz)
+    return Spec(
+        nout=nout, bps=linspace_c(0.0, T, nbps), kninterv=[ninterv] * nout,
+        knots=[linspace_c(0.0, T, ninterv + 1) for _ in range(nout)],
+        order=[order] * nout, mult=[mult] * nout, maxderiv=[3] * nout, family=FAM_MANIP,
+        lic=eye.copy(), lfc=eye.copy(), ltc=np.zeros((0, nz)),
+        nnltc=narms, tcav=[(o, 0) for o in range(nout)],
+        nucf=1, tcostav=[(o, 2) for o in range(nout)], name=f"E:manipulator-{nout}out-k{order}-l{ninterv}")
+
+
+def manipulator_bounds(batch: int, narms: int = 4, ceiling: float = 2.5, seed: int = SEED):
+    """Rest-to-rest swings of every arm from low on the right to low on the left (shoulder 0.1-0.5 -> 2.6-3.0 rad,
+    elbow and wrist bent 0.2-0.6 rad): the straight joint-space path lifts the tip to ~2.9, above the ceiling.
+    Rows: [lic (9 narms); lfc (9 narms); tip height of arm j in (-inf, ceiling]]."""
+    rng = np.random.default_rng(seed)
+    nout = 3 * narms
+    nb = 6 * nout + narms
+    lo = np.zeros((batch, nb)); up = np.zeros((batch, nb))
+    for p in range(batch):
+        zi = np.zeros((nout, 3)); zf = np.zeros((nout, 3))
+        for j in range(narms):
+            zi[3 * j, 0] = rng.uniform(0.1, 0.5); zf[3 * j, 0] = rng.uniform(2.6, 3.0)
+            zi[3 * j + 1, 0] = rng.uniform(0.2, 0.6); zf[3 * j + 1, 0] = rng.uniform(0.2, 0.6)
+            zi[3 * j + 2, 0] = rng.uniform(0.2, 0.6); zf[3 * j + 2, 0] = rng.uniform(0.2, 0.6)
+        lo[p, :3 * nout] = zi.ravel(); lo[p, 3 * nout:6 * nout] = zf.ravel()
+        up[p, :6 * nout] = lo[p, :6 * nout]
+        lo[p, 6 * nout:] = -INF_BOUND; up[p, 6 * nout:] = ceiling
     return lo, up

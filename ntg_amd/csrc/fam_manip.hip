@@ -1,0 +1,20 @@
+// fam_manip.hip -- eval_kernel / sqp_kernel instances of one problem family (own translation unit: the
+// families compile in parallel).  Tuned instances fix nout and the spline order at compile time.
+#include "solve_impl.hpp"
+
+// config E: 12 outputs, order 6 (2196 coefficients, 301 breakpoints): 512 lanes, five coefficients per lane
+hipError_t ntg_launch_eval_manip(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
+{
+	if (a.nt == 512 && ntg_all_d(D, 3) && D.nout == 12 && ntg_uniform_order(D, 512, 5) == 6)
+		return launch_eval_one<NTG_FAM_MANIP, 12, 6, 512, 5>(D, T, L, a);
+	return launch_eval_generic<NTG_FAM_MANIP>(D, T, L, a);
+}
+
+hipError_t ntg_launch_sqp_manip(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
+{
+	if (a.nt == 512 && ntg_all_d(D, 3) && D.nout == 12 && ntg_uniform_order(D, 512, 5) == 6) {
+		if (a.big) return launch_sqp_one<NTG_FAM_MANIP, 12, 6, 512, 5, true>(D, T, L, sp, a);
+		return launch_sqp_one<NTG_FAM_MANIP, 12, 6, 512, 5, false>(D, T, L, sp, a);
+	}
+	return launch_sqp_generic<NTG_FAM_MANIP>(D, T, L, sp, a);
+}

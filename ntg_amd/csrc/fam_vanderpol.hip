@@ -1,0 +1,21 @@
+// fam_vanderpol.hip -- eval_kernel / sqp_kernel instances of one problem family (own translation unit: the
+// families compile in parallel).  Tuned instances fix nout and the spline order at compile time.
+#include "solve_impl.hpp"
+
+hipError_t ntg_launch_eval_vanderpol(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
+{
+	const bool small = (a.nt == 128 || a.nt == 256) && ntg_all_d(D, 3);
+	const int ku = ntg_uniform_order(D, a.nt, 4);
+	(void)ku;
+	if (small && ku == 5) return launch_eval_small<NTG_FAM_VANDERPOL, 1, 5>(D, T, L, a);
+	return launch_eval_generic<NTG_FAM_VANDERPOL>(D, T, L, a);
+}
+
+hipError_t ntg_launch_sqp_vanderpol(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
+{
+	const bool small = (a.nt == 128 || a.nt == 256) && ntg_all_d(D, 3);
+	const int ku = ntg_uniform_order(D, a.nt, 4);
+	(void)ku;
+	if (small && !a.big && ku == 5) return launch_sqp_small<NTG_FAM_VANDERPOL, 1, 5>(D, T, L, sp, a);
+	return launch_sqp_generic<NTG_FAM_VANDERPOL>(D, T, L, sp, a);
+}

@@ -4,19 +4,43 @@
 // run on the GPU, so the batched path selects a problem family by id.  A functor sees the flat
 // flag of ONE breakpoint as z[iz[o]+r] (== the reference's zp[o][r], colloc.c:425-447) and
 // returns the value and the gradient over the full stacked flag, exactly like the callbacks
-// (cost.c:107-108, constraints.c:146-151).  All families assume maxderiv == 3 per output.
+// (cost.c:107-108, constraints.c:146-151).  Every output of a family has maxderiv == Family::DM.
+// Besides the dense callbacks every family offers the trajectory constraints in the two-step form the
+// augmented-Lagrangian evaluation uses: nltc_val (values only) and nltc_vjp (df += J' t), so that a family
+// with many constraints never holds its dense [ncon][nz] Jacobian in registers.
 //
 //   NTG_FAM_KINCAR     f = sum_o (z_o'')^2                      examples/kincar.c:105-117
 //   NTG_FAM_VANDERPOL  f = (z^2 + z'^2 + u^2)/2, u = z''+z-(1-z^2)z'   examples/vanderpol.c:206-241
 //   NTG_FAM_TESTFAM    synthetic, every slot populated (mirrors oracle/families.c family 2)
 //   NTG_FAM_OBSTACLE   kincar cost (2 outputs) + trajectory constraint c = (x-20)^2 + (y-0.5)^2 (>= r^2 via bounds)
+//   NTG_FAM_QUADROTOR  4 outputs (x, y, z, yaw), maxderiv 5: snap^2 + yaw''^2; c0 = x''^2+y''^2+(z''+g)^2, c1 = |v|^2
+//   NTG_FAM_MANIP      3 joints per planar arm, maxderiv 3: sum q''^2; per arm c = sin(qa)+sin(qa+qb)+sin(qa+qb+qc)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "../../include/ntg_amd.h"
 
 template <int FAM> struct Family;
 
+// nltc_val / nltc_vjp through the dense callback (families with a handful of constraints)
+template <class Fam, int NZMAX>
+struct DenseTraj {
+	static __device__ __forceinline__ void val(int nout, int i, const double *z, double *c)
+	{
+		double dc[(Fam::NNLTC > 0 ? Fam::NNLTC : 1) * NZMAX];
+		Fam::nltcf(nout, i, z, c, dc);
+	}
+	static __device__ __forceinline__ void vjp(int nout, int nz, int i, const double *z, const double *t, double *df)
+	{
+		double c[Fam::NNLTC > 0 ? Fam::NNLTC : 1], dc[(Fam::NNLTC > 0 ? Fam::NNLTC : 1) * NZMAX];
+		Fam::nltcf(nout, i, z, c, dc);
+		for (int j = 0; j < Fam::NNLTC; j++)
+#pragma unroll
+			for (int v = 0; v < NZMAX; v++) { if (v < nz) df[v] += t[j] * dc[j * nz + v]; }
+	}
+};
+
 template <> struct Family<NTG_FAM_KINCAR> {
+	static constexpr int DM = 3;
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int, const double *z, double &f, double *df)
 	{
@@ -32,9 +56,12 @@ template <> struct Family<NTG_FAM_KINCAR> {
 	static __device__ __forceinline__ void nlicf(int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nltcf(int, int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nlfcf(int, const double *, double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *, const double *, double *) {}
 };
 
 template <> struct Family<NTG_FAM_VANDERPOL> {
+	static constexpr int DM = 3;
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int, int, const double *zz, double &f, double *df)
 	{
@@ -50,10 +77,13 @@ template <> struct Family<NTG_FAM_VANDERPOL> {
 	static __device__ __forceinline__ void nlicf(int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nltcf(int, int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nlfcf(int, const double *, double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *, const double *, double *) {}
 };
 
 // dc is [ncon][nz] row-major (== the reference's dc[constraint][variable])
 template <> struct Family<NTG_FAM_TESTFAM> {
+	static constexpr int DM = 3;
 	static constexpr int NNLIC = 1, NNLTC = 2, NNLFC = 1;
 	static __device__ __forceinline__ void icf(int nout, const double *z, double &f, double *df)
 	{
@@ -110,9 +140,12 @@ template <> struct Family<NTG_FAM_TESTFAM> {
 		for (int v = 0; v < nz; v++) dc[v] = 0.0;
 		dc[2] += z[0]; dc[0] += z[2]; dc[3 * L + 1] += 2.0 * z[3 * L + 1];
 	}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int i, const double *z, double *c) { DenseTraj<Family, NZMAX>::val(nout, i, z, c); }
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int nz, int i, const double *z, const double *t, double *df) { DenseTraj<Family, NZMAX>::vjp(nout, nz, i, z, t, df); }
 };
 
 template <> struct Family<NTG_FAM_OBSTACLE> {
+	static constexpr int DM = 3;
 	static constexpr int NNLIC = 0, NNLTC = 1, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int i, const double *z, double &f, double *df) { Family<NTG_FAM_KINCAR>::ucf(nout, i, z, f, df); }
 	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }
@@ -125,5 +158,92 @@ template <> struct Family<NTG_FAM_OBSTACLE> {
 		c[0] = dx * dx + dy * dy;
 		for (int v = 0; v < 3 * nout; v++) dc[v] = 0.0;
 		dc[0] = 2.0 * dx; dc[3] = 2.0 * dy;
+	}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int i, const double *z, double *c) { DenseTraj<Family, NZMAX>::val(nout, i, z, c); }
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int nz, int i, const double *z, const double *t, double *df) { DenseTraj<Family, NZMAX>::vjp(nout, nz, i, z, t, df); }
+};
+
+template <> struct Family<NTG_FAM_QUADROTOR> {
+	static constexpr int DM = 5;
+	static constexpr int NNLIC = 0, NNLTC = 2, NNLFC = 0;
+	static constexpr double G = 9.81;
+	static __device__ __forceinline__ void ucf(int, int, const double *z, double &f, double *df)
+	{
+#pragma unroll
+		for (int v = 0; v < 20; v++) df[v] = 0.0;
+		f = z[4] * z[4] + z[9] * z[9] + z[14] * z[14] + z[17] * z[17];
+		df[4] = 2.0 * z[4]; df[9] = 2.0 * z[9]; df[14] = 2.0 * z[14]; df[17] = 2.0 * z[17];
+	}
+	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }
+	static __device__ __forceinline__ void fcf(int, const double *, double &f, double *) { f = 0.0; }
+	static __device__ __forceinline__ void nlicf(int, const double *, double *, double *) {}
+	static __device__ __forceinline__ void nlfcf(int, const double *, double *, double *) {}
+	static __device__ __forceinline__ void nltcf(int, int, const double *z, double *c, double *dc)
+	{
+		const double ax = z[2], ay = z[7], az = z[12] + G;
+		c[0] = ax * ax + ay * ay + az * az;
+		c[1] = z[1] * z[1] + z[6] * z[6] + z[11] * z[11];
+#pragma unroll
+		for (int v = 0; v < 40; v++) dc[v] = 0.0;
+		dc[2] = 2.0 * ax; dc[7] = 2.0 * ay; dc[12] = 2.0 * az;
+		dc[20 + 1] = 2.0 * z[1]; dc[20 + 6] = 2.0 * z[6]; dc[20 + 11] = 2.0 * z[11];
+	}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *z, double *c)
+	{
+		const double ax = z[2], ay = z[7], az = z[12] + G;
+		c[0] = ax * ax + ay * ay + az * az;
+		c[1] = z[1] * z[1] + z[6] * z[6] + z[11] * z[11];
+	}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *z, const double *t, double *df)
+	{
+		df[2] += t[0] * (2.0 * z[2]); df[7] += t[0] * (2.0 * z[7]); df[12] += t[0] * (2.0 * (z[12] + G));
+		df[1] += t[1] * (2.0 * z[1]); df[6] += t[1] * (2.0 * z[6]); df[11] += t[1] * (2.0 * z[11]);
+	}
+};
+
+template <> struct Family<NTG_FAM_MANIP> {
+	static constexpr int DM = 3;
+	static constexpr int MAXARMS = NTG_MAX_OUT / 3;
+	static constexpr int NNLIC = 0, NNLTC = MAXARMS, NNLFC = 0;
+	static __device__ __forceinline__ void ucf(int nout, int i, const double *z, double &f, double *df) { Family<NTG_FAM_KINCAR>::ucf(nout, i, z, f, df); }
+	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }
+	static __device__ __forceinline__ void fcf(int, const double *, double &f, double *) { f = 0.0; }
+	static __device__ __forceinline__ void nlicf(int, const double *, double *, double *) {}
+	static __device__ __forceinline__ void nlfcf(int, const double *, double *, double *) {}
+	static __device__ __forceinline__ void nltcf(int nout, int, const double *z, double *c, double *dc)
+	{
+		const int narms = nout / 3, nz = 3 * nout;
+		for (int j = 0; j < narms; j++) {
+			const double a1 = z[9 * j], a2 = a1 + z[9 * j + 3], a3 = a2 + z[9 * j + 6];
+			const double c1 = cos(a1), c2 = cos(a2), c3 = cos(a3);
+			c[j] = sin(a1) + sin(a2) + sin(a3);
+			for (int v = 0; v < nz; v++) dc[j * nz + v] = 0.0;
+			dc[j * nz + 9 * j] = c1 + c2 + c3;
+			dc[j * nz + 9 * j + 3] = c2 + c3;
+			dc[j * nz + 9 * j + 6] = c3;
+		}
+	}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int, const double *z, double *c)
+	{
+#pragma unroll
+		for (int j = 0; j < MAXARMS; j++) {
+			if (3 * j < nout) {
+				const double a1 = z[9 * j], a2 = a1 + z[9 * j + 3], a3 = a2 + z[9 * j + 6];
+				c[j] = sin(a1) + sin(a2) + sin(a3);
+			}
+		}
+	}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int, int, const double *z, const double *t, double *df)
+	{
+#pragma unroll
+		for (int j = 0; j < MAXARMS; j++) {
+			if (3 * j < nout) {
+				const double a1 = z[9 * j], a2 = a1 + z[9 * j + 3], a3 = a2 + z[9 * j + 6];
+				const double c1 = cos(a1), c2 = cos(a2), c3 = cos(a3);
+				df[9 * j] += t[j] * (c1 + c2 + c3);
+				df[9 * j + 3] += t[j] * (c2 + c3);
+				df[9 * j + 6] += t[j] * c3;
+			}
+		}
 	}
 };

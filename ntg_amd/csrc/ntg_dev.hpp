@@ -79,3 +79,10 @@ struct SolveParams {
 	int stamps;   // diagnostic: clambda[b][0..7] receives per-phase cycle counts instead of multipliers
 	double sr, steplimit, ls_mu, ls_eta;
 };
+
+// launcher arguments (host side)
+struct EvalArgs { int nt, grid, batch, mode; const double *x; double *f, *g, *c, *jb, *cj; hipStream_t st; };
+struct SqpArgs {
+	int nt, big, batch; const double *lo, *up; double *x, *obj; int *inf, *it, *nf; double *cl, *hist, *alw, *vecw; hipStream_t st;
+};
+

@@ -141,7 +141,7 @@ bool host_funcon(HostProblem &hp, int mode, const double *x, double *c, double *
 bool alloc_host_problem(HostProblem &hp)
 {
 	const NtgDims &D = hp.plan->D;
-	hp.L = ntg_make_layout(D, 128, 1, 0);
+	hp.L = ntg_make_layout(D, 128, 1, 1);
 	hp.Z.assign((size_t)D.nz * D.P, 0.0);
 	hp.zp.resize(D.nout);
 	auto al = [&](double **p, size_t n) { return hip_ok(hipMalloc((void **)p, std::max<size_t>(n, 1) * 8), "hipMalloc"); };
@@ -427,6 +427,10 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 			d = gp;
 			for (;;) {
 				if (iter >= itlim) { inner = 4; stop = true; break; }
+				if (nal > 0 && mE) {   // keep the direction in null(A) to rounding relative to |d|, not |g| (see sqp_kernel)
+					const std::vector<double> keep = lamE;
+					project(d, xt); d = xt; lamE = keep;
+				}
 				for (int i = 0; i < n; i++) p[i] = -d[i];
 				double dphi0 = dot(gp, p);
 				pnorm = nrm2(p);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#include <utility>
 #include "ntg_dev.hpp"
 #include "plan.hpp"
 
@@ -116,12 +117,17 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	D.nclin = s->nlic + s->nltc * s->nbps + s->nlfc;           // ntg.c:156
 	D.ncnln = s->nnlic + s->nnltc * s->nbps + s->nnlfc;        // ntg.c:157
 	D.nbounds = s->nlic + s->nltc + s->nlfc + s->nnlic + s->nnltc + s->nnlfc;
-	if (s->family != NTG_FAM_KINCAR && s->family != NTG_FAM_VANDERPOL && s->family != NTG_FAM_TESTFAM && s->family != NTG_FAM_OBSTACLE && s->family != NTG_FAM_HOST) {
+	if (s->family != NTG_FAM_KINCAR && s->family != NTG_FAM_VANDERPOL && s->family != NTG_FAM_TESTFAM && s->family != NTG_FAM_OBSTACLE &&
+	    s->family != NTG_FAM_QUADROTOR && s->family != NTG_FAM_MANIP && s->family != NTG_FAM_HOST) {
 		delete p; return fail(NTG_E_BADARG, "unknown problem family");
 	}
-	if (s->family != NTG_FAM_HOST)
+	if (s->family != NTG_FAM_HOST) {
+		const int dm = s->family == NTG_FAM_QUADROTOR ? 5 : 3;   // Family<>::DM of families.hpp
 		for (int o = 0; o < s->nout; o++)
-			if (D.d[o] != 3) { delete p; return fail(NTG_E_UNSUPPORTED, "device families assume maxderiv == 3"); }
+			if (D.d[o] != dm) { delete p; return fail(NTG_E_UNSUPPORTED, "device family: wrong maxderiv (5 for the quadrotor family, 3 otherwise)"); }
+	}
+	if (s->family == NTG_FAM_QUADROTOR && (s->nout != 4 || s->nnlic || s->nnlfc || s->nnltc > 2)) { delete p; return fail(NTG_E_BADARG, "quadrotor family: 4 outputs, at most two trajectory constraints"); }
+	if (s->family == NTG_FAM_MANIP && (s->nout % 3 || s->nnlic || s->nnlfc || s->nnltc > s->nout / 3)) { delete p; return fail(NTG_E_BADARG, "manipulator family: 3 outputs per arm, at most one trajectory constraint per arm"); }
 	if (s->family == NTG_FAM_VANDERPOL && s->nout != 1) { delete p; return fail(NTG_E_BADARG, "vanderpol family has one output"); }
 	if (s->family == NTG_FAM_TESTFAM && (s->nnlic > 1 || s->nnltc > 2 || s->nnlfc > 1)) { delete p; return fail(NTG_E_BADARG, "testfam has 1/2/1 nonlinear constraints"); }
 	if ((s->family == NTG_FAM_KINCAR || s->family == NTG_FAM_VANDERPOL) && D.ncnln > 0) { delete p; return fail(NTG_E_BADARG, "family has no nonlinear constraints"); }
@@ -399,35 +405,15 @@ extern "C" int ntg_plan_tables(const ntg_plan *p, double *blk, int *off, double 
 	return 0;
 }
 
-// W0 = Z (Z' H0 Z)^-1 Z', H0 = trapezoid-weighted sum of m m' over the cost active variables.
-// Host, once per plan (shared by the whole batch); dense symmetric n x n uploaded to HBM.
-static int build_precond(ntg_plan *p)
+// Dense core of the preconditioner for one block: W0 = Z (Z' H0 Z)^-1 Z' with Z = null(A) from a Householder QR of A'.
+// H0 (n x n), A (m x n) and W0 (n x n) are row-major.
+static int precond_block(const std::vector<double> &H0, const std::vector<double> &A, int m, int n, std::vector<double> &W0)
 {
-	const NtgDims &D = p->D;
-	const int n = D.nC, m = D.nclin, nr = n - m, P = D.P;
+	const int nr = n - m;
 	if (nr <= 0) return fail(NTG_E_UNSUPPORTED, "no free directions");
-	std::vector<double> H0((size_t)n * n, 0.0);
-	auto add = [&](const std::vector<ntg_av> &av, int bp, double w) {
-		for (const ntg_av &a : av) {
-			const int o = a.output, r = a.deriv, k = D.order[o], d = D.d[o], c = D.cls[o];
-			const int base = D.iC[o] + p->h_off[(size_t)c * P + bp];
-			const double *b = p->h_blk.data() + D.cls_blk[c] + (size_t)bp * k * d;
-			for (int q1 = 0; q1 < k; q1++) for (int q2 = 0; q2 < k; q2++)
-				H0[(size_t)(base + q1) * n + base + q2] += w * b[q1 * d + r] * b[q2 * d + r];
-		}
-	};
-	for (int i = 0; i < P; i++) {
-		double w = 0.0;
-		if (i > 0) w += (p->h_bps[i] - p->h_bps[i - 1]) / 2;
-		if (i < P - 1) w += (p->h_bps[i + 1] - p->h_bps[i]) / 2;
-		if (D.nucf) add(p->tcostav, i, w);
-	}
-	if (D.nicf) add(p->icostav, 0, 1.0);
-	if (D.nfcf) add(p->fcostav, P - 1, 1.0);
-	// Householder QR of A' -> explicit Q (row-major n x n)
 	std::vector<double> Q((size_t)n * n, 0.0), R((size_t)n * std::max(m, 1), 0.0), v(n);
 	for (int i = 0; i < n; i++) Q[(size_t)i * n + i] = 1.0;
-	for (int j = 0; j < m; j++) for (int i = 0; i < n; i++) R[(size_t)i * m + j] = p->h_Adense[(size_t)j * n + i];
+	for (int j = 0; j < m; j++) for (int i = 0; i < n; i++) R[(size_t)i * m + j] = A[(size_t)j * n + i];
 	for (int j = 0; j < m && j < n; j++) {
 		double nrm = 0.0;
 		for (int i = j; i < n; i++) nrm += R[(size_t)i * m + j] * R[(size_t)i * m + j];
@@ -456,28 +442,86 @@ static int build_precond(ntg_plan *p)
 	form_hr(1e-12);
 	if (!chol_lower(Hr, nr)) { form_hr(1e-6); if (!chol_lower(Hr, nr)) return fail(NTG_E_UNSUPPORTED, "preconditioner not positive definite"); }
 	// X[:, c] = Hr^-1 Zt[:, c] ; W0 = Zt' X
-	std::vector<double> X((size_t)n * nr), col(nr), W0((size_t)n * n);
-	for (int c = 0; c < n; c++) { for (int i = 0; i < nr; i++) col[i] = Zt[(size_t)i * n + c]; chol_solve(Hr, nr, col.data()); for (int i = 0; i < nr; i++) X[(size_t)c * nr + i] = col[i]; }
+	std::vector<double> X((size_t)n * nr), col(nr), Zc((size_t)n * nr);
+	for (int c = 0; c < n; c++) { for (int i = 0; i < nr; i++) { col[i] = Zt[(size_t)i * n + c]; Zc[(size_t)c * nr + i] = col[i]; } chol_solve(Hr, nr, col.data()); for (int i = 0; i < nr; i++) X[(size_t)c * nr + i] = col[i]; }
+	W0.assign((size_t)n * n, 0.0);
 	for (int i = 0; i < n; i++) for (int j = 0; j <= i; j++) {
 		double s = 0.0;
-		for (int k = 0; k < nr; k++) s += Zt[(size_t)k * n + i] * X[(size_t)j * nr + k];
+		const double *zi = &Zc[(size_t)i * nr], *xj = &X[(size_t)j * nr];
+		for (int k = 0; k < nr; k++) s += zi[k] * xj[k];
 		W0[(size_t)i * n + j] = s; W0[(size_t)j * n + i] = s;
 	}
-	// entries at rounding level relative to the diagonal are noise of the orthogonal factorisation
-	// (outputs that no constraint couples give exactly decoupled blocks): drop them
+	// entries at rounding level relative to the diagonal are noise of the orthogonal factorisation: drop them
 	for (int i = 0; i < n; i++) for (int j = 0; j < n; j++)
-		if (std::fabs(W0[(size_t)i * n + j]) <= 1e-13 * std::sqrt(std::fabs(W0[(size_t)i * n + i] * W0[(size_t)j * n + j]))) W0[(size_t)i * n + j] = 0.0;
+		if (i != j && std::fabs(W0[(size_t)i * n + j]) <= 1e-13 * std::sqrt(std::fabs(W0[(size_t)i * n + i] * W0[(size_t)j * n + j]))) W0[(size_t)i * n + j] = 0.0;
+	return 0;
+}
+
+// W0 = Z (Z' H0 Z)^-1 Z', H0 = trapezoid-weighted sum of m m' over the cost active variables.
+// Host, once per plan (shared by the whole batch).  H0 is block diagonal by output, so outputs that no row of A
+// couples give independent blocks of W0: each block is factorised on its own (12 x 183^3 instead of 2196^3 for
+// config E) and the result goes to HBM as ELL rows.
+static int build_precond(ntg_plan *p)
+{
+	const NtgDims &D = p->D;
+	const int n = D.nC, m = D.nclin, P = D.P;
+	if (n - m <= 0) return fail(NTG_E_UNSUPPORTED, "no free directions");
+	if (n > 65535) return fail(NTG_E_UNSUPPORTED, "preconditioner: more than 65535 coefficients");
+	// components of outputs under "some row of A touches both"
+	std::vector<int> comp(D.nout), outof(n);
+	for (int o = 0; o < D.nout; o++) { comp[o] = o; for (int j = 0; j < D.ncoef[o]; j++) outof[D.iC[o] + j] = o; }
+	for (int r = 0; r < m; r++) {
+		int first = -1;
+		for (int j = 0; j < n; j++) if (p->h_Adense[(size_t)r * n + j] != 0.0) {
+			const int c = comp[outof[j]];
+			if (first < 0) first = c;
+			else if (c != first) { const int lo = std::min(c, first), hi = std::max(c, first); for (int o = 0; o < D.nout; o++) if (comp[o] == hi) comp[o] = lo; first = lo; }
+		}
+	}
+	std::vector<std::vector<std::pair<int, double>>> rows(n);   // W0 row i: (column, value), zeros dropped
+	for (int o0 = 0; o0 < D.nout; o0++) {
+		if (comp[o0] != o0) continue;
+		std::vector<int> idx, rsel, loc(n, -1);
+		for (int j = 0; j < n; j++) if (comp[outof[j]] == o0) { loc[j] = (int)idx.size(); idx.push_back(j); }
+		for (int r = 0; r < m; r++) { bool hit = false; for (int j : idx) if (p->h_Adense[(size_t)r * n + j] != 0.0) { hit = true; break; } if (hit) rsel.push_back(r); }
+		const int nb = (int)idx.size(), mb = (int)rsel.size();
+		std::vector<double> H0((size_t)nb * nb, 0.0), Ab((size_t)std::max(mb, 1) * nb, 0.0), Wb;
+		auto add = [&](const std::vector<ntg_av> &av, int bp, double w) {
+			for (const ntg_av &a : av) {
+				const int o = a.output, r = a.deriv, k = D.order[o], d = D.d[o], c = D.cls[o];
+				if (comp[o] != o0) continue;
+				const int base = loc[D.iC[o]] + p->h_off[(size_t)c * P + bp];   // an output's coefficients are contiguous in idx
+				const double *b = p->h_blk.data() + D.cls_blk[c] + (size_t)bp * k * d;
+				for (int q1 = 0; q1 < k; q1++) for (int q2 = 0; q2 < k; q2++)
+					H0[(size_t)(base + q1) * nb + base + q2] += w * b[q1 * d + r] * b[q2 * d + r];
+			}
+		};
+		for (int i = 0; i < P; i++) {
+			double w = 0.0;
+			if (i > 0) w += (p->h_bps[i] - p->h_bps[i - 1]) / 2;
+			if (i < P - 1) w += (p->h_bps[i + 1] - p->h_bps[i]) / 2;
+			if (D.nucf) add(p->tcostav, i, w);
+		}
+		if (D.nicf) add(p->icostav, 0, 1.0);
+		if (D.nfcf) add(p->fcostav, P - 1, 1.0);
+		for (int i = 0; i < mb; i++) for (int j = 0; j < nb; j++) Ab[(size_t)i * nb + j] = p->h_Adense[(size_t)rsel[i] * n + idx[j]];
+		const int rc = precond_block(H0, Ab, mb, nb, Wb);
+		if (rc) return rc;
+		for (int i = 0; i < nb; i++) for (int j = 0; j < nb; j++) if (Wb[(size_t)i * nb + j] != 0.0) rows[idx[i]].push_back({idx[j], Wb[(size_t)i * nb + j]});
+	}
 	// ELL, s-major, zeros dropped
 	int w = 0;
-	for (int i = 0; i < n; i++) { int cnt = 0; for (int j = 0; j < n; j++) if (W0[(size_t)i * n + j] != 0.0) cnt++; w = std::max(w, cnt); }
-	if (n > 65535) return fail(NTG_E_UNSUPPORTED, "preconditioner: more than 65535 coefficients");
+	for (int i = 0; i < n; i++) w = std::max(w, (int)rows[i].size());
 	std::vector<double> ev((size_t)w * n, 0.0); std::vector<unsigned short> ec((size_t)w * n, 0);
-	for (int i = 0; i < n; i++) { int e = 0; for (int j = 0; j < n; j++) if (W0[(size_t)i * n + j] != 0.0) { ev[(size_t)e * n + i] = W0[(size_t)i * n + j]; ec[(size_t)e * n + i] = (unsigned short)j; e++; } }
+	for (int i = 0; i < n; i++) { int e = 0; for (auto &cv : rows[i]) { ev[(size_t)e * n + i] = cv.second; ec[(size_t)e * n + i] = (unsigned short)cv.first; e++; } }
 	double *d_n0 = nullptr; unsigned short *d_n0c = nullptr;
 	if (dev_upload(&d_n0, ev.data(), ev.size(), p->owned) || dev_upload(&d_n0c, ec.data(), ec.size(), p->owned)) return NTG_E_HIP;
 	p->T.n0 = d_n0; p->T.n0c = d_n0c; p->T.n0_w = w;
 	return 0;
 }
+
+// workgroup size: breakpoints and coefficients are spread over the lanes
+static int auto_threads(const NtgDims &D) { return (D.P <= 128 && D.nC <= 512) ? 128 : (D.nC <= 1024 ? 256 : 512); }
 
 static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParams *sp, int *nt)
 {
@@ -488,23 +532,39 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	sp->memcap = std::min(sp->itlim, 256);
 	sp->ls_maxfev = o->ls_maxfev > 0 ? o->ls_maxfev : 20;
 	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters;
-	sp->stamps = getenv("NTG_AMD_STAMPS") ? 1 : 0;
+	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
 	sp->sr = std::sqrt(r);
 	sp->steplimit = o->steplimit > 0 ? o->steplimit : 2.0;
 	sp->ls_mu = o->ls_mu > 0 ? o->ls_mu : 1e-4; sp->ls_eta = o->ls_eta > 0 ? o->ls_eta : 0.9;
 	int t = o->block_threads;
-	if (t != 128 && t != 256) t = (D.P <= 128 && D.nC <= 512) ? 128 : 256;
+	if (t != 128 && t != 256 && t != 512) t = auto_threads(D);
 	*nt = t;
 	return 0;
 }
+
+// does the solve keep all its vectors in LDS, or only the two that are read across lanes (sqp_kernel, BIG)?
+static int solve_layout(const NtgDims &D, int nt, SmemLayout *L, int *big)
+{
+	*big = 0;
+	*L = ntg_make_layout(D, nt, 5, 1);
+	if (L->total <= 160 * 1024) return 0;
+	*big = 1;
+	*L = ntg_make_layout(D, nt, 1, 0);
+	return L->total <= 160 * 1024 ? 0 : -1;
+}
+static size_t hist_doubles(const NtgDims &D, int batch, const SolveParams &sp) { return (size_t)batch * sp.memcap * (2 * D.nC + 2); }
+static size_t al_doubles(const NtgDims &D, int batch) { return (size_t)batch * 2 * D.ncnln; }
 
 extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, const ntg_solve_opts *o)
 {
 	if (!p) return 0;
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
-	return (long long)batch * sp.memcap * (2 * p->D.nC + 2) * 8 + (long long)batch * 2 * p->D.ncnln * 8 + 256;
+	SmemLayout L; int big;
+	solve_layout(p->D, nt, &L, &big);
+	const size_t npad = (size_t)((p->D.nC + 1) & ~1);
+	return (long long)((hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0)) * 8 + 256);
 }
 
 extern "C" int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
@@ -527,8 +587,8 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	if (batch <= 0) return 0;
 	HIPCHK(hipSetDevice(p->device));
 	const NtgDims &D = p->D;
-	const int nt = (D.P <= 128 && D.nC <= 512) ? 128 : 256;
-	SmemLayout L = ntg_make_layout(D, nt, 1, 0);
+	const int nt = auto_threads(D);
+	SmemLayout L = ntg_make_layout(D, nt, 0, 1);
 	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem tables exceed 160 KiB of LDS");
 	hipStream_t st = (hipStream_t)stream;
 	if (d_cjac && D.ncnln) HIPCHK(hipMemsetAsync(d_cjac, 0, (size_t)batch * D.ncnln * D.nC * 8, st)); // GcJac starts zeroed (ntg.c:217)
@@ -539,7 +599,8 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	{ hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
 	const int wg_per_cu = std::max(1, std::min(std::min(8, 32 / (nt / 64)), (160 * 1024) / std::max(L.total, 1)));
 	const int grid = std::min(batch, ncu * wg_per_cu);
-	HIPCHK(ntg_launch_eval(nt, D, p->T, L, grid, batch, mode, d_x, d_f, d_g, d_c, d_jband, d_cjac, st));
+	EvalArgs ea{nt, grid, batch, mode, d_x, d_f, d_g, d_c, d_jband, d_cjac, st};
+	HIPCHK(ntg_launch_eval(D, p->T, L, ea));
 	return 0;
 }
 
@@ -559,11 +620,13 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	resolve_params(p, o, &sp, &nt);
 	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
 	if (sp.hessian == 1 && !p->T.n0) { int rc = build_precond(p); if (rc) return rc; }
-	SmemLayout L = ntg_make_layout(p->D, nt, 5, sp.memcap);
-	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
-	double *alw = (double *)d_work + (size_t)batch * sp.memcap * (2 * p->D.nC + 2);   // [batch][2][ncnln] multipliers, estimates
-	HIPCHK(ntg_launch_sqp(nt, p->D, p->T, L, sp, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev,
-	                      d_clambda, (double *)d_work, alw, (hipStream_t)stream));
+	SmemLayout L; int big;
+	if (solve_layout(p->D, nt, &L, &big)) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
+	double *alw = (double *)d_work + hist_doubles(p->D, batch, sp);   // [batch][2][ncnln] multipliers, estimates
+	double *vecw = alw + al_doubles(p->D, batch);                     // [batch][5][npad] x, gp, gp+, d, g (BIG only)
+	SqpArgs sa{nt, big, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev, d_clambda, (double *)d_work, alw,
+	           big ? vecw : nullptr, (hipStream_t)stream};
+	HIPCHK(ntg_launch_sqp(p->D, p->T, L, sp, sa));
 	return 0;
 }
 
@@ -584,8 +647,10 @@ extern "C" int ntg_debug_layout(const ntg_plan *p, const ntg_solve_opts *o, int 
 	if (!p) return NTG_E_BADARG;
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
-	if (lds_solve) *lds_solve = ntg_make_layout(p->D, nt, 5, sp.memcap).total;
-	if (lds_eval) *lds_eval = ntg_make_layout(p->D, (p->D.P <= 128 && p->D.nC <= 512) ? 128 : 256, 1, 0).total;
+	SmemLayout L; int big;
+	solve_layout(p->D, nt, &L, &big);
+	if (lds_solve) *lds_solve = big ? -L.total : L.total;   // negative: only the cross-lane vectors are in LDS
+	if (lds_eval) *lds_eval = ntg_make_layout(p->D, auto_threads(p->D), 0, 1).total;
 	if (nt_solve) *nt_solve = nt;
 	return 0;
 }

@@ -19,13 +19,13 @@ struct ntg_plan {
 
 void ntg_plan_dense_A(const ntg_plan *p, double *A);
 
-SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int memcap);
-hipError_t ntg_launch_eval(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, int grid, int batch,
-                           int mode, const double *x, double *f, double *g, double *c, double *jb, double *cj,
-                           hipStream_t st);
-hipError_t ntg_launch_sqp(int nt, const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp,
-                          int batch, const double *lo, const double *up, double *x, double *obj, int *inf, int *it,
-                          int *nf, double *cl, double *hist, double *alw, hipStream_t st);
+// LDS carve-up: tables + (with_x) the coefficient vector + nvec further vectors of nC doubles.
+//   eval_kernel   nvec 0 (the gradient is assembled into the x buffer once x is no longer needed)
+//   host path     nvec 1
+//   sqp_kernel    nvec 5 (xt, gp, gp+, d, g) with x -- or, BIG, nvec 1 (xt) without x: the rest lives in HBM/L2
+SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x);
+hipError_t ntg_launch_eval(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a);
+hipError_t ntg_launch_sqp(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a);
 hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,
                             long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st);
 hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,

@@ -1,0 +1,1212 @@
+// solve_impl.hpp -- templated device code of eval_kernel and sqp_kernel (gfx950).  Included by the per-family
+// translation units (fam_*.hip: one per problem family, so that they compile in parallel) and by kernels.hip
+// (host-callback kernels share the quadrature / gradient assembly).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <type_traits>
+#include "ntg_dev.hpp"
+#include "families.hpp"
+#include "linesearch.hpp"
+
+// tuning knobs: minimum waves per SIMD the register allocator must leave room
+// for, and how many quasi-Newton pairs one reduction round of apply_history covers
+#ifndef NTG_SQP_WAVES
+#define NTG_SQP_WAVES 2
+#endif
+#ifndef NTG_EVAL_WAVES
+#define NTG_EVAL_WAVES 2
+#endif
+#ifndef NTG_HIST_G
+#define NTG_HIST_G 6
+#endif
+
+// ------------------------------------------------------------------------------------------
+// reductions: sum K values over the workgroup, result broadcast to every lane
+// ------------------------------------------------------------------------------------------
+// Workgroup barrier for LDS-only hand-offs.  __syncthreads() also drains vmcnt(0), which would
+// serialise every in-flight HBM load (history pairs, prefetched coefficient vectors) behind each of
+// the many barriers of this kernel; LDS visibility only needs lgkmcnt(0) on both sides.
+__device__ __forceinline__ void lds_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// 64-lane wavefront sum with DPP (row shifts + row broadcasts stay in the VALU; __shfl_down
+// would go through ds_bpermute, i.e. the LDS crossbar, ~100 cycles per hop).  The total lands
+// in lane 63 and is broadcast from there through an SGPR.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+	return v + __hiloint2double(hi, lo);   // disabled / out-of-row lanes contribute +0.0
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+	v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+	v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+	v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+	v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds its row total
+	v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+	v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave total
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	return __hiloint2double(hi, lo);
+}
+
+// exchange a double with the lane whose index differs in one bit (1, 2, 4, 8: DPP inside a row of
+// 16; 16: ds_swizzle; 32: bpermute)
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_mov(double v, double old)
+{
+	const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+	const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+	return __hiloint2double(hi, lo);
+}
+template <int BIT>
+__device__ __forceinline__ double lane_xchg(double v)
+{
+	if (BIT == 1) return dpp_mov<0xB1, 0xf>(v, 0.0);                       // quad_perm [1,0,3,2]
+	if (BIT == 2) return dpp_mov<0x4E, 0xf>(v, 0.0);                       // quad_perm [2,3,0,1]
+	if (BIT == 4) return dpp_mov<0x114, 0xA>(v, dpp_mov<0x104, 0x5>(v, 0.0)); // row_shl:4 into banks 0,2 ; row_shr:4 into banks 1,3
+	if (BIT == 8) return dpp_mov<0x128, 0xf>(v, 0.0);                      // row_ror:8
+	if (BIT == 16) {
+		const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), 0x401F), hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), 0x401F);
+		return __hiloint2double(hi, lo);
+	}
+	return __shfl_xor(v, 32, 64);
+}
+
+// Sum KV (<= 16) per-lane values over the 64 lanes with the "halving" butterfly: at the step of
+// bit b a lane keeps the half of its values whose index has bit b equal to its own lane bit and
+// hands the other half to its partner, so the number of live values halves every step (15 exchanges
+// for 16 values instead of 16 x 6).  Afterwards lane L holds the wave total of value L & 15.
+template <int KV, int N, int BIT>
+__device__ __forceinline__ void halve_step(const double *in, double *out, int lane)
+{
+	const bool hi = (lane & BIT) != 0;
+#pragma unroll
+	for (int j = 0; j < N / 2; j++) {
+		// original indices covered by in[2j] / in[2j+1] start at (2j)*BIT and (2j+1)*BIT: skip all-padding pairs
+		if ((2 * j) * BIT >= KV) { out[j] = 0.0; continue; }
+		const double a = in[2 * j], b = ((2 * j + 1) * BIT < KV) ? in[2 * j + 1] : 0.0;
+		const double keep = hi ? b : a, send = hi ? a : b;
+		out[j] = keep + lane_xchg<BIT>(send);
+	}
+}
+template <int KV>
+__device__ __forceinline__ double wave_sum_many(const double *v, int lane)   // v has 16 slots, KV valid
+{
+	double a[8], b[4], c[2], d[1];
+	halve_step<KV, 16, 1>(v, a, lane);
+	halve_step<KV, 8, 2>(a, b, lane);
+	halve_step<KV, 4, 4>(b, c, lane);
+	halve_step<KV, 2, 8>(c, d, lane);
+	double t = d[0];
+	t += lane_xchg<16>(t);
+	t += lane_xchg<32>(t);
+	return t;
+}
+
+template <int NT, int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *red)
+{
+	constexpr int NW = NT / 64;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (K >= 4) {
+		double w[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) w[k] = k < K ? v[k] : 0.0;
+		const double t = wave_sum_many<K>(w, lane);   // lane L: wave total of value L & 15
+		lds_sync(); // red[] may still be read by the previous call
+		if (lane < K) red[lane * NW + wave] = t;
+		lds_sync();
+#pragma unroll
+		for (int k = 0; k < K; k++) {
+			double s2 = red[k * NW];
+#pragma unroll
+			for (int w2 = 1; w2 < NW; w2++) s2 += red[k * NW + w2];
+			v[k] = s2;
+		}
+		return;
+	}
+#pragma unroll
+	for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+	if (NW == 1) return;
+	lds_sync(); // red[] may still be read by the previous call
+	if (lane == 0) {
+#pragma unroll
+		for (int k = 0; k < K; k++) red[k * NW + wave] = v[k];
+	}
+	lds_sync();
+#pragma unroll
+	for (int k = 0; k < K; k++) {
+		double s = red[k * NW];
+#pragma unroll
+		for (int w = 1; w < NW; w++) s += red[k * NW + w];
+		v[k] = s;
+	}
+}
+
+// every lane owns the vector elements c = tid + e*NT.  For n <= 3*NT the three slots are unrolled
+// so that their (independent) LDS dependency chains overlap; longer vectors take the plain loop.
+template <int NT, class F>
+__device__ __forceinline__ void for_vec(int n, F f)
+{
+	if (n <= 3 * NT) {
+#pragma unroll
+		for (int e = 0; e < 3; e++) { const int c = threadIdx.x + e * NT; if (c < n) f(c); }
+	} else {
+		for (int c = threadIdx.x; c < n; c += NT) f(c);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS carve-up shared by eval_kernel and sqp_kernel
+// ------------------------------------------------------------------------------------------
+struct Smem {
+	double *rowv; unsigned int *colp; int *chrow, *chcol;
+	int *off; double *bps, *wts; int *ivl_lo, *ivl_hi;
+	double *x, *dfz, *fvals, *red, *dfi, *dff, *vecs, *lam, *rho, *c2;
+	// sparse linear-constraint operator: LDS copies when they fit, HBM/L2 otherwise
+	const int *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col; const double *csr_val, *csc_val, *sinv_val;
+	int *oinfo, *tavrow;   // per-output scalars and flag->row map in LDS (no per-lane kernarg gathers)
+	short *q_idx; int *q_col; double *q_val;
+	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T)
+	{
+		rowv = (double *)(base + L.rowv); colp = (unsigned int *)(base + L.colp);
+		chrow = (int *)(base + L.chrow); chcol = (int *)(base + L.chcol);
+		off = (int *)(base + L.off); bps = (double *)(base + L.bps);
+		wts = (double *)(base + L.wts);
+		ivl_lo = (int *)(base + L.ivl_lo); ivl_hi = (int *)(base + L.ivl_hi);
+		x = (double *)(base + L.x); dfz = (double *)(base + L.dfz); fvals = (double *)(base + L.fvals);
+		red = (double *)(base + L.red); dfi = (double *)(base + L.dfi); dff = (double *)(base + L.dff);
+		vecs = (double *)(base + L.vecs); lam = (double *)(base + L.lam); rho = (double *)(base + L.rho);
+		c2 = (double *)(base + L.c2);
+		if (D.lin_lds) {
+			csr_ptr = (const int *)(base + L.csr_ptr); csr_col = (const int *)(base + L.csr_col); csr_val = (const double *)(base + L.csr_val);
+			csc_ptr = (const int *)(base + L.csc_ptr); csc_row = (const int *)(base + L.csc_row); csc_val = (const double *)(base + L.csc_val);
+			sinv_ptr = (const int *)(base + L.sinv_ptr); sinv_col = (const int *)(base + L.sinv_col); sinv_val = (const double *)(base + L.sinv_val);
+		} else {
+			csr_ptr = T.csr_ptr; csr_col = T.csr_col; csr_val = T.csr_val;
+			csc_ptr = T.csc_ptr; csc_row = T.csc_row; csc_val = T.csc_val;
+			sinv_ptr = T.sinv_ptr; sinv_col = T.sinv_col; sinv_val = T.sinv_val;
+		}
+		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow);
+		q_idx = (short *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
+	}
+};
+
+template <int NT>
+__device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &T, const Smem &S, char *base, const SmemLayout &L)
+{
+	const int tid = threadIdx.x;
+	for (int i = tid; i < D.row_total; i += NT) S.rowv[i] = T.rowv[i];
+	for (int i = tid; i < D.col_total; i += NT) S.colp[i] = T.colp[i];
+	for (int i = tid; i < D.nclass * NTG_MAX_ORDER; i += NT) { S.chrow[i] = T.chrow[i]; S.chcol[i] = T.chcol[i]; }
+	for (int i = tid; i < D.nclass * D.P; i += NT) S.off[i] = T.off[i];
+	for (int i = tid; i < D.P; i += NT) {
+		S.bps[i] = T.bps[i];
+		// trapezoid weight of breakpoint i: integrator.c:21-24 regrouped per node
+		double w = 0.0;
+		if (i > 0) w += (T.bps[i] - T.bps[i - 1]) / 2;
+		if (i < D.P - 1) w += (T.bps[i + 1] - T.bps[i]) / 2;
+		S.wts[i] = w;
+	}
+	if (D.lin_lds) {
+		int *rp = (int *)(base + L.csr_ptr), *rc = (int *)(base + L.csr_col), *cp = (int *)(base + L.csc_ptr), *cr = (int *)(base + L.csc_row);
+		double *rv = (double *)(base + L.csr_val), *cv = (double *)(base + L.csc_val), *sv = (double *)(base + L.sinv_val);
+		int *sp_ = (int *)(base + L.sinv_ptr), *sc = (int *)(base + L.sinv_col);
+		for (int i = tid; i <= D.nclin; i += NT) rp[i] = T.csr_ptr[i];
+		for (int i = tid; i <= D.nC; i += NT) cp[i] = T.csc_ptr[i];
+		for (int i = tid; i < D.lin_nnz; i += NT) { rc[i] = T.csr_col[i]; rv[i] = T.csr_val[i]; cr[i] = T.csc_row[i]; cv[i] = T.csc_val[i]; }
+		for (int i = tid; i <= D.nclin; i += NT) sp_[i] = T.sinv_ptr[i];
+		for (int i = tid; i < D.sinv_nnz; i += NT) { sc[i] = T.sinv_col[i]; sv[i] = T.sinv_val[i]; }
+	}
+	// per-output scalars: k, m, l, d, iC, iz, class blk offset, class off offset, class ivl offset, ncoef
+	for (int o = tid; o < D.nout; o += NT) {
+		int *q = S.oinfo + o * 10;
+		q[0] = D.order[o]; q[1] = D.mult[o]; q[2] = D.ninterv[o]; q[3] = D.d[o]; q[4] = D.iC[o]; q[5] = D.iz[o];
+		q[6] = D.cls[o] * NTG_MAX_ORDER; q[7] = D.cls[o] * D.P; q[8] = D.cls_W[D.cls[o]]; q[9] = D.ncoef[o];
+	}
+	for (int v = tid; v < D.nz; v += NT) S.tavrow[v] = D.tav_row[v];
+	for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;   // padding target of the column form
+	if (D.q_use) {
+		for (int i = tid; i < D.nC; i += NT) S.q_idx[i] = T.q_idx[i];
+		for (int i = tid; i < D.q_nt * D.q_w; i += NT) { S.q_col[i] = T.q_col[i]; S.q_val[i] = T.q_val[i]; }
+	}
+}
+
+// Z = M C at one breakpoint for the declared active variables (colloc.c:318-326,344-367);
+// entries that are not active stay 0 like the reference's calloc'd GZ (ntg.c:119).
+template <int NOUT, int K, int DM>
+__device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const double *sx, int bp,
+                                          u64 mask, double *z)
+{
+	const int nout = NOUT > 0 ? NOUT : D.nout, P = D.P;
+	if (NOUT > 0 && K > 0 && DM > 3 && D.uniform) {
+		// one basis class, compile-time order, many derivatives: the coefficients of one output stay in
+		// registers while its active derivative rows stream from LDS (keeping all DM rows would not fit)
+		constexpr int KK = K > 0 ? K : 1;
+		const int ofs = S.off[bp], nco = D.ncoef[0];
+#pragma unroll
+		for (int o = 0; o < (NOUT > 0 ? NOUT : 1); o++) {
+			const double *cx = sx + o * nco + ofs;
+			double xv[KK];
+#pragma unroll
+			for (int q = 0; q < KK; q++) xv[q] = cx[q];
+#pragma unroll
+			for (int r = 0; r < DM; r++) {
+				double acc = 0.0;
+				const int ch = S.chrow[r];
+				if (((mask >> (DM * o + r)) & 1ull) && ch >= 0) {   // wave-uniform
+#pragma unroll
+					for (int q = 0; q < KK; q++) acc += S.rowv[ch + q * P + bp] * xv[q];
+				}
+				z[DM * o + r] = acc;
+			}
+		}
+		return;
+	}
+	if (NOUT > 0 && K > 0 && D.uniform) {
+		// one basis class, compile-time order, maxderiv == 3: the rows of the active derivative
+		// channels at this breakpoint are read once into registers and reused by every output
+		constexpr int KK = K > 0 ? K : 1;
+		double b[3][KK];
+#pragma unroll
+		for (int r = 0; r < 3; r++) {
+			const int ch = S.chrow[r];
+			if (ch >= 0) {                                   // wave-uniform
+#pragma unroll
+				for (int q = 0; q < KK; q++) b[r][q] = S.rowv[ch + q * P + bp];
+			} else {
+#pragma unroll
+				for (int q = 0; q < KK; q++) b[r][q] = 0.0;
+			}
+		}
+		const int ofs = S.off[bp], nco = D.ncoef[0];
+#pragma unroll
+		for (int o = 0; o < (NOUT > 0 ? NOUT : 1); o++) {
+			const double *cx = sx + o * nco + ofs;
+			double xv[KK];
+#pragma unroll
+			for (int q = 0; q < KK; q++) xv[q] = cx[q];
+#pragma unroll
+			for (int r = 0; r < 3; r++) {
+				double acc = 0.0;
+				if ((mask >> (3 * o + r)) & 1ull) {           // wave-uniform
+#pragma unroll
+					for (int q = 0; q < KK; q++) acc += b[r][q] * xv[q];
+				}
+				z[3 * o + r] = acc;
+			}
+		}
+		return;
+	}
+#pragma unroll
+	for (int o = 0; o < nout; o++) {
+		const int k = D.order[o], c = D.cls[o];
+		const int d = NOUT > 0 ? DM : D.d[o], iz = NOUT > 0 ? DM * o : D.iz[o];
+		const double *cx = sx + D.iC[o] + S.off[c * P + bp];
+#pragma unroll
+		for (int r = 0; r < (NOUT > 0 ? DM : NTG_MAX_ORDER); r++) {
+			if (r >= d) break;
+			double acc = 0.0;
+			if ((mask >> (iz + r)) & 1ull) {
+				const double *rv = S.rowv + S.chrow[c * NTG_MAX_ORDER + r] + bp;
+				for (int q = 0; q < k; q++) acc += rv[q * P] * cx[q];
+			}
+			z[iz + r] = acc;
+		}
+	}
+}
+
+// which coefficients a lane owns (c = tid + e*NT) and where their column-form data sit: decoded
+// once per kernel, kept in registers for every evaluation of the solve
+template <int EPT>
+struct CoefMap {
+	int o[EPT], cl[EPT];   // output and local coefficient index of slot e (c = tid + e*NT), o = -1: no coefficient
+};
+template <int NT, int EPT>
+__device__ __forceinline__ void make_coefmap(const NtgDims &D, const Smem &S, CoefMap<EPT> &cm)
+{
+#pragma unroll
+	for (int e = 0; e < EPT; e++) {
+		const int c = threadIdx.x + e * NT;
+		cm.o[e] = -1; cm.cl[e] = 0;
+		if (c < D.nC) {
+			int o = 0;
+			while (o + 1 < D.nout && D.iC[o + 1] <= c) o++;
+			cm.o[e] = o; cm.cl[e] = c - D.iC[o];
+		}
+	}
+}
+
+// Augmented-Lagrangian state of one problem: with mu > 0 the evaluation returns
+//   F_A = F + sum_j (t_j^2 - lam_j^2)/(2 mu),  t_j = mu (v_j - clamp(v_j, bl_j, bu_j)),  v_j = c_j + lam_j/mu
+// and its gradient g + J' t; t (the next multiplier estimate) is written to tnew.  mu == 0: plain F.
+struct ALState {
+	double mu;
+	const double *lam;   // [ncnln] current multipliers (HBM)
+	double *tnew;        // [ncnln] multiplier estimates of the last evaluation (HBM)
+	const double *lo, *up; // this problem's rows of lowerb/upperb [nbounds]
+};
+
+// per-breakpoint cost functor pass: Z = M C, then ucf/icf/fcf -> fvals, dfz, dfi, dff in LDS
+template <int FAM, int NOUT, int K, int NT>
+__device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx, const ALState &al,
+                                            double &psi, double &rv2)
+{
+	using Fam = Family<FAM>;
+	constexpr int DM = Fam::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
+	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
+	const int tid = threadIdx.x;
+	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
+	constexpr int NI = Fam::NNLIC > 0 ? Fam::NNLIC : 1, NTc = Fam::NNLTC > 0 ? Fam::NNLTC : 1, NF = Fam::NNLFC > 0 ? Fam::NNLFC : 1;
+	const bool alon = HASCON && al.mu > 0.0;
+	const int b0 = D.nlic + D.nltc + D.nlfc;   // first nonlinear slot of lowerb/upperb
+	psi = 0.0; rv2 = 0.0;
+	// one constraint value -> AL term, violation, multiplier estimate; returns t
+	auto al_term = [&](double cj, int row, int slot) -> double {
+		const double lamj = al.lam[row], l = al.lo[slot], u = al.up[slot];
+		const double v = cj + lamj / al.mu;
+		const double pj = v < l ? l : (v > u ? u : v), cc = cj < l ? l : (cj > u ? u : cj);
+		const double t = al.mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
+		psi += (t - lamj) * (t + lamj) / (2.0 * al.mu);   // factored: no cancellation when c is tiny
+		rv2 += rj * rj;
+		al.tnew[row] = t;
+		return t;
+	};
+	lds_sync(); // sx complete, previous users of dfz/fvals done
+	if ((D.nucf || (alon && D.nnltc))) {
+		const u64 zmask = alon ? (D.tcost_mask | D.tcon_mask) : D.tcost_mask;
+		for (int i = tid; i < P; i += NT) {                       // cost.c:103-109
+			double z[NZ], df[NZ], f = 0.0;
+			compute_z<NOUT, K, DM>(D, S, sx, i, zmask, z);
+			if (D.nucf) Fam::ucf(nout, i, z, f, df);
+			else {
+#pragma unroll
+				for (int v = 0; v < NZ; v++) df[v] = 0.0;
+			}
+			S.fvals[i] = f;
+			const double w = S.wts[i];
+#pragma unroll
+			for (int v = 0; v < NZ; v++) df[v] *= w;
+			if (HASCON && alon && D.nnltc) {                      // constraints.c:148-155 folded into the same pass
+				double c[NTc], t[NTc];
+				Fam::template nltc_val<NZ>(nout, i, z, c);
+#pragma unroll
+				for (int j = 0; j < NTc; j++) t[j] = j < D.nnltc ? al_term(c[j], D.nnlic + j * P + i, b0 + D.nnlic + j) : 0.0;
+				Fam::template nltc_vjp<NZ>(nout, nz, i, z, t, df);   // df += J' t, constraint-major like the dense loop
+			}
+#pragma unroll
+			for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = df[v]; }
+		}
+	}
+	if ((D.nicf || (alon && D.nnlic)) && tid == 0) {              // cost.c:4-36, constraints.c:88-117
+		double z[NZ], df[NZ], f = 0.0;
+		compute_z<NOUT, K, DM>(D, S, sx, 0, alon ? (D.icost_mask | D.icon_mask) : D.icost_mask, z);
+		if (D.nicf) Fam::icf(nout, z, f, df); else for (int v = 0; v < nz; v++) df[v] = 0.0;
+		if (HASCON && alon && D.nnlic) {
+			double c[NI], dc[NI * NZ];
+			Fam::nlicf(nout, z, c, dc);
+			for (int j = 0; j < D.nnlic; j++) { const double t = al_term(c[j], j, b0 + j); for (int v = 0; v < nz; v++) df[v] += t * dc[j * nz + v]; }
+		}
+		for (int v = 0; v < nz; v++) S.dfi[v] = df[v];
+		S.dfi[nz] = f;
+	}
+	if ((D.nfcf || (alon && D.nnlfc)) && tid == (NT > 64 ? 64 : 0)) {   // cost.c:141-174, constraints.c:165-195
+		double z[NZ], df[NZ], f = 0.0;
+		compute_z<NOUT, K, DM>(D, S, sx, P - 1, alon ? (D.fcost_mask | D.fcon_mask) : D.fcost_mask, z);
+		if (D.nfcf) Fam::fcf(nout, z, f, df); else for (int v = 0; v < nz; v++) df[v] = 0.0;
+		if (HASCON && alon && D.nnlfc) {
+			double c[NF], dc[NF * NZ];
+			Fam::nlfcf(nout, z, c, dc);
+			for (int j = 0; j < D.nnlfc; j++) { const double t = al_term(c[j], D.nnlic + D.nnltc * P + j, b0 + D.nnlic + D.nnltc + j); for (int v = 0; v < nz; v++) df[v] += t * dc[j * nz + v]; }
+		}
+		for (int v = 0; v < nz; v++) S.dff[v] = df[v];
+		S.dff[nz] = f;
+	}
+}
+
+// quadrature + banded gradient assembly from the per-breakpoint values in LDS (fvals, dfz,
+// dfi, dff); shared by the device-functor path and the host-callback path of ntg()
+template <int NOUT, int K, int NT, int DM, int EPT>
+__device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<EPT> &cm,
+                                              bool hasI, bool hasF, double psi, double rv2, double *Fpure, double *rv2_out)
+{
+	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
+	const int tid = threadIdx.x;
+	lds_sync();
+	// trapezoid of the running cost (integrator.c:21-24); per-interval terms across the lanes,
+	// wavefront reduction
+	double acc[4] = {0.0, 0.0, psi, rv2};
+	if (D.nucf)
+		for (int i = tid; i < P - 1; i += NT)
+			acc[0] += (S.bps[i + 1] - S.bps[i]) * (S.fvals[i + 1] + S.fvals[i]) / 2;
+	// gradient: the reference integrates the dense nbps x nC matrix column by column
+	// (cost.c:117-134, integrator.c:44-48); here every lane owns a coefficient and takes the same
+	// sum node-wise, g[c] = sum_s colv[c][s] * (w_i df_i)[coli[c][s]], over the non-zeros of column c
+	// of the collocation matrix only.  The column form is s-major ([s][cl]): lanes with consecutive
+	// coefficients read consecutive LDS words.
+	if (NOUT > 0 && !hasI && !hasF) {
+		// all (breakpoint, block column) pairs of a column are read first, then all values and
+		// weighted gradients, then the FMAs: two LDS round trips per coefficient, independent of W
+		auto gather = [&](auto Wtag) {
+			constexpr int W = decltype(Wtag)::value;   // 0: run-time width
+#pragma unroll
+			for (int e = 0; e < EPT; e++) {
+				const int c = tid + e * NT;
+				if (c >= D.nC) break;
+				double dIn = 0.0;
+				const int o = cm.o[e], cl = cm.cl[e];
+				const int *oi = S.oinfo + o * 10;
+				const int chb = oi[6], nc = oi[9], Wr = oi[8];
+#pragma unroll
+				for (int r = 0; r < DM; r++) {
+					if (!((D.tav_rmask >> r) & 1)) continue;                 // wave-uniform
+					const int row = S.tavrow[DM * o + r], chc = S.chcol[chb + r];
+					if (row < 0 || chc < 0) continue;
+					const double *rv = S.rowv + S.chrow[chb + r]; const double *wdf = S.dfz + row * (P + 1);
+					if (W > 0) {
+						// W packed entries of this column, contiguous and 16-byte aligned: read as uint4
+						const uint4 *cp4 = (const uint4 *)(S.colp + chc + cl * Wr);
+						unsigned int pe[W > 0 ? W : 4];
+#pragma unroll
+						for (int s4 = 0; s4 < W / 4; s4++) { const uint4 t4 = cp4[s4]; pe[4 * s4] = t4.x; pe[4 * s4 + 1] = t4.y; pe[4 * s4 + 2] = t4.z; pe[4 * s4 + 3] = t4.w; }
+						double vv[W > 0 ? W : 1], ww[W > 0 ? W : 1];
+#pragma unroll
+						for (int s2 = 0; s2 < W; s2++) { vv[s2] = rv[pe[s2] >> 16]; ww[s2] = wdf[pe[s2] & 0xffffu]; }
+#pragma unroll
+						for (int s2 = 0; s2 < W; s2++) dIn += vv[s2] * ww[s2];
+					} else {
+						const unsigned int *cp = S.colp + chc + cl * Wr;
+						for (int s2 = 0; s2 < Wr; s2++) { const unsigned int pe = cp[s2]; dIn += rv[pe >> 16] * wdf[pe & 0xffffu]; }
+					}
+				}
+				sg[c] = dIn;
+				acc[1] += dIn * dIn;
+				__builtin_amdgcn_sched_barrier(0);   // keep the slots sequential: their temporaries share registers
+			}
+		};
+		const int W4 = D.uniform ? D.cls_W[0] : 1000;
+		if (W4 == 8) gather(std::integral_constant<int, 8>());
+		else if (W4 == 12) gather(std::integral_constant<int, 12>());
+		else if (W4 == 16) gather(std::integral_constant<int, 16>());
+		else gather(std::integral_constant<int, 0>());
+	} else {
+		for (int c = tid; c < D.nC; c += NT) {
+			int o = 0;
+			while (o + 1 < nout && S.oinfo[(o + 1) * 10 + 4] <= c) o++;
+			const int *oi = S.oinfo + o * 10;
+			const int k = oi[0], d = oi[3], iz = oi[5], cl = c - oi[4], chb = oi[6], W4 = oi[8], nc = oi[9];
+			const int *coff = S.off + oi[7];
+			double dI = 0.0, dIn = 0.0, dF = 0.0;
+			for (int r = 0; r < d; r++) {
+				const int row = S.tavrow[iz + r], chc = S.chcol[chb + r], chr = S.chrow[chb + r];
+				if (row >= 0 && chc >= 0) {
+					const unsigned int *cp = S.colp + chc + cl * W4; const double *wdf = S.dfz + row * (P + 1);
+					for (int s = 0; s < W4; s++) { const unsigned int pe = cp[s]; dIn += S.rowv[chr + (pe >> 16)] * wdf[pe & 0xffffu]; }
+				}
+				if (chr >= 0) {
+					if (hasI && cl < k) dI += S.dfi[iz + r] * S.rowv[chr + cl * P];                // colloc.c:243-260 (block 0)
+					const int ol = coff[P - 1];
+					if (hasF && cl >= ol && cl < ol + k) dF += S.dff[iz + r] * S.rowv[chr + (cl - ol) * P + P - 1];   // colloc.c:287-316
+				}
+			}
+			const double g = dI + dIn + dF;                       // Vector3Add (matrix.c:177)
+			sg[c] = g;
+			acc[1] += g * g;
+		}
+	}
+	block_sum<NT, 4>(acc, S.red);
+	const double I = D.nicf ? S.dfi[nz] : 0.0, Ff = D.nfcf ? S.dff[nz] : 0.0;
+	*gnorm2 = acc[1];
+	const double Fp = I + acc[0] + Ff;                            // ntg.c:328
+	if (Fpure) *Fpure = Fp;
+	if (rv2_out) *rv2_out = acc[3];
+	return Fp + acc[2];
+}
+
+// NPfunobj (ntg.c:274-335): F and the full gradient into LDS vector sg.  Returns F; *gnorm2
+// receives |g|^2.  Every lane of the workgroup must call it (it contains barriers).
+template <int FAM, int NOUT, int K, int NT, int EPT>
+__device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
+                                            const CoefMap<EPT> &cm, const ALState &al, double *Fpure = nullptr,
+                                            double *rv2_out = nullptr, unsigned long long *tk = nullptr)
+{
+	using Fam = Family<FAM>;
+	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
+	const bool alon = HASCON && al.mu > 0.0;
+	unsigned long long t0 = 0;
+	if (tk) t0 = __builtin_amdgcn_s_memtime();
+	double psi, rv2;
+	cost_phase1<FAM, NOUT, K, NT>(D, S, sx, al, psi, rv2);
+	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
+	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
+	                                          psi, rv2, Fpure, rv2_out);
+	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
+	return F;
+}
+
+// NPfuncon (ntg.c:337-371, constraints.c:36-195): residuals and banded Jacobian rows straight
+// to HBM.  Row order [initial; trajectory constraint-major x breakpoint; final].
+template <int FAM, int NOUT, int K, int NT>
+__device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S, const double *sx, int mode,
+                                 double *c_out, double *jband, double *cjac)
+{
+	using Fam = Family<FAM>;
+	constexpr int DM = Fam::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
+	constexpr int NI = Fam::NNLIC > 0 ? Fam::NNLIC : 1, NTc = Fam::NNLTC > 0 ? Fam::NNLTC : 1, NF = Fam::NNLFC > 0 ? Fam::NNLFC : 1;
+	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz, tid = threadIdx.x;
+	auto emit_row = [&](int row, int bp, const double *dcrow) {
+		for (int o = 0; o < nout; o++) {
+			const int k = D.order[o], cc = D.cls[o], d = D.d[o];
+			const int col0 = D.iC[o] + S.off[cc * P + bp];
+			for (int q = 0; q < k; q++) {
+				double a = 0.0;
+				for (int r = 0; r < d; r++) {
+					const int chr = S.chrow[cc * NTG_MAX_ORDER + r];
+					if (chr >= 0) a += dcrow[D.iz[o] + r] * S.rowv[chr + q * P + bp];
+				}
+				if (jband) jband[(size_t)row * D.sumk + D.koff[o] + q] = a;
+				if (cjac) cjac[(size_t)(col0 + q) * D.ncnln + row] = a;
+			}
+		}
+	};
+	if (Fam::NNLIC > 0 && D.nnlic && tid == 0) {
+		double z[NZ], c[NI], dc[NI * NZ];
+		compute_z<NOUT, K, DM>(D, S, sx, 0, D.icon_mask, z);
+		Fam::nlicf(nout, z, c, dc);
+		for (int j = 0; j < D.nnlic; j++) {
+			if (c_out && mode != 1) c_out[j] = c[j];
+			if (mode != 0) emit_row(j, 0, dc + j * nz);
+		}
+	}
+	if (Fam::NNLTC > 0 && D.nnltc) {
+		for (int i = tid; i < P; i += NT) {
+			double z[NZ], c[NTc], dc[NTc * NZ];
+			compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
+			Fam::nltcf(nout, i, z, c, dc);
+			for (int j = 0; j < D.nnltc; j++) {
+				const int row = D.nnlic + j * P + i;              // constraints.c:139,153
+				if (c_out && mode != 1) c_out[row] = c[j];
+				if (mode != 0) emit_row(row, i, dc + j * nz);
+			}
+		}
+	}
+	if (Fam::NNLFC > 0 && D.nnlfc && tid == (NT > 64 ? 64 : 0)) {
+		double z[NZ], c[NF], dc[NF * NZ];
+		compute_z<NOUT, K, DM>(D, S, sx, P - 1, D.fcon_mask, z);
+		Fam::nlfcf(nout, z, c, dc);
+		for (int j = 0; j < D.nnlfc; j++) {
+			const int row = D.nnlic + D.nnltc * P + j;
+			if (c_out && mode != 1) c_out[row] = c[j];
+			if (mode != 0) emit_row(row, P - 1, dc + j * nz);
+		}
+	}
+}
+
+// Persistent workgroups stride over the batch; tables are staged once per workgroup.
+template <int FAM, int NOUT, int K, int NT, int EPT>
+__global__ void __launch_bounds__(NT, NTG_EVAL_WAVES)
+eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const double *__restrict__ x,
+            double *__restrict__ f, double *__restrict__ g, double *__restrict__ c,
+            double *__restrict__ jband, double *__restrict__ cjac)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	Smem S(smem_raw, L, D, T);
+	stage_tables<NT>(D, T, S, smem_raw, L);
+	double *sg = S.x;   // the gradient is assembled (owner lanes, after the last read of x) into the x buffer
+	lds_sync();
+	CoefMap<EPT> cm;
+	if (NOUT > 0) make_coefmap<NT, EPT>(D, S, cm);   // the host only picks a NOUT > 0 instance when nC <= EPT NT
+	// software pipeline over problems: the coefficient vector of the NEXT problem is already in
+	// flight (registers) while the current one is evaluated
+	constexpr int XE = EPT;
+	const bool xreg = D.nC <= XE * NT;
+	double xn[XE];
+	if (xreg && (int)blockIdx.x < batch) {
+#pragma unroll
+		for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; xn[e] = i < D.nC ? x[(size_t)blockIdx.x * D.nC + i] : 0.0; }
+	}
+	for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+		lds_sync();
+		if (xreg) {
+#pragma unroll
+			for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; if (i < D.nC) S.x[i] = xn[e]; }
+			const int bn = b + gridDim.x;
+			if (bn < batch) {
+#pragma unroll
+				for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; xn[e] = i < D.nC ? x[(size_t)bn * D.nC + i] : 0.0; }
+			}
+		} else {
+			for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
+		}
+		if (D.ncnln && (c || jband || cjac)) {   // constraints first: they still need x, the cost pass overwrites it with g
+			lds_sync();
+			eval_constraints<FAM, NOUT, K, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
+			                                jband ? jband + (size_t)b * D.ncnln * D.sumk : nullptr,
+			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr);
+		}
+		double gn2;
+		const double F = eval_cost<FAM, NOUT, K, NT, EPT>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr});
+		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
+		if (g && mode != 0)
+			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// SQP pieces
+// ------------------------------------------------------------------------------------------
+// gp = g - A'(AA')^-1 A g  (projection onto null(A)); S.lam receives the multipliers estimate.
+// A is kept sparse (CSR for A g, CSC for A' lam); (AA')^-1 is a small dense matrix.
+template <int NT, bool BIG>
+__device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */)
+{
+	const int m = D.nclin, tid = threadIdx.x;
+	if (BIG) __syncthreads();   // g lives in HBM/L2 and is read across lanes
+	else lds_sync();
+	if (m == 0) { for (int c = tid; c < D.nC; c += NT) sgp[c] = sg[c]; lds_sync(); return; }
+	if (D.q_use) {
+		// gp = g - Q g with Q = A'(AA')^-1 A stored as ELL over its non-zero rows: one pass, no
+		// intermediate barrier; the padded entries (value 0, column 0) keep every load unconditional
+		const int w = D.q_w;
+		for_vec<NT>(D.nC, [&](int c) {
+			const int t = S.q_idx[c];
+			double s = 0.0;
+			if (t >= 0) {
+#pragma unroll 4
+				for (int e = 0; e < w; e++) s += S.q_val[t * w + e] * sg[S.q_col[t * w + e]];
+			}
+			sgp[c] = sg[c] - s;
+		});
+		lds_sync();
+		return;
+	}
+	for (int r = tid; r < m; r += NT) {
+		double a = 0.0;
+		for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
+		tmp[r] = a;
+	}
+	lds_sync();
+	for (int r = tid; r < m; r += NT) {
+		double a = 0.0;
+		for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
+		S.lam[r] = a;
+	}
+	lds_sync();
+	for (int c = tid; c < D.nC; c += NT) {
+		double s = 0.0;
+		for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * S.lam[S.csc_row[e]];
+		sgp[c] = sg[c] - s;
+	}
+	lds_sync();
+}
+
+// out = W0 v for the collocation preconditioner (ELL, rows streamed from L2).  Kept out of line:
+// it runs a handful of times per solve and must not add to the register pressure of the main loop.
+template <int NT>
+__device__ __attribute__((noinline)) void apply_n0(int n, int w, const double *__restrict__ n0,
+                                                   const unsigned short *__restrict__ n0c, const double *v, double *out)
+{
+	for (int c = threadIdx.x; c < n; c += NT) {
+		double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+		int s = 0;
+		for (; s + 4 <= w; s += 4) {   // four independent chains: the L2 loads of a row overlap
+			a0 += n0[(size_t)(s + 0) * n + c] * v[n0c[(size_t)(s + 0) * n + c]];
+			a1 += n0[(size_t)(s + 1) * n + c] * v[n0c[(size_t)(s + 1) * n + c]];
+			a2 += n0[(size_t)(s + 2) * n + c] * v[n0c[(size_t)(s + 2) * n + c]];
+			a3 += n0[(size_t)(s + 3) * n + c] * v[n0c[(size_t)(s + 3) * n + c]];
+		}
+		for (; s < w; s++) a0 += n0[(size_t)s * n + c] * v[n0c[(size_t)s * n + c]];
+		out[c] = (a0 + a1) + (a2 + a3);
+	}
+}
+
+// out = W0 v : identity on null(A) (cold start) or the collocation preconditioner
+template <int NT, bool BIG>
+__device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out)
+{
+	if (BIG) __syncthreads();   // v lives in HBM/L2 and apply_n0 reads it across lanes
+	else lds_sync();
+	if (hessian == 1 && T.n0) apply_n0<NT>(D.nC, T.n0_w, T.n0, T.n0c, v, out);
+	else for_vec<NT>(D.nC, [&](int c) { out[c] = v[c]; });
+	lds_sync();
+}
+
+// t += (sum of the stored rank-2 BFGS terms) v.  Pairs are streamed from HBM/L2 once, G at a
+// time: 2G partial dots per lane, ONE workgroup reduction, then the axpys from the registers
+// that still hold the pair elements.
+template <int NT>
+__device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, const double *hist, int npairs,
+                              const double *v, double *t)
+{
+	constexpr int G = NTG_HIST_G, EPT = 3;
+	const int n = D.nC, tid = threadIdx.x;
+	if (n <= EPT * NT) {
+		double vv[EPT], tt[EPT];
+#pragma unroll
+		for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; vv[e] = c < n ? v[c] : 0.0; tt[e] = c < n ? t[c] : 0.0; }
+		for (int base = 0; base < npairs; base += G) {
+			const int cnt = min(G, npairs - base);
+			double hs[G][EPT], hu[G][EPT], acc[2 * G];
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				acc[2 * g] = 0.0; acc[2 * g + 1] = 0.0;
+				const double *h = hist + (size_t)(base + g) * (2 * n + 2);
+#pragma unroll
+				for (int e = 0; e < EPT; e++) {
+					const int c = tid + e * NT;
+					const bool on = g < cnt && c < n;
+					hs[g][e] = on ? h[c] : 0.0;
+					hu[g][e] = on ? h[n + c] : 0.0;
+				}
+			}
+#pragma unroll
+			for (int g = 0; g < G; g++)
+#pragma unroll
+				for (int e = 0; e < EPT; e++) { acc[2 * g] += hs[g][e] * vv[e]; acc[2 * g + 1] += hu[g][e] * vv[e]; }
+			block_sum<NT, 2 * G>(acc, S.red);
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				if (g < cnt) {
+					const double *hh = hist + (size_t)(base + g) * (2 * n + 2) + 2 * n;
+					const double rho = hh[0], c2 = hh[1];
+#pragma unroll
+					for (int e = 0; e < EPT; e++)
+						tt[e] += -rho * (hs[g][e] * acc[2 * g + 1] + hu[g][e] * acc[2 * g]) + c2 * hs[g][e] * acc[2 * g];
+				}
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; if (c < n) t[c] = tt[e]; }
+		lds_sync();
+		return;
+	}
+	for (int base = 0; base < npairs; base += 4) {
+		const int cnt = min(4, npairs - base);
+		double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+		for (int c = tid; c < n; c += NT) {
+			const double vv = v[c];
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				if (g < cnt) {
+					const double *h = hist + (size_t)(base + g) * (2 * n + 2);
+					acc[2 * g] += h[c] * vv;
+					acc[2 * g + 1] += h[n + c] * vv;
+				}
+			}
+		}
+		block_sum<NT, 8>(acc, S.red);
+		for (int c = tid; c < n; c += NT) {
+			double tt = t[c];
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				if (g < cnt) {
+					const double *h = hist + (size_t)(base + g) * (2 * n + 2);
+					const double s = h[c], u = h[n + c], rho = h[2 * n], c2 = h[2 * n + 1];
+					tt += -rho * (s * acc[2 * g + 1] + u * acc[2 * g]) + c2 * s * acc[2 * g];
+				}
+			}
+			t[c] = tt;
+		}
+	}
+	lds_sync();
+}
+
+// One workgroup solves one problem from start to finish (ntg.c:250: the npsol_ call).
+// The loop below has ONE evaluation site (funobj + projection at the trial point sxt); what the
+// result means is decided by `state`: the first evaluation, a line-search trial, a forced
+// acceptance, or the final multiplier estimate.  One site keeps the assembly code inlined once
+// and the register state (coefficient map, line search) out of scratch.
+// BIG: the coefficient vectors no longer fit in LDS next to the tables (config E: nC = 2196).  Only the trial point
+// (read across lanes by Z = M C at every evaluation) stays in LDS; x, gp, gp+, d and g live in a per-problem HBM/L2
+// workspace `vec_all`.  They are touched element-wise by their owner lane, except in the projection, the feasibility
+// step and the preconditioner, which read a handful of entries across lanes behind a full barrier.
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG>
+__global__ void __launch_bounds__(NT, NTG_SQP_WAVES)
+sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
+           const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
+           double *__restrict__ objective, int *__restrict__ inform_out, int *__restrict__ iters_out,
+           int *__restrict__ nfev_out, double *__restrict__ clambda, double *__restrict__ hist_all,
+           double *__restrict__ al_all, double *__restrict__ vec_all)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	Smem S(smem_raw, L, D, T);
+	const int b = blockIdx.x, tid = threadIdx.x, n = D.nC, m = D.nclin, P = D.P;
+	if (b >= batch) return;
+	const int npad = (n + 1) & ~1;
+	double *gv = BIG ? vec_all + (size_t)b * 5 * npad : nullptr;
+	double *sx = BIG ? gv : S.x, *sxt = S.vecs, *sgp = BIG ? gv + npad : S.vecs + npad,
+	       *sgpt = BIG ? gv + 2 * npad : S.vecs + 2 * npad, *sd = BIG ? gv + 3 * npad : S.vecs + 3 * npad,
+	       *st = sxt /* t = W gp+ lives in the trial-point buffer once x is committed */,
+	       *sg = BIG ? gv + 4 * npad : S.vecs + 4 * npad, *tmp = S.vecs + (BIG ? 1 : 5) * npad;
+	double *hist = hist_all + (size_t)b * sp.memcap * (2 * n + 2);   // pair i: [s (n) | u (n) | rho | c2]
+	stage_tables<NT>(D, T, S, smem_raw, L);
+	for (int i = tid; i < n; i += NT) sx[i] = xio[(size_t)b * n + i];
+	lds_sync();
+	CoefMap<EPT> cm;
+	if (NOUT > 0) make_coefmap<NT, EPT>(D, S, cm);
+
+	enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3, ST_REEVAL = 4 };
+	using Fam = Family<FAM>;
+	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
+	const int ncn = D.ncnln;
+	// augmented-Lagrangian state (nonlinear constraints): multipliers and their estimates live in HBM
+	double *al_lam = al_all + (size_t)b * 2 * ncn, *al_t = al_lam + ncn;
+	ALState al{(HASCON && ncn > 0) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
+	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
+	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history / rest
+	unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define NTG_STAMP(slot) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot] += now_ - tlast; tlast = now_; } } while (0)
+	if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
+	// ---- scope check (uniform): linear equalities only ----
+	{
+		double bad[1] = {0.0};
+		for (int s = tid; s < D.nlic + D.nltc + D.nlfc; s += NT)      // linear rows must be equalities
+			if (lower[(size_t)b * D.nbounds + s] != upper[(size_t)b * D.nbounds + s]) bad[0] += 1.0;
+		block_sum<NT, 1>(bad, S.red);
+		if (bad[0] != 0.0 || (ncn > 0 && (!HASCON || sp.fixed_iters))) inform = 9;
+	}
+	double F = 0.0, Fp = 0.0, gn2 = 0.0, rv2 = 0.0, alpha = 0.0, pnorm = 0.0;
+	double sri = sp.sr, rvprev = HUGE_VAL;   // inner tolerance and best violation so far (AL outer loop)
+	int outer = 0, inner_inform = 4;
+	bool at_x = true, weak = false;
+	double mfres = 0.0;   // diagnostic: linear residual seen by the last feasibility step
+	if (inform != 9) {
+		// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
+		auto make_feasible = [&]() {
+			if (m <= 0) return;
+			if (BIG) __syncthreads();   // x lives in HBM/L2 and the rows of A read it across lanes
+			else lds_sync();
+			for (int r = tid; r < m; r += NT) {
+				int s;
+				if (r < D.nlic) s = r;
+				else if (r < D.nlic + D.nltc * P) s = D.nlic + (r - D.nlic) / P;
+				else s = D.nlic + D.nltc + (r - D.nlic - D.nltc * P);
+				double a = 0.0;
+				for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sx[S.csr_col[e]];
+				tmp[r] = lower[(size_t)b * D.nbounds + s] - a;
+			}
+			lds_sync();
+			if (sp.stamps == 2) { mfres = 0.0; for (int r = 0; r < m; r++) mfres = fmax(mfres, fabs(tmp[r])); }
+			for (int r = tid; r < m; r += NT) {
+				double a = 0.0;
+				for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
+				tmp[m + r] = a;   // not S.lam: that holds the multiplier estimate reported in clambda
+			}
+			lds_sync();
+			for (int c = tid; c < n; c += NT) {
+				double s = 0.0;
+				for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * tmp[m + S.csc_row[e]];
+				sx[c] += s;
+			}
+			lds_sync();
+		};
+		make_feasible();
+		for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+		if (al.mu > 0.0) {
+			for (int j = tid; j < ncn; j += NT) al_lam[j] = 0.0;
+			sri = fmax(sp.sr, 1e-3);
+			__syncthreads();   // multipliers cross lanes through HBM: full barrier
+		}
+		NTG_STAMP(0);
+
+		// line-search state lives in LDS (17 doubles would otherwise sit in every lane's registers);
+		// each step works on a register copy and lane 0 publishes it back between two barriers
+		LineSearch *lsm = (LineSearch *)(smem_raw + L.ls);
+		double r4[4] = {0, 0, 0, 0};   // gp.d, d.d, x.x, gp.gp of the current iterate
+		bool finished = false;
+		for (;;) {
+			// ================= the one evaluation site =================
+			double gn2n, Fpn, rv2n;
+			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr);
+			NTG_STAMP(1);
+			if (state == ST_FINAL) {
+				// multipliers estimate lam = (AA')^-1 A g at the final point
+				if (BIG) __syncthreads(); else lds_sync();
+				for (int r = tid; r < m; r += NT) {
+					double a = 0.0;
+					for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sg[S.csr_col[e]];
+					tmp[r] = a;
+				}
+				lds_sync();
+				for (int r = tid; r < m; r += NT) {
+					double a = 0.0;
+					for (int e = S.sinv_ptr[r]; e < S.sinv_ptr[r + 1]; e++) a += S.sinv_val[e] * tmp[S.sinv_col[e]];
+					S.lam[r] = a;
+				}
+				lds_sync();
+				break;
+			}
+			nfev++;
+			bool new_major = false;
+			if (state == ST_REEVAL) {   // constraint values and multiplier estimates refreshed at x
+				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
+			} else {
+			project<NT, BIG>(D, S, sg, sgpt, tmp);
+			NTG_STAMP(2);
+			if (state == ST_INIT) {
+				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
+				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
+				apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd);
+				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
+				for_vec<NT>(n, [&](int c) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; });
+				block_sum<NT, 4>(r4, S.red);
+				NTG_STAMP(4);
+				new_major = true;
+			} else {
+				int rc = 1;
+				if (state == ST_LS) {
+					double dd[1] = {0.0};
+					for_vec<NT>(n, [&](int c) { dd[0] += sgpt[c] * (-sd[c]); });
+					block_sum<NT, 1>(dd, S.red);
+					LineSearch lsr = *lsm;
+					rc = lsr.step(Fn, dd[0]);
+					lds_sync();
+					if (tid == 0) *lsm = lsr;
+					lds_sync();
+				}
+				if (rc == 0 || rc == 2) {
+					if (rc == 2) state = ST_FORCE;
+					const double a = lsm->a;
+					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * (-sd[c]); });
+					NTG_STAMP(5);
+					continue;
+				}
+				if (rc != 1) {
+					const double tolg = sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+					if (npairs > 0 && sqrt(r4[3]) > tolg) {
+						// line search failed with a non-trivial W: drop the pairs and retry from the same point with W0
+						npairs = 0;
+						apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd);
+						double r2[2] = {0, 0};
+						for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
+						block_sum<NT, 2>(r2, S.red);
+						r4[0] = r2[0]; r4[1] = r2[1];
+						new_major = true;
+					} else {
+						// no further decrease obtainable: converged within tolerance, or "optimal but not to the
+						// requested accuracy" (NPSOL inform 1) within 10^3 of it, else failure (6)
+						const double gpn0 = sqrt(r4[3]);
+						if (gpn0 <= tolg) inner_inform = 0;
+						else if (gpn0 <= 1e3 * tolg) { inner_inform = 0; weak = true; }
+						else inner_inform = 6;
+						finished = true; at_x = false;
+					}
+				} else {
+					alpha = lsm->a;
+					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
+					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
+					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd); } // memory full: restart
+					NTG_STAMP(5);
+					apply_w0<NT, BIG>(D, T, sp.hessian, sgpt, st);
+					NTG_STAMP(4);
+					apply_history<NT>(D, S, hist, npairs, sgpt, st);
+					NTG_STAMP(3);
+					double r6[6] = {0, 0, 0, 0, 0, 0};
+					for_vec<NT>(n, [&](int c) {
+						const double s = sg[c], y = sgpt[c] - sgp[c], u = st[c] - sd[c], gpn = sgpt[c];
+						r6[0] += s * y; r6[1] += y * u; r6[2] += s * gpn; r6[3] += u * gpn; r6[4] += s * s; r6[5] += y * y;
+					});
+					block_sum<NT, 6>(r6, S.red);
+					const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
+					const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
+					r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
+					for_vec<NT>(n, [&](int c) {
+						const double s = sg[c], u = st[c] - sd[c];
+						if (upd) { hist[(size_t)npairs * (2 * n + 2) + c] = s; hist[(size_t)npairs * (2 * n + 2) + n + c] = u; }
+						const double dn = upd ? st[c] - rho * (s * r6[3] + u * r6[2]) + c2 * s * r6[2] : st[c];
+						const double xn = sx[c], gq = sgpt[c];
+						sgp[c] = gq;
+						sd[c] = dn;
+						r4[0] += gq * dn; r4[1] += dn * dn; r4[2] += xn * xn; r4[3] += gq * gq;
+					});
+					if (upd) {
+						if (tid == 0) { hist[(size_t)npairs * (2 * n + 2) + 2 * n] = rho; hist[(size_t)npairs * (2 * n + 2) + 2 * n + 1] = c2; }
+						npairs++;
+					}
+					__threadfence_block();
+					__syncthreads();   // rho/c2 of the new pair go through HBM/L2: needs the full barrier (vmcnt(0))
+					block_sum<NT, 4>(r4, S.red);
+					F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n;
+					iter++;
+					if (!sp.fixed_iters && alpha * pnorm <= sri * (1.0 + sqrt(r4[2])) &&
+					    sqrt(r4[3]) <= sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inner_inform = 0; finished = true; }
+					else new_major = true;
+				}
+			}
+			}
+			if (new_major) {
+				// ---- start of a major iteration at (sx, sgp, sd) ----
+				if (iter >= sp.itlim) { inner_inform = 4; finished = true; }
+				else {
+					if (al.mu > 0.0 && m > 0) {
+						// Under a large penalty |g| >> |Z'g|: the rounding error of the projection, relative to |g|, is then
+						// a visible fraction of gp and of d = W gp, and x would creep off A x = b along the path.
+						// Projecting the direction itself leaves an error relative to |d| only.  (g's buffer is free here.)
+						project<NT, BIG>(D, S, sd, sg, tmp);
+						double r2[2] = {0, 0};
+						for_vec<NT>(n, [&](int c) { const double dn = sg[c]; sd[c] = dn; r2[0] += sgp[c] * dn; r2[1] += dn * dn; });
+						block_sum<NT, 2>(r2, S.red);
+						r4[0] = r2[0]; r4[1] = r2[1];
+					}
+					double dphi0 = -r4[0];
+					pnorm = sqrt(r4[1]);
+					const double xnorm = sqrt(r4[2]), gpnorm = sqrt(r4[3]);
+					const double tolg = sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+					if (pnorm == 0.0 || !(dphi0 < 0.0)) {
+						if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
+							npairs = 0;
+							apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd);
+							double r2[2] = {0, 0};
+							for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
+							block_sum<NT, 2>(r2, S.red);
+							r4[0] = r2[0]; r4[1] = r2[1];
+							dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
+						}
+						if (pnorm == 0.0 || !(dphi0 < 0.0)) { inner_inform = (gpnorm <= tolg) ? 0 : 6; finished = true; }
+					}
+					if (!finished && !sp.fixed_iters && gpnorm <= 1e-3 * tolg) { inner_inform = 0; finished = true; }
+					if (!finished) {
+						const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
+						const double a = amax < 1.0 ? amax : 1.0;
+						lds_sync();
+						if (tid == 0) lsm->init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
+						lds_sync();
+						state = ST_LS;
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * (-sd[c]); });
+					}
+				}
+			}
+			NTG_STAMP(5);
+			if (finished) {
+				if (al.mu > 0.0) {
+					// ---- multiplier / penalty update of the augmented Lagrangian ----
+					if (!at_x) {   // inner solve ended on a rejected trial: refresh c, t at x first
+						state = ST_REEVAL;
+						lds_sync();
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+						continue;
+					}
+					const double rv = sqrt(rv2);
+					bool done_al = false;
+					bool take = false;
+					if (inner_inform == 6) { inform = 6; done_al = true; }
+					else if (rv <= 1e-8 && sri <= sp.sr && inner_inform == 0) { take = true; inform = weak ? 1 : 0; done_al = true; }
+					else if (inner_inform == 4) { inform = 4; done_al = true; }
+					else {
+						if (rv <= 0.25 * rvprev) { take = true; rvprev = rv; }
+						else al.mu *= 10.0;
+						outer++;
+						if (outer >= 30) { inform = 3; done_al = true; }
+					}
+					if (take) for (int j = tid; j < ncn; j += NT) al_lam[j] = al_t[j];
+					__syncthreads();   // multipliers cross lanes through HBM: full barrier
+					if (!done_al) {
+						sri = fmax(sp.sr, fmin(1e-3, 0.1 * rvprev));
+						npairs = 0; finished = false; inner_inform = 4; state = ST_INIT; weak = false;
+						make_feasible();   // steps stay in null(A) only to rounding: re-project before every further pass
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+						continue;
+					}
+				} else inform = (inner_inform == 0 && weak) ? 1 : inner_inform;
+				if (clambda && m > 0 && (D.q_use || al.mu > 0.0)) {   // one more pass for the multipliers (the Q form does not produce
+				                                                       // them; projecting directions overwrote the estimate)
+					state = ST_FINAL;
+					lds_sync();
+					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+					continue;
+				}
+				break;
+			}
+		}
+		// many hundreds of majors under a large penalty let x drift off A x = b by rounding: restore it
+		if (al.mu > 0.0) make_feasible();
+	}
+	lds_sync();
+	for (int i = tid; i < n; i += NT) xio[(size_t)b * n + i] = sx[i];
+	NTG_STAMP(5);
+	if (clambda) {
+		const int ntot = n + m + D.ncnln;
+		for (int i = tid; i < ntot; i += NT)
+			clambda[(size_t)b * ntot + i] = (inform == 9 || i < n) ? 0.0 : (i < n + m ? S.lam[i - n] : (al.mu > 0.0 ? -al_lam[i - n - m] : 0.0));
+		if (sp.stamps == 1 && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
+		if (sp.stamps == 2 && tid == 0) {   // diagnostic: state of the augmented-Lagrangian loop at exit
+			double *o = clambda + (size_t)b * ntot;
+			o[0] = sqrt(rv2); o[1] = al.mu; o[2] = outer; o[3] = sri; o[4] = rvprev; o[5] = inner_inform; o[6] = mfres; o[7] = F;
+		}
+	}
+#undef NTG_STAMP
+	if (tid == 0) {
+		if (objective) objective[b] = Fp;
+		if (inform_out) inform_out[b] = inform;
+		if (iters_out) iters_out[b] = iter;
+		if (nfev_out) nfev_out[b] = nfev;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers: one (family, nout, order) instance at the workgroup size the host picked
+// ------------------------------------------------------------------------------------------
+template <int FAM, int NOUT, int K, int NT, int EPT>
+static hipError_t launch_eval_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
+{
+	auto kfn = eval_kernel<FAM, NOUT, K, NT, EPT>;
+	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+	hipLaunchKernelGGL(kfn, dim3(a.grid), dim3(NT), L.total, a.st, D, T, L, a.batch, a.mode, a.x, a.f, a.g, a.c, a.jb, a.cj);
+	return hipGetLastError();
+}
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG>
+static hipError_t launch_sqp_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
+{
+	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG>;
+	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
+	hipLaunchKernelGGL(kfn, dim3(a.batch), dim3(NT), L.total, a.st, D, T, L, sp, a.batch, a.lo, a.up, a.x, a.obj, a.inf, a.it, a.nf,
+	                   a.cl, a.hist, a.alw, a.vecw);
+	return hipGetLastError();
+}
+// the small-problem instances: 128 or 256 lanes, all vectors in LDS
+template <int FAM, int NOUT, int K>
+static hipError_t launch_eval_small(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
+{
+	if (a.nt == 128) return launch_eval_one<FAM, NOUT, K, 128, 4>(D, T, L, a);
+	if (a.nt == 256) return launch_eval_one<FAM, NOUT, K, 256, 4>(D, T, L, a);
+	return hipErrorInvalidValue;
+}
+template <int FAM, int NOUT, int K>
+static hipError_t launch_sqp_small(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
+{
+	if (a.big) return hipErrorInvalidValue;
+	if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false>(D, T, L, sp, a);
+	if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false>(D, T, L, sp, a);
+	return hipErrorInvalidValue;
+}
+// the generic instance of a family (run-time nout / order) at every workgroup size, LDS-resident or BIG
+template <int FAM>
+static hipError_t launch_eval_generic(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
+{
+	if (a.nt == 128) return launch_eval_one<FAM, 0, 0, 128, 4>(D, T, L, a);
+	if (a.nt == 256) return launch_eval_one<FAM, 0, 0, 256, 4>(D, T, L, a);
+	if (a.nt == 512) return launch_eval_one<FAM, 0, 0, 512, 4>(D, T, L, a);
+	return hipErrorInvalidValue;
+}
+template <int FAM>
+static hipError_t launch_sqp_generic(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
+{
+	if (a.big) {
+		if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, true>(D, T, L, sp, a);
+		if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, true>(D, T, L, sp, a);
+		return hipErrorInvalidValue;
+	}
+	if (a.nt == 128) return launch_sqp_one<FAM, 0, 0, 128, 4, false>(D, T, L, sp, a);
+	if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, false>(D, T, L, sp, a);
+	if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, false>(D, T, L, sp, a);
+	return hipErrorInvalidValue;
+}
+// shape tests shared by the per-family dispatchers
+static inline bool ntg_all_d(const NtgDims &D, int d) { for (int o = 0; o < D.nout; o++) if (D.d[o] != d) return false; return true; }
+static inline int ntg_uniform_order(const NtgDims &D, int nt, int ept) { return (D.uniform && D.nC <= ept * nt) ? D.order[0] : 0; }

@@ -15,6 +15,8 @@ FAM_KINCAR = 0
 FAM_VANDERPOL = 1
 FAM_TESTFAM = 2
 FAM_OBSTACLE = 3
+FAM_QUADROTOR = 4
+FAM_MANIP = 5
 
 
 def linspace_c(d0: float, d1: float, n: int) -> np.ndarray:

@@ -15,7 +15,15 @@
  *                        c = (x - 20)^2 + (y - 0.5)^2  (>= r^2 through the bounds): a circular obstacle on the
  *                        lane-change path -- build-defined (BASELINE configs D/E are, too), used to exercise
  *                        the nonlinear-constraint path of NPfuncon / npsol_ end to end.
- * All families assume maxderiv == 3 for every output (flat index iz[o] = 3*o).
+ *   family 4  quadrotor  4 flat outputs (x, y, z, yaw), maxderiv 5 (BASELINE config D).  Running cost
+ *                        snap^2 of the position outputs + yaw acceleration^2; two nonlinear trajectory
+ *                        constraints: c0 = x''^2 + y''^2 + (z'' + g)^2 (mass-normalised thrust squared,
+ *                        bounded on both sides) and c1 = x'^2 + y'^2 + z'^2 (speed squared, bounded above).
+ *   family 5  manipulator  nout = 3*narms joint angles, maxderiv 3 (BASELINE config E: 12 outputs = 4 planar
+ *                        3-link arms).  Running cost sum of joint accelerations squared; one nonlinear
+ *                        trajectory inequality per arm: tip height sin(qa) + sin(qa+qb) + sin(qa+qb+qc)
+ *                        (bounded above by a ceiling through the bounds).
+ * Families 0-3 and 5 use maxderiv == 3 for every output (flat index iz[o] = 3*o); family 4 uses 5.
  */
 #include <stdlib.h>
 #include <string.h>
@@ -105,11 +113,52 @@ static void obs_nltcf(int *mode, int *nstate, int *i, double *c, double **dc, do
 	if (*mode == 1 || *mode == 2) { for (v = 0; v < 6; v++) dc[0][v] = 0; dc[0][0] = 2.0 * dx; dc[0][3] = 2.0 * dy; }
 }
 
-orc_ucf_t orc_family_ucf(int fam) { return (fam == 0 || fam == 3) ? kincar_ucf : fam == 1 ? vdp_ucf : fam == 2 ? tf_ucf : NULL; }
+/* ---- family 4 ---- */
+#define QUAD_G 9.81
+static void quad_ucf(int *mode, int *nstate, int *i, double *f, double *df, double **zp)
+{
+	int v; (void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) *f = zp[0][4] * zp[0][4] + zp[1][4] * zp[1][4] + zp[2][4] * zp[2][4] + zp[3][2] * zp[3][2];
+	if (*mode == 1 || *mode == 2) {
+		for (v = 0; v < 20; v++) df[v] = 0;
+		df[4] = 2 * zp[0][4]; df[9] = 2 * zp[1][4]; df[14] = 2 * zp[2][4]; df[17] = 2 * zp[3][2];
+	}
+}
+static void quad_nltcf(int *mode, int *nstate, int *i, double *c, double **dc, double **zp)
+{
+	const double ax = zp[0][2], ay = zp[1][2], az = zp[2][2] + QUAD_G; int v; (void)nstate; (void)i;
+	if (*mode == 0 || *mode == 2) {
+		c[0] = ax * ax + ay * ay + az * az;
+		c[1] = zp[0][1] * zp[0][1] + zp[1][1] * zp[1][1] + zp[2][1] * zp[2][1];
+	}
+	if (*mode == 1 || *mode == 2) {
+		for (v = 0; v < 20; v++) { dc[0][v] = 0; dc[1][v] = 0; }
+		dc[0][2] = 2 * ax; dc[0][7] = 2 * ay; dc[0][12] = 2 * az;
+		dc[1][1] = 2 * zp[0][1]; dc[1][6] = 2 * zp[1][1]; dc[1][11] = 2 * zp[2][1];
+	}
+}
+/* ---- family 5 ---- */
+static void manip_nltcf(int *mode, int *nstate, int *i, double *c, double **dc, double **zp)
+{
+	int j, v, narms = fam_nout / 3; (void)nstate; (void)i;
+	for (j = 0; j < narms; j++) {
+		const double qa = zp[3 * j][0], qb = zp[3 * j + 1][0], qc = zp[3 * j + 2][0];
+		const double a1 = qa, a2 = qa + qb, a3 = qa + qb + qc;
+		if (*mode == 0 || *mode == 2) c[j] = sin(a1) + sin(a2) + sin(a3);
+		if (*mode == 1 || *mode == 2) {
+			for (v = 0; v < 3 * fam_nout; v++) dc[j][v] = 0;
+			dc[j][9 * j] = cos(a1) + cos(a2) + cos(a3);
+			dc[j][9 * j + 3] = cos(a2) + cos(a3);
+			dc[j][9 * j + 6] = cos(a3);
+		}
+	}
+}
+
+orc_ucf_t orc_family_ucf(int fam) { return (fam == 0 || fam == 3 || fam == 5) ? kincar_ucf : fam == 1 ? vdp_ucf : fam == 2 ? tf_ucf : fam == 4 ? quad_ucf : NULL; }
 orc_icf_t orc_family_icf(int fam) { return fam == 2 ? tf_icf : NULL; }
 orc_icf_t orc_family_fcf(int fam) { return fam == 2 ? tf_fcf : NULL; }
 orc_nlic_t orc_family_nlicf(int fam) { return fam == 2 ? tf_nlicf : NULL; }
-orc_nltc_t orc_family_nltcf(int fam) { return fam == 2 ? tf_nltcf : fam == 3 ? obs_nltcf : NULL; }
+orc_nltc_t orc_family_nltcf(int fam) { return fam == 2 ? tf_nltcf : fam == 3 ? obs_nltcf : fam == 4 ? quad_nltcf : fam == 5 ? manip_nltcf : NULL; }
 orc_nlic_t orc_family_nlfcf(int fam) { return fam == 2 ? tf_nlfcf : NULL; }
 
 /* ---------------- batched CPU driver ---------------- */

@@ -127,6 +127,8 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 #define ORC_FAM_VANDERPOL 1
 #define ORC_FAM_TESTFAM 2
 #define ORC_FAM_OBSTACLE 3
+#define ORC_FAM_QUADROTOR 4
+#define ORC_FAM_MANIP 5
 orc_ucf_t orc_family_ucf(int fam);
 orc_icf_t orc_family_icf(int fam);
 orc_icf_t orc_family_fcf(int fam);

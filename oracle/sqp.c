@@ -201,13 +201,57 @@ static void qr_full_q(const double *A, int m, int n, double *Q)
 	}
 	free(R); free(v);
 }
-/* returns 0 and fills W0 (n x n) on success */
+/* dense core: W0 = Z (Z'H0Z)^-1 Z' for one block (H0 n x n, AE m x n); returns 0 on success */
+static int w0_dense(const double *H0, const double *AE, int m, int n, double *W0)
+{
+	int nr = n - m, i, j, k, rc;
+	double *Q, *Hr, *T, *Zt, tr = 0.0;
+	if (nr <= 0) return 1;
+	Q = malloc((size_t)n * n * sizeof(double));
+	if (m > 0) qr_full_q(AE, m, n, Q);
+	else { memset(Q, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(Q, n, i, i) = 1.0; }
+	/* Z = Q[:, m:],  T = H0 Z (n x nr),  Hr = Z' T  (H0 is symmetric: its columns are read as rows) */
+	T = malloc((size_t)n * nr * sizeof(double)); Hr = malloc((size_t)nr * nr * sizeof(double));
+	for (j = 0; j < nr; j++) for (i = 0; i < n; i++) M_(T, n, i, j) = dot_(&M_(H0, n, 0, i), &M_(Q, n, 0, m + j), n);
+	for (j = 0; j < nr; j++) for (i = 0; i < nr; i++) M_(Hr, nr, i, j) = dot_(&M_(Q, n, 0, m + i), &M_(T, n, 0, j), n);
+	for (i = 0; i < nr; i++) tr += M_(Hr, nr, i, i);
+	for (i = 0; i < nr; i++) M_(Hr, nr, i, i) += 1e-12 * tr / nr + 1e-300;
+	rc = chol_(Hr, nr);
+	if (rc) {
+		/* not positive definite on null(A): regularise harder once */
+		for (j = 0; j < nr; j++) for (i = 0; i < nr; i++) M_(Hr, nr, i, j) = dot_(&M_(Q, n, 0, m + i), &M_(T, n, 0, j), n);
+		for (i = 0; i < nr; i++) M_(Hr, nr, i, i) += 1e-6 * tr / nr + 1e-300;
+		rc = chol_(Hr, nr);
+	}
+	if (!rc) {
+		/* W0 = Z Hr^-1 Z' : solve Hr X = Z' column by column (X is nr x n), W0 = Z X */
+		double *X = malloc((size_t)nr * n * sizeof(double));
+		Zt = malloc((size_t)nr * n * sizeof(double));   /* Zt[k + nr*i] = Z[i][k]: rows of Z contiguous */
+		for (j = 0; j < n; j++) {
+			for (i = 0; i < nr; i++) { M_(X, nr, i, j) = M_(Q, n, j, m + i); M_(Zt, nr, i, j) = M_(Q, n, j, m + i); }
+			chol_solve_(Hr, nr, &M_(X, nr, 0, j));
+		}
+		for (j = 0; j < n; j++) for (i = 0; i < n; i++) M_(W0, n, i, j) = dot_(&M_(Zt, nr, 0, i), &M_(X, nr, 0, j), nr);
+		for (j = 0; j < n; j++) for (i = 0; i < j; i++) {   /* symmetrise */
+			double sym = 0.5 * (M_(W0, n, i, j) + M_(W0, n, j, i)); M_(W0, n, i, j) = sym; M_(W0, n, j, i) = sym;
+		}
+		free(X); free(Zt);
+	}
+	(void)k;
+	free(Q); free(T); free(Hr);
+	return rc;
+}
+
+/* returns 0 and fills W0 (n x n) on success.  H0 is block diagonal by output; outputs that no row of AE couples
+ * give independent blocks of W0, which are built one at a time (a 12-output problem is twelve small
+ * factorisations instead of one large one). */
 static int build_colloc_W0(const orc_problem *p, const double *AE, int m, double *W0)
 {
 	const orc_colloc *cc = p->cc;
-	int n = cc->nC, nr = n - m, i, j, k, P = cc->nbps, rc;
-	double *H0 = calloc((size_t)n * n, sizeof(double)), *Q, *Hr, *T, tr = 0.0;
-	if (nr <= 0) { free(H0); return 1; }
+	int n = cc->nC, nout = cc->nout, i, j, o, r, P = cc->nbps, rc = 0;
+	double *H0 = calloc((size_t)n * n, sizeof(double));
+	int *comp = malloc(nout * sizeof(int)), *outof = malloc(n * sizeof(int));
+	if (n - m <= 0) { free(H0); free(comp); free(outof); return 1; }
 	for (i = 0; i < P; i++) {   /* trapezoid weight of breakpoint i */
 		double w = 0.0;
 		if (i > 0) w += (cc->bps[i] - cc->bps[i - 1]) / 2;
@@ -216,49 +260,30 @@ static int build_colloc_W0(const orc_problem *p, const double *AE, int m, double
 	}
 	if (p->nicf) add_av_terms(H0, n, cc, p->icostav, p->nicostav, 0, 1.0);
 	if (p->nfcf) add_av_terms(H0, n, cc, p->fcostav, p->nfcostav, P - 1, 1.0);
-	Q = malloc((size_t)n * n * sizeof(double));
-	if (m > 0) qr_full_q(AE, m, n, Q);
-	else { memset(Q, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(Q, n, i, i) = 1.0; }
-	/* Z = Q[:, m:],  T = H0 Z (n x nr),  Hr = Z' T */
-	T = malloc((size_t)n * nr * sizeof(double)); Hr = malloc((size_t)nr * nr * sizeof(double));
-	for (j = 0; j < nr; j++) for (i = 0; i < n; i++) {
-		double s = 0.0; for (k = 0; k < n; k++) s += M_(H0, n, i, k) * M_(Q, n, k, m + j);
-		M_(T, n, i, j) = s;
-	}
-	for (j = 0; j < nr; j++) for (i = 0; i < nr; i++) {
-		double s = 0.0; for (k = 0; k < n; k++) s += M_(Q, n, k, m + i) * M_(T, n, k, j);
-		M_(Hr, nr, i, j) = s;
-	}
-	for (i = 0; i < nr; i++) tr += M_(Hr, nr, i, i);
-	for (i = 0; i < nr; i++) M_(Hr, nr, i, i) += 1e-12 * tr / nr + 1e-300;
-	rc = chol_(Hr, nr);
-	if (rc) {
-		/* not positive definite on null(A): regularise harder once */
-		for (j = 0; j < nr; j++) for (i = 0; i < nr; i++) {
-			double s = 0.0; for (k = 0; k < n; k++) s += M_(Q, n, k, m + i) * M_(T, n, k, j);
-			M_(Hr, nr, i, j) = s;
+	for (o = 0; o < nout; o++) { comp[o] = o; for (j = 0; j < cc->ncoef[o]; j++) outof[cc->iC[o] + j] = o; }
+	for (r = 0; r < m; r++) {   /* merge the outputs a row touches (label = smallest output index) */
+		int first = -1;
+		for (j = 0; j < n; j++) if (M_(AE, m, r, j) != 0.0) {
+			int c = comp[outof[j]];
+			if (first < 0) first = c;
+			else if (c != first) { int lo = c < first ? c : first, hi = c < first ? first : c; for (o = 0; o < nout; o++) if (comp[o] == hi) comp[o] = lo; first = lo; }
 		}
-		for (i = 0; i < nr; i++) M_(Hr, nr, i, i) += 1e-6 * tr / nr + 1e-300;
-		rc = chol_(Hr, nr);
 	}
-	if (!rc) {
-		/* W0 = Z Hr^-1 Z' : solve Hr X = Z' column by column (X is nr x n), W0 = Z X */
-		double *X = malloc((size_t)nr * n * sizeof(double));
-		for (j = 0; j < n; j++) {
-			for (i = 0; i < nr; i++) M_(X, nr, i, j) = M_(Q, n, j, m + i);
-			chol_solve_(Hr, nr, &M_(X, nr, 0, j));
-		}
-		for (j = 0; j < n; j++) for (i = 0; i < n; i++) {
-			double s = 0.0; for (k = 0; k < nr; k++) s += M_(Q, n, i, m + k) * M_(X, nr, k, j);
-			M_(W0, n, i, j) = s;
-		}
-		/* symmetrise */
-		for (j = 0; j < n; j++) for (i = 0; i < j; i++) {
-			double s = 0.5 * (M_(W0, n, i, j) + M_(W0, n, j, i)); M_(W0, n, i, j) = s; M_(W0, n, j, i) = s;
-		}
-		free(X);
+	memset(W0, 0, (size_t)n * n * sizeof(double));
+	for (o = 0; o < nout && !rc; o++) {
+		int nb = 0, mb = 0, *idx, *rows; double *Hb, *Ab, *Wb;
+		if (comp[o] != o) continue;
+		idx = malloc(n * sizeof(int)); rows = malloc((m + 1) * sizeof(int));
+		for (j = 0; j < n; j++) if (comp[outof[j]] == o) idx[nb++] = j;
+		for (r = 0; r < m; r++) { int hit = 0; for (j = 0; j < nb && !hit; j++) if (M_(AE, m, r, idx[j]) != 0.0) hit = 1; if (hit) rows[mb++] = r; }
+		Hb = malloc((size_t)nb * nb * sizeof(double)); Ab = malloc((size_t)(mb + 1) * nb * sizeof(double)); Wb = malloc((size_t)nb * nb * sizeof(double));
+		for (j = 0; j < nb; j++) for (i = 0; i < nb; i++) M_(Hb, nb, i, j) = M_(H0, n, idx[i], idx[j]);
+		for (j = 0; j < nb; j++) for (i = 0; i < mb; i++) M_(Ab, mb, i, j) = M_(AE, m, rows[i], idx[j]);
+		rc = w0_dense(Hb, Ab, mb, nb, Wb);
+		if (!rc) for (j = 0; j < nb; j++) for (i = 0; i < nb; i++) M_(W0, n, idx[i], idx[j]) = M_(Wb, nb, i, j);
+		free(idx); free(rows); free(Hb); free(Ab); free(Wb);
 	}
-	free(H0); free(Q); free(T); free(Hr);
+	free(H0); free(comp); free(outof);
 	return rc;
 }
 
@@ -403,6 +428,13 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			double dphi0, xnorm, amax, a1, sy, yu, rho, cc2, tolg;
 			int rc;
 			if (iter >= itlim) { inner_inform = 4; stop = 1; break; }
+			if (nal > 0 && m > 0) {
+				/* Under a large penalty |g| >> |Z'g|: the rounding error of the projection, relative to |g|, is
+				 * then a visible fraction of gp and of d = W gp, and x would creep off A x = b along the path.
+				 * Projecting the direction itself leaves an error relative to |d| only. */
+				project(&pj, d, xt, NULL);
+				memcpy(d, xt, n * sizeof(double));
+			}
 			for (i = 0; i < n; i++) pdir[i] = -d[i];
 			dphi0 = dot_(gp, pdir, n);
 			pnorm = nrm2_(pdir, n); xnorm = nrm2_(x, n);

@@ -1,0 +1,110 @@
+"""-m gpu: BASELINE configs D (quadrotor, 4 outputs, order 8, maxderiv 5, 2 nonlinear trajectory rows) and E
+(manipulator, 12 outputs, order 6, 4 nonlinear trajectory inequalities) through the C ABI.
+
+Reduced grids are compared with the oracle's solve (same algorithm); at the full sizes of BASELINE.json
+(nC = 656 / 2196, P = 201 / 301, ncnln = 402 / 1204) the evaluation is compared with the oracle entry by
+entry and the solve through its KKT conditions, which do not depend on how the optimum was reached."""
+import numpy as np
+import pytest
+import torch
+
+import orc
+from ntg_amd import api, configs as cf
+from gpu_common import dev, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(name, l):
+    if name == "D":
+        return cf.config_D(ninterv=l), cf.quadrotor_bounds
+    return cf.config_E(ninterv=l), cf.manipulator_bounds
+
+
+@pytest.mark.parametrize("name,l", [("D", 8), ("D", 40), ("E", 8), ("E", 60)])
+def test_eval_matches_oracle(name, l):
+    """funobj + funcon (values, gradient, banded and dense Jacobian) at random points."""
+    spec, _ = _case(name, l)
+    p = api.Plan(spec, 0)
+    nb = 3
+    rng = np.random.default_rng(11)
+    x = rng.normal(size=(nb, spec.nC)) * 0.5 + 1.0
+    ev = p.eval(dev(x), 2, want_dense_jac=True)
+    ref = orc.eval_batch(spec, x, 2, nthreads=3)
+    assert rel(ev["f"].cpu().numpy(), ref["f"]) <= 1e-12
+    assert rel(ev["g"].cpu().numpy(), ref["g"]) <= 1e-12
+    assert rel(ev["c"].cpu().numpy(), ref["c"]) <= 1e-12
+    J = ev["cJac"].cpu().numpy()
+    assert np.array_equal(J != 0.0, ref["cJac"] != 0.0) or rel(J, ref["cJac"]) <= 1e-12
+    assert rel(J, ref["cJac"]) <= 1e-12
+    # banded rows hold exactly the entries of the dense Jacobian inside the band
+    jb = ev["jband"].cpu().numpy()
+    assert np.isclose(np.abs(jb).sum(), np.abs(J).sum(), rtol=1e-12)
+
+
+def _kkt(spec, p, x, lo, up, lam, inf, feas_tol=1e-7):
+    """first-order conditions of  min F  s.t.  A x = b,  bl <= c(x) <= bu  at the returned points"""
+    ev = p.eval(x, 2, want_dense_jac=True)
+    g = ev["g"].cpu().numpy(); J = ev["cJac"].cpu().numpy(); c = ev["c"].cpu().numpy()
+    A = p.tables()["A"]
+    xg = x.cpu().numpy()
+    P = spec.nbps
+    nl0 = spec.nclin_rows if hasattr(spec, "nclin_rows") else spec.lic.shape[0] + spec.ltc.shape[0] + spec.lfc.shape[0]
+    for i in range(xg.shape[0]):
+        assert inf[i] in (0, 1)
+        ll, ln = lam[i, spec.nC:spec.nC + spec.nclin], lam[i, spec.nC + spec.nclin:]
+        r = g[i] - A.T @ ll - J[i].T @ ln
+        assert np.abs(r).max() <= 2e-5 * max(1.0, np.abs(g[i]).max()), (i, np.abs(r).max(), np.abs(g[i]).max())
+        bres = A @ xg[i] - lo[i][:spec.nclin]
+        rowscale = np.abs(A).max(axis=1) * max(1.0, np.abs(xg[i]).max())
+        assert (np.abs(bres) <= 1e-9 * rowscale + 1e-9).all()
+        for j in range(spec.nnltc):
+            cj = c[i, j * P:(j + 1) * P]; lj = ln[j * P:(j + 1) * P]
+            l, u = lo[i, nl0 + j], up[i, nl0 + j]
+            assert cj.min() >= l - feas_tol * (1 + abs(l)) and cj.max() <= u + feas_tol * (1 + abs(u))
+            # multiplier sign (NPSOL: g = A' lam_lin + J' lam_nl; lower bound active => lam >= 0, upper => lam <= 0)
+            inactive = (cj > l + 1e-5 * (1 + abs(l))) & (cj < u - 1e-5 * (1 + abs(u)))
+            assert np.abs(lj[inactive]).max(initial=0.0) <= 1e-6 * max(1.0, np.abs(lj).max())
+            at_up = cj >= u - 1e-5 * (1 + abs(u))
+            at_lo = cj <= l + 1e-5 * (1 + abs(l))
+            assert lj[at_up].max(initial=0.0) <= 1e-9 and lj[at_lo].min(initial=0.0) >= -1e-9
+    return c
+
+
+@pytest.mark.parametrize("name,l,nb", [("D", 8, 6), ("E", 8, 4)])
+def test_reduced_grid_solve_matches_oracle(name, l, nb):
+    spec, bounds = _case(name, l)
+    p = api.Plan(spec, 0)
+    lo, up = bounds(nb)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=1), want_lambda=True)
+    torch.cuda.synchronize()
+    inf = out["inform"].cpu().numpy(); obj = out["objective"].cpu().numpy(); lam = out["clambda"].cpu().numpy()
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(hessian=1), nthreads=nb)
+    assert np.isin(ref["inform"], (0, 1)).all()
+    _kkt(spec, p, x, lo, up, lam, inf)
+    # both stop at a scaled constraint violation <= 1e-8 (NPSOL's nonlinear feasibility tolerance is sqrt(eps)):
+    # the objectives may differ by (multipliers x that slack), a few 1e-6 relative for the stiff snap cost
+    assert (np.abs(obj - ref["objective"]) <= 2e-5 * np.abs(ref["objective"])).all()
+    xg = x.cpu().numpy()
+    for i in range(nb):
+        assert np.abs(xg[i] - ref["x"][i]).max() <= 1e-4 * np.abs(ref["x"][i]).max()
+
+
+@pytest.mark.parametrize("name,l,nb", [("D", 40, 8), ("E", 60, 6)])
+def test_full_size_solve_kkt(name, l, nb):
+    """BASELINE.json sizes.  KKT conditions for every problem; one problem also against the oracle's solve."""
+    spec, bounds = _case(name, l)
+    p = api.Plan(spec, 0)
+    lo, up = bounds(nb)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=1), want_lambda=True)
+    torch.cuda.synchronize()
+    inf = out["inform"].cpu().numpy(); obj = out["objective"].cpu().numpy(); lam = out["clambda"].cpu().numpy()
+    c = _kkt(spec, p, x, lo, up, lam, inf)
+    # some inequality is active somewhere in the batch (the workload is not secretly unconstrained)
+    nlam = lam[:, spec.nC + spec.nclin:]
+    assert (np.abs(nlam) > 1e-8).any()
+    ref = orc.solve_one(spec, lo[1], up[1], np.ones(spec.nC), orc.default_opts(hessian=1))
+    assert ref["inform"] in (0, 1)
+    assert abs(obj[1] - ref["objective"]) <= 2e-5 * abs(ref["objective"])
