@@ -206,6 +206,11 @@ def cases():
     yield "B", B, rng.normal(size=(2, B.nC)) * 5, loB, upB
     yield "M", M, rng.normal(size=(1, M.nC)) * 5, loM, upM
     yield "T", T, rng.normal(size=(3, T.nC)), loT, upT
+    # reduced grids of BASELINE configs D (maxderiv 5, order 8) and E (two arms): new draws AFTER the ones above
+    D8 = cf.config_D(ninterv=8); loD, upD = cf.quadrotor_bounds(1)
+    E8 = cf.config_E(ninterv=8, narms=2); loE, upE = cf.manipulator_bounds(1, narms=2)
+    yield "D8", D8, rng.normal(size=(2, D8.nC)) * 2, loD, upD
+    yield "E8", E8, rng.normal(size=(2, E8.nC)), loE, upE
 
 
 def main():

@@ -5,7 +5,8 @@ import torch
 import orc
 from ntg_amd import api, configs as cf
 
-SPECS = {"A": cf.config_A, "K0": cf.config_K0, "B": cf.config_B, "M": cf.config_M, "T": cf.config_T}
+SPECS = {"A": cf.config_A, "K0": cf.config_K0, "B": cf.config_B, "M": cf.config_M, "T": cf.config_T,
+         "D8": lambda: cf.config_D(ninterv=8), "E8": lambda: cf.config_E(ninterv=8, narms=2)}
 _plans = {}
 
 

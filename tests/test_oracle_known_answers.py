@@ -172,3 +172,68 @@ def test_R_factor_is_cholesky_of_hessian_estimate():
     assert np.allclose(R, np.triu(R))
     H = R.T @ R
     assert np.all(np.linalg.eigvalsh(H) > 0)
+
+
+def _de_case(name):
+    if name == "D":
+        return cf.config_D(ninterv=4), cf.quadrotor_bounds(3)
+    return cf.config_E(ninterv=4, narms=1), cf.manipulator_bounds(3, narms=1)
+
+
+@pytest.mark.parametrize("name", ["D", "E"])
+def test_families_4_5_derivatives_by_finite_differences(name):
+    """The quadrotor / manipulator callbacks are build-defined: their hand-written gradients and Jacobians are
+    pinned by central differences of their own values."""
+    spec, _ = _de_case(name)
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=spec.nC) * 0.4 + 0.8
+    ev = orc.eval_batch(spec, x[None], 2)
+    h = 1e-6
+    dirs = rng.normal(size=(6, spec.nC))
+    xp = np.concatenate([x[None] + h * dirs, x[None] - h * dirs])
+    e2 = orc.eval_batch(spec, xp, 0)
+    df = (e2["f"][:6] - e2["f"][6:]) / (2 * h)
+    dc = (e2["c"][:6] - e2["c"][6:]) / (2 * h)
+    assert np.abs(df - dirs @ ev["g"][0]).max() <= 1e-6 * max(1.0, np.abs(df).max())
+    assert np.abs(dc - dirs @ ev["cJac"][0].T).max() <= 1e-6 * max(1.0, np.abs(dc).max())
+
+
+@pytest.mark.parametrize("name", ["D", "E"])
+def test_families_4_5_reduced_grid_vs_slsqp(name):
+    """Reduced configs D / E against scipy's SLSQP on the same functions: the augmented-Lagrangian solve must
+    reach the same constrained optimum (the problems are smooth and, at this size, have one minimum nearby)."""
+    spec, (lo, up) = _de_case(name)
+    A = orc.export_tables(spec)["A"]
+    P, nl = spec.nbps, spec.nclin
+    nact = 0
+    for b in range(3):
+        r = orc.solve_one(spec, lo[b], up[b], np.ones(spec.nC), orc.default_opts(hessian=1))
+        assert r["inform"] in (0, 1)
+        lcb = np.repeat(lo[b][nl:], P); ucb = np.repeat(up[b][nl:], P)
+        fin_l = lcb > -1e19; fin_u = ucb < 1e19
+
+        def cons(x):
+            c = orc.eval_batch(spec, x[None], 0)["c"][0]
+            return np.concatenate([(c - lcb)[fin_l], (ucb - c)[fin_u]])
+
+        def cons_jac(x):
+            J = orc.eval_batch(spec, x[None], 2)["cJac"][0]
+            return np.concatenate([J[fin_l], -J[fin_u]])
+        def slsqp(start):
+            return so.minimize(lambda x: orc.eval_batch(spec, x[None], 0)["f"][0], start, jac=lambda x: orc.eval_batch(spec, x[None], 2)["g"][0],
+                               constraints=[{"type": "eq", "fun": lambda x: A @ x - lo[b][:nl], "jac": lambda x: A},
+                                            {"type": "ineq", "fun": cons, "jac": cons_jac}],
+                               method="SLSQP", options=dict(ftol=1e-14, maxiter=400))
+        # SLSQP at ftol 1e-14 usually stops with status 8 ("positive directional derivative") at the optimum
+        ref = slsqp(np.ones(spec.nC))
+        assert ref.status in (0, 8) and cons(ref.x).min() >= -1e-7 and np.abs(A @ ref.x - lo[b][:nl]).max() <= 1e-7
+        assert cons(r["x"]).min() >= -1e-6 and np.abs(A @ r["x"] - lo[b][:nl]).max() <= 1e-8
+        # the arm problem is not convex: from the same start SLSQP may stop in a worse local minimum, never a better one
+        assert r["objective"] <= ref.fun + 2e-6 * max(1.0, abs(ref.fun))
+        if name == "D":
+            assert abs(r["objective"] - ref.fun) <= 2e-6 * max(1.0, abs(ref.fun))
+        # and SLSQP started at the returned point stays there: it is a constrained local minimum
+        pol = slsqp(r["x"])
+        assert abs(r["objective"] - pol.fun) <= 2e-6 * max(1.0, abs(pol.fun))
+        nact += int((np.abs(r["clambda"][spec.nC + spec.nclin:]) > 1e-8).any())
+    assert nact >= 1                                       # an inequality binds for at least one of the draws
