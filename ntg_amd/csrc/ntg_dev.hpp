@@ -39,6 +39,7 @@ struct NtgDims {
 	int row_total, col_total;           // doubles in rowv / entries in colv+coli
 	int cls_W[NTG_MAX_OUT];             // padded (multiple of 4) support width of the column form, per class
 	int cls_nc[NTG_MAX_OUT];            // coefficients per output of the class
+	int n0_blk[NTG_MAX_OUT];            // which dense preconditioner block an output uses (NtgTables::n0b)
 	int tav_rmask;                      // union over outputs of the derivative indices with a cost AV
 };
 
@@ -54,6 +55,9 @@ struct NtgTables {
 	// preconditioner W0 = Z(Z'H0Z)^-1 Z' as ELL, s-major ([s][nC]) so that lanes with consecutive rows
 	// read consecutive words; exact zeros dropped (block diagonal when outputs decouple); nullptr: none
 	const double *n0; const unsigned short *n0c; int n0_w;
+	// ... or, when W0 is block diagonal by output with equal block sizes: the distinct blocks, each s-major [s][row]
+	// (see apply_n0_block); NtgDims::n0_blk maps outputs to blocks
+	const double *n0b; int n0b_n, n0b_sp, n0b_nblk;   // rows per block, rows padded to 16 (zeros), distinct blocks
 	// sparse A: CSR (rows) and CSC (columns)
 	const int *csr_ptr, *csr_col; const double *csr_val;
 	const int *csc_ptr, *csc_row; const double *csc_val;

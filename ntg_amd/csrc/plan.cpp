@@ -479,6 +479,7 @@ static int build_precond(ntg_plan *p)
 		}
 	}
 	std::vector<std::vector<std::pair<int, double>>> rows(n);   // W0 row i: (column, value), zeros dropped
+	std::vector<std::vector<double>> wblocks; int nb_first = -1; bool by_output = true;   // one dense block per output, few distinct?
 	for (int o0 = 0; o0 < D.nout; o0++) {
 		if (comp[o0] != o0) continue;
 		std::vector<int> idx, rsel, loc(n, -1);
@@ -507,7 +508,29 @@ static int build_precond(ntg_plan *p)
 		for (int i = 0; i < mb; i++) for (int j = 0; j < nb; j++) Ab[(size_t)i * nb + j] = p->h_Adense[(size_t)rsel[i] * n + idx[j]];
 		const int rc = precond_block(H0, Ab, mb, nb, Wb);
 		if (rc) return rc;
+		{
+			int nouts = 0; for (int o = 0; o < D.nout; o++) if (comp[o] == o0) nouts++;
+			if (nouts != 1 || idx[0] != D.iC[o0] || (nb_first >= 0 && nb != nb_first)) by_output = false;
+			else {
+				nb_first = nb;
+				int found = -1;
+				for (size_t q = 0; q < wblocks.size(); q++) if (std::memcmp(Wb.data(), wblocks[q].data(), Wb.size() * sizeof(double)) == 0) found = (int)q;
+				if (found < 0) { found = (int)wblocks.size(); wblocks.push_back(Wb); }
+				p->D.n0_blk[o0] = found;
+			}
+		}
 		for (int i = 0; i < nb; i++) for (int j = 0; j < nb; j++) if (Wb[(size_t)i * nb + j] != 0.0) rows[idx[i]].push_back({idx[j], Wb[(size_t)i * nb + j]});
+	}
+	if (by_output && nb_first > 0 && nb_first * D.nout == n && wblocks.size() <= 4) {
+		// one dense block per output, kept once per distinct block: s-major (symmetric, so [s][row] == [row][s]),
+		// rows padded with zeros to a multiple of 16
+		const int spad = (nb_first + 15) & ~15;
+		std::vector<double> all(wblocks.size() * (size_t)spad * nb_first, 0.0);
+		for (size_t q = 0; q < wblocks.size(); q++) std::copy(wblocks[q].begin(), wblocks[q].end(), all.begin() + q * (size_t)spad * nb_first);
+		double *d_wb = nullptr;
+		if (dev_upload(&d_wb, all.data(), all.size(), p->owned)) return NTG_E_HIP;
+		p->T.n0b = d_wb; p->T.n0b_n = nb_first; p->T.n0b_sp = spad; p->T.n0b_nblk = (int)wblocks.size();
+		// the ELL form below stays as the fallback (block taller than the workgroup)
 	}
 	// ELL, s-major, zeros dropped
 	int w = 0;
@@ -517,6 +540,7 @@ static int build_precond(ntg_plan *p)
 	double *d_n0 = nullptr; unsigned short *d_n0c = nullptr;
 	if (dev_upload(&d_n0, ev.data(), ev.size(), p->owned) || dev_upload(&d_n0c, ec.data(), ec.size(), p->owned)) return NTG_E_HIP;
 	p->T.n0 = d_n0; p->T.n0c = d_n0c; p->T.n0_w = w;
+	p->precond_ready = true;
 	return 0;
 }
 
@@ -619,7 +643,7 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
 	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
-	if (sp.hessian == 1 && !p->T.n0) { int rc = build_precond(p); if (rc) return rc; }
+	if (sp.hessian == 1 && !p->precond_ready) { int rc = build_precond(p); if (rc) return rc; }
 	SmemLayout L; int big;
 	if (solve_layout(p->D, nt, &L, &big)) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
 	double *alw = (double *)d_work + hist_doubles(p->D, batch, sp);   // [batch][2][ncnln] multipliers, estimates

@@ -9,6 +9,7 @@ struct ntg_plan {
 	NtgDims D;
 	NtgTables T;
 	bool lin_ok = true;
+	bool precond_ready = false;                 // W0 tables (T.n0 or T.n0b) built
 	std::vector<void *> owned;                  // device allocations
 	std::vector<std::vector<double>> h_knots;   // host mirrors of the setup tables
 	std::vector<double> h_bps, h_blk, h_aband, h_Adense;

@@ -224,10 +224,10 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 		for (int i = tid; i <= D.nclin; i += NT) sp_[i] = T.sinv_ptr[i];
 		for (int i = tid; i < D.sinv_nnz; i += NT) { sc[i] = T.sinv_col[i]; sv[i] = T.sinv_val[i]; }
 	}
-	// per-output scalars: k, m, l, d, iC, iz, class blk offset, class off offset, class ivl offset, ncoef
+	// per-output scalars: k, m, preconditioner block, d, iC, iz, class blk offset, class off offset, class ivl offset, ncoef
 	for (int o = tid; o < D.nout; o += NT) {
 		int *q = S.oinfo + o * 10;
-		q[0] = D.order[o]; q[1] = D.mult[o]; q[2] = D.ninterv[o]; q[3] = D.d[o]; q[4] = D.iC[o]; q[5] = D.iz[o];
+		q[0] = D.order[o]; q[1] = D.mult[o]; q[2] = D.n0_blk[o]; q[3] = D.d[o]; q[4] = D.iC[o]; q[5] = D.iz[o];
 		q[6] = D.cls[o] * NTG_MAX_ORDER; q[7] = D.cls[o] * D.P; q[8] = D.cls_W[D.cls[o]]; q[9] = D.ncoef[o];
 	}
 	for (int v = tid; v < D.nz; v += NT) S.tavrow[v] = D.tav_row[v];
@@ -726,10 +726,79 @@ __device__ __attribute__((noinline)) void apply_n0(int n, int w, const double *_
 	}
 }
 
-// out = W0 v : identity on null(A) (cold start) or the collocation preconditioner
-template <int NT, bool BIG>
-__device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out)
+// out = W0 v when W0 is block diagonal by output with equally sized dense blocks, few of them distinct (one basis
+// class, the same constraint pattern at the ends; outputs with the same cost derivative share a block): small dense
+// products  Out(nco x nout_b) = Wb(nco x nco) V(nco x nout_b).  A lane owns one row of the block for a share of
+// the outputs, so every word of Wb it reads from L2 is used for several outputs (the ELL form streams one copy of
+// the block per output).  V is staged in LDS (`stage`, laid out like v) and read
+// as broadcasts; `out` may alias `stage`: it is only written after the last read.
+typedef const __attribute__((address_space(3))) double *lds_cdp;
+typedef const __attribute__((address_space(3))) int *lds_cip;
+// OPP = outputs per lane (compile time, so that the accumulators are plain registers and the inner loop has no
+// branches); outputs beyond the lane's share are computed on a clamped index and dropped.
+template <int NT, int OPP>
+__device__ __attribute__((noinline)) void apply_n0_block(int nout, int nco, int spad, int nblk, int parts, const double *__restrict__ wb,
+                                                         lds_cip oinfo, lds_cdp stage, double *out)
 {
+	constexpr int U = 16;
+	// nco <= NT (checked by the caller): lane i owns row (i mod nco) of the block for the outputs of part (i / nco)
+	const int opp = (nout + parts - 1) / parts;   // outputs per part (<= OPP)
+	const int i = threadIdx.x, part = min(i / nco, parts - 1), row = i - (i / nco) * nco, o0 = part * opp;
+	const int no = i < parts * nco ? min(opp, nout - o0) : 0;
+	double acc[OPP];
+	int base[OPP], blk[OPP];
+#pragma unroll
+	for (int j = 0; j < OPP; j++) {
+		const int o = min(o0 + j, nout - 1);
+		acc[j] = 0.0; base[j] = o * nco; blk[j] = j < no ? oinfo[o * 10 + 2] : -1;
+	}
+	for (int b = 0; b < nblk; b++) {   // outputs that share block b reuse every word of it
+		const double *wbb = wb + (size_t)b * spad * nco + row;
+		for (int s0 = 0; s0 < spad; s0 += U) {
+			// U independent L2 loads in flight per lane (rows beyond nco are zero padding), then the FMAs
+			double wv[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) wv[u] = wbb[(size_t)(s0 + u) * nco];   // consecutive lanes, consecutive words
+#pragma unroll
+			for (int u = 0; u < U; u++) {
+				const int sidx = min(s0 + u, nco - 1);
+#pragma unroll
+				for (int j = 0; j < OPP; j++) {
+					const double sv = stage[base[j] + sidx];
+					acc[j] = fma(wv[u], blk[j] == b ? sv : 0.0, acc[j]);
+				}
+			}
+		}
+	}
+	lds_sync();   // every read of stage is done: out may be the same buffer
+#pragma unroll
+	for (int j = 0; j < OPP; j++) { if (j < no) out[base[j] + row] = acc[j]; }
+}
+template <int NT>
+__device__ __forceinline__ void apply_n0_block_any(int nout, int nco, int spad, int nblk, const double *wb, lds_cip oinfo, lds_cdp stage, double *out)
+{
+	const int parts = min(NT / nco, nout), opp = (nout + parts - 1) / parts;
+	if (opp <= 2) apply_n0_block<NT, 2>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
+	else if (opp <= 4) apply_n0_block<NT, 4>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
+	else if (opp <= 6) apply_n0_block<NT, 6>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
+	else if (opp <= 8) apply_n0_block<NT, 8>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
+	else apply_n0_block<NT, NTG_MAX_OUT>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
+}
+
+// out = W0 v : identity on null(A) (cold start) or the collocation preconditioner.  `stage` is an LDS buffer of
+// nC doubles that is free at every call site (the trial point: it is rebuilt from x and d afterwards).
+template <int NT, bool BIG>
+__device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out, double *stage, const int *oinfo)
+{
+	if (hessian == 1 && T.n0b && T.n0b_n <= NT) {
+		lds_sync();   // previous readers of stage are done
+		for_vec<NT>(D.nC, [&](int c) { stage[c] = v[c]; });   // owner lanes: v may live in HBM
+		lds_sync();
+		apply_n0_block_any<NT>(D.nout, T.n0b_n, T.n0b_sp, T.n0b_nblk, T.n0b, (lds_cip)oinfo, (lds_cdp)stage, out);
+		if (BIG) __syncthreads();   // out may live in HBM and was written by row, not by owner lane
+		else lds_sync();
+		return;
+	}
 	if (BIG) __syncthreads();   // v lives in HBM/L2 and apply_n0 reads it across lanes
 	else lds_sync();
 	if (hessian == 1 && T.n0) apply_n0<NT>(D.nC, T.n0_w, T.n0, T.n0c, v, out);
@@ -952,7 +1021,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (state == ST_INIT) {
 				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
-				apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd);
+				apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
 				for_vec<NT>(n, [&](int c) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; });
 				block_sum<NT, 4>(r4, S.red);
@@ -982,7 +1051,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (npairs > 0 && sqrt(r4[3]) > tolg) {
 						// line search failed with a non-trivial W: drop the pairs and retry from the same point with W0
 						npairs = 0;
-						apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd);
+						apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 						double r2[2] = {0, 0};
 						for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 						block_sum<NT, 2>(r2, S.red);
@@ -1001,9 +1070,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					alpha = lsm->a;
 					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
 					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
-					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd); } // memory full: restart
+					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
 					NTG_STAMP(5);
-					apply_w0<NT, BIG>(D, T, sp.hessian, sgpt, st);
+					apply_w0<NT, BIG>(D, T, sp.hessian, sgpt, st, sxt, S.oinfo);
 					NTG_STAMP(4);
 					apply_history<NT>(D, S, hist, npairs, sgpt, st);
 					NTG_STAMP(3);
@@ -1061,7 +1130,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (pnorm == 0.0 || !(dphi0 < 0.0)) {
 						if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
 							npairs = 0;
-							apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd);
+							apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 							double r2[2] = {0, 0};
 							for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 							block_sum<NT, 2>(r2, S.red);

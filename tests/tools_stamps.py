@@ -5,13 +5,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ntg_amd import api, configs as cf
 cfg = sys.argv[1] if len(sys.argv) > 1 else "M"
-spec = cf.config_M() if cfg == "M" else cf.config_B()
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-lo, up = cf.kincar_random_bounds(spec.nout // 2, B)
+if cfg == "D":
+    spec = cf.config_D(); lo, up = cf.quadrotor_bounds(B)
+elif cfg == "E":
+    spec = cf.config_E(); lo, up = cf.manipulator_bounds(B)
+else:
+    spec = cf.config_M() if cfg == "M" else cf.config_B()
+    lo, up = cf.kincar_random_bounds(spec.nout // 2, B)
 dev = torch.device("cuda:0")
 plan = api.Plan(spec, 0)
 x = torch.ones((B, spec.nC), dtype=torch.float64, device=dev)
-for mode in (dict(itlim=50, fixed_iters=1, hessian=0), dict(hessian=1, itlim=50)):
+for mode in ((dict(hessian=1),) if cfg in "DE" else (dict(itlim=50, fixed_iters=1, hessian=0), dict(hessian=1, itlim=50))):
     x.fill_(1.0)
     out = plan.solve(torch.tensor(lo, device=dev), torch.tensor(up, device=dev), x, api.default_opts(**mode), want_lambda=True)
     torch.cuda.synchronize()
