@@ -67,6 +67,10 @@ typedef struct {
 	int nicf, nucf, nfcf;
 	int nicostav, ntcostav, nfcostav;
 	const ntg_av *icostav, *tcostav, *fcostav;
+	/* optional, may be NULL: [nlic+nltc+nlfc] flags, non-zero = this linear row is an INEQUALITY row (lower <= row <= upper)
+	 * for every problem of the batch.  Rows not flagged must have lower == upper in every problem (they are kept satisfied
+	 * by projection); a problem that breaks this returns inform 9.  ntg() itself needs no flags: it reads the bounds. */
+	const int *lin_ineq;
 } ntg_spec;
 
 typedef struct {

@@ -34,7 +34,8 @@ class _Spec(C.Structure):
                 ("icav", C.POINTER(_AV)), ("tcav", C.POINTER(_AV)), ("fcav", C.POINTER(_AV)),
                 ("nicf", C.c_int), ("nucf", C.c_int), ("nfcf", C.c_int),
                 ("nicostav", C.c_int), ("ntcostav", C.c_int), ("nfcostav", C.c_int),
-                ("icostav", C.POINTER(_AV)), ("tcostav", C.POINTER(_AV)), ("fcostav", C.POINTER(_AV))]
+                ("icostav", C.POINTER(_AV)), ("tcostav", C.POINTER(_AV)), ("fcostav", C.POINTER(_AV)),
+                ("lin_ineq", ip)]
 
 
 class SolveOpts(C.Structure):
@@ -125,6 +126,10 @@ class Plan:
         s.nicf, s.nucf, s.nfcf = spec.nicf, spec.nucf, spec.nfcf
         s.nicostav, s.ntcostav, s.nfcostav = len(spec.icostav), len(spec.tcostav), len(spec.fcostav)
         s.icostav, s.tcostav, s.fcostav = k["icostav"], k["tcostav"], k["fcostav"]
+        if len(spec.lin_ineq):
+            assert len(spec.lin_ineq) == spec.nlic + spec.nltc + spec.nlfc
+            k["lin_ineq"] = np.asarray(spec.lin_ineq, dtype=np.int32)
+            s.lin_ineq = k["lin_ineq"].ctypes.data_as(ip)
         self._cspec = s
         h = C.c_void_p()
         _check(lib().ntg_plan_create(C.byref(s), device, C.byref(h)))

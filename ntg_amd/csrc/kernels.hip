@@ -359,7 +359,6 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
 	L.off = p; p = align16(p + D.nclass * D.P * 4);
 	L.bps = p; p = align16(p + D.P * 8);
 	L.wts = p; p = align16(p + D.P * 8);
-	L.ivl_lo = L.ivl_hi = p;
 	L.x = p; if (with_x) p = align16(p + npad * 8);
 	L.dfz = p; p = align16(p + (D.ntav > 0 ? D.ntav : 1) * (D.P + 1) * 8);   // [row][P+1], last entry stays 0 (padding target)
 	L.fvals = p; p = align16(p + D.P * 8);
@@ -372,6 +371,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
 	L.oinfo = p; p = align16(p + D.nout * 10 * 4);
 	L.tavrow = p; p = align16(p + D.nz * 4);
 	L.ls = p; p = align16(p + (int)sizeof(LineSearch));
+	L.tI = p; p = align16(p + (D.nI + 1) * 8);   // multiplier estimates of the linear inequality rows
 	L.q_idx = L.q_col = L.q_val = p;
 	if (D.q_use) {
 		L.q_idx = p; p = align16(p + D.nC * 2);

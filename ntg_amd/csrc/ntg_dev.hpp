@@ -23,18 +23,18 @@ struct NtgDims {
 	int family;
 	int order[NTG_MAX_OUT], mult[NTG_MAX_OUT], ninterv[NTG_MAX_OUT], d[NTG_MAX_OUT];
 	int ncoef[NTG_MAX_OUT], iC[NTG_MAX_OUT], iz[NTG_MAX_OUT], koff[NTG_MAX_OUT], cls[NTG_MAX_OUT];
-	int nclass, blk_total, ivl_total;
-	int cls_blk[NTG_MAX_OUT], cls_ivl[NTG_MAX_OUT], cls_k[NTG_MAX_OUT], cls_d[NTG_MAX_OUT], cls_l[NTG_MAX_OUT], cls_m[NTG_MAX_OUT];
+	int nclass, blk_total;
+	int cls_blk[NTG_MAX_OUT], cls_k[NTG_MAX_OUT], cls_d[NTG_MAX_OUT], cls_l[NTG_MAX_OUT], cls_m[NTG_MAX_OUT];
 	u64 icost_mask, tcost_mask, fcost_mask, icon_mask, tcon_mask, fcon_mask;
 	// running-cost gradient rows kept in LDS: only the flag entries that can be non-zero
 	// (the declared trajectory-cost active variables; all of them for host callbacks)
 	int ntav;
 	signed char tav_row[NTG_MAX_NZ];   // flat flag index -> compact row, or -1
 	int uniform;                        // 1: one basis class and equal ncoef for every output
-	int lin_nnz, lin_lds;               // sparse A (exact zeros dropped); 1: staged in LDS
+	int mE, nI;                         // linear rows kept by projection (equalities) / handled by the AL loop (declared inequalities)
+	int lin_nnz, lin_lds;               // sparse A_E (exact zeros dropped); 1: staged in LDS
 	int sinv_nnz;                       // sparse (A A')^-1 (block diagonal when the rows decouple)
 	int q_use, q_nt, q_w;               // projector Q = A'(AA')^-1 A kept as ELL over its non-zero rows
-	int max_bpi;                        // most breakpoints inside one knot interval (over classes)
 	// collocation matrix of every ACTIVE (class, derivative) channel, in two sparse forms
 	int row_total, col_total;           // doubles in rowv / entries in colv+coli
 	int cls_W[NTG_MAX_OUT];             // padded (multiple of 4) support width of the column form, per class
@@ -47,8 +47,6 @@ struct NtgTables {
 	const double *bps;     // [P]
 	const double *blk;     // [blk_total]
 	const int *off;        // [nclass][P]
-	const int *ivl_lo;     // [ivl_total] first breakpoint of each knot interval, per class
-	const int *ivl_hi;     // [ivl_total] last breakpoint (inclusive); lo > hi if the interval holds none
 	const double *aband;   // [nclin][sumk]
 	const int *rbp;        // [nclin]
 	const double *sinv;    // [nclin][nclin]  (A A')^-1
@@ -67,6 +65,10 @@ struct NtgTables {
 	// matrix: value = rowv[chrow + q*P + i], breakpoint i; padding entries are (P)<<16 | P -> weight 0
 	// chrow/chcol[class*NTG_MAX_ORDER + r] = channel offsets, -1 when no active variable uses D^r
 	const double *rowv; const unsigned int *colp; const int *chrow, *chcol;
+	// linear rows: erow[mE] = original row of equality e; rowmap[nclin] = e, or -(j+1) for inequality j; linflag[slot]
+	// = 1 for slots declared as inequalities; inequality rows as CSR (by row) and CSC (by coefficient)
+	const int *erow, *rowmap, *linflag, *irow;
+	const int *icsr_ptr, *icsr_col, *icsc_ptr, *icsc_row; const double *icsr_val, *icsc_val;
 	const short *q_idx;    // [nC] row of coefficient c in the compact Q, or -1
 	const int *q_col;      // [q_nt][q_w]
 	const double *q_val;   // [q_nt][q_w], zero padded
@@ -74,8 +76,8 @@ struct NtgTables {
 
 // byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
 struct SmemLayout {
-	int rowv, colp, chrow, chcol, off, bps, wts, ivl_lo, ivl_hi, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
-	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, q_idx, q_col, q_val, ls, total;
+	int rowv, colp, chrow, chcol, off, bps, wts, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
+	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, q_idx, q_col, q_val, ls, tI, total;
 };
 
 struct SolveParams {

@@ -401,8 +401,8 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 				double pen = 0.0, rv2 = 0.0;
 				for (int j = 0; j < nal; j++) {
 					const double cj = cval[j], v = cj + allam[j] / mu;
-					const double pj = v < nbl[j] ? nbl[j] : (v > nbu[j] ? nbu[j] : v), cc = cj < nbl[j] ? nbl[j] : (cj > nbu[j] ? nbu[j] : cj);
-					const double tj = mu * (v - pj), rj = (cj - cc) / (1.0 + std::fabs(cj));
+					const double pj = v < nbl[j] ? nbl[j] : (v > nbu[j] ? nbu[j] : v);
+					const double tj = mu * (v - pj), rj = (cj - pj) / (1.0 + std::fabs(cj));   // violation and complementarity (see sqp_kernel)
 					tnew[j] = tj; pen += (tj - allam[j]) * (tj + allam[j]) / (2.0 * mu); rv2 += rj * rj;
 				}
 				Fv += pen;

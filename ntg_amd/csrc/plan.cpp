@@ -154,7 +154,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	for (int o = 0; o < s->nout; o++) p->h_knots[o].assign(s->knots[o], s->knots[o] + s->kninterv[o] + 1);
 	D.nclass = 0;
 	std::vector<int> rep;
-	int blk_total = 0, ivl_total = 0;
+	int blk_total = 0;
 	for (int o = 0; o < s->nout; o++) {
 		int c = -1;
 		for (int j = 0; j < D.nclass; j++) {
@@ -165,14 +165,13 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		if (c < 0) {
 			c = D.nclass++;
 			rep.push_back(o);
-			D.cls_blk[c] = blk_total; D.cls_ivl[c] = ivl_total;
+			D.cls_blk[c] = blk_total;
 			D.cls_k[c] = D.order[o]; D.cls_d[c] = D.d[o]; D.cls_l[c] = D.ninterv[o]; D.cls_m[c] = D.mult[o];
 			blk_total += s->nbps * D.order[o] * D.d[o];
-			ivl_total += D.ninterv[o];
 		}
 		D.cls[o] = c;
 	}
-	D.blk_total = blk_total; D.ivl_total = ivl_total;
+	D.blk_total = blk_total;
 	D.tav_rmask = 0;
 	for (int o = 0; o < s->nout; o++) for (int r = 0; r < D.d[o]; r++) if (D.tav_row[D.iz[o] + r] >= 0) D.tav_rmask |= 1 << r;
 	D.uniform = D.nclass == 1;
@@ -200,24 +199,9 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	p->h_blk.resize(blk_total); p->h_off.resize((size_t)D.nclass * s->nbps);
 	HIPCHK(hipMemcpy(p->h_blk.data(), d_blk, (size_t)blk_total * 8, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(p->h_off.data(), d_off, p->h_off.size() * 4, hipMemcpyDeviceToHost));
-	// interval -> breakpoint ranges (monotone bounds, see kernels.hip eval_cost)
-	std::vector<int> ivl_lo(ivl_total > 0 ? ivl_total : 1), ivl_hi(ivl_total > 0 ? ivl_total : 1);
-	for (int c = 0; c < D.nclass; c++) {
-		const int km = D.cls_k[c] - D.cls_m[c], l = D.cls_l[c], P = s->nbps;
-		const int *off = p->h_off.data() + (size_t)c * P;
-		for (int j = 0; j < l; j++) {
-			int lo = P, hi = -1;
-			for (int i = 0; i < P; i++) { const int iv = off[i] / km; if (iv >= j && i < lo) lo = i; if (iv <= j) hi = i; }
-			ivl_lo[D.cls_ivl[c] + j] = lo; ivl_hi[D.cls_ivl[c] + j] = hi;
-		}
-	}
-	D.max_bpi = 0;
-	for (int c = 0; c < D.nclass; c++) for (int j = 0; j < D.cls_l[c]; j++) D.max_bpi = std::max(D.max_bpi, ivl_hi[D.cls_ivl[c] + j] - ivl_lo[D.cls_ivl[c] + j] + 1);
-	int *d_ilo = nullptr, *d_ihi = nullptr;
-	if (dev_upload(&d_ilo, ivl_lo.data(), ivl_lo.size(), own) || dev_upload(&d_ihi, ivl_hi.data(), ivl_hi.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 	NtgTables &T = p->T;
 	std::memset(&T, 0, sizeof(T));
-	T.bps = d_bps; T.blk = d_blk; T.off = d_off; T.ivl_lo = d_ilo; T.ivl_hi = d_ihi;
+	T.bps = d_bps; T.blk = d_blk; T.off = d_off;
 	// ---- active (class, derivative) channels: a derivative row is kept on chip only if some
 	//      active variable (any of the six lists) uses it; host callbacks use all of them ----
 	{
@@ -279,10 +263,46 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		HIPCHK(hipMemcpy(p->h_aband.data(), d_ab, p->h_aband.size() * 8, hipMemcpyDeviceToHost));
 		HIPCHK(hipMemcpy(p->h_rbp.data(), d_rbp, p->h_rbp.size() * 4, hipMemcpyDeviceToHost));
 		T.aband = d_ab; T.rbp = d_rbp;
-		// dense rows -> S = A A' -> S^-1
-		const int m = D.nclin;
-		std::vector<double> Ad((size_t)m * nC, 0.0);
-		ntg_plan_dense_A(p, Ad.data());
+		// dense rows; split into the equality rows (kept satisfied by projection) and the rows declared as
+		// inequalities (spec->lin_ineq, handled by the augmented-Lagrangian loop like nonlinear rows)
+		const int mall = D.nclin;
+		std::vector<double> Aall((size_t)mall * nC, 0.0);
+		ntg_plan_dense_A(p, Aall.data());
+		std::vector<int> erow, irow, rowmap(mall), linflag((size_t)std::max(1, s->nlic + s->nltc + s->nlfc), 0);
+		for (int r = 0; r < mall; r++) {
+			int slot;
+			if (r < s->nlic) slot = r;
+			else if (r < s->nlic + s->nltc * s->nbps) slot = s->nlic + (r - s->nlic) / s->nbps;
+			else slot = s->nlic + s->nltc + (r - s->nlic - s->nltc * s->nbps);
+			const bool ineq = s->lin_ineq && s->lin_ineq[slot] != 0;
+			linflag[slot] = ineq ? 1 : 0;
+			if (ineq) { rowmap[r] = -(int)irow.size() - 1; irow.push_back(r); } else { rowmap[r] = (int)erow.size(); erow.push_back(r); }
+		}
+		const int m = (int)erow.size(), nI = (int)irow.size();
+		D.mE = m; D.nI = nI;
+		std::vector<double> Ad((size_t)std::max(m, 1) * nC, 0.0);
+		for (int i = 0; i < m; i++) std::copy(&Aall[(size_t)erow[i] * nC], &Aall[(size_t)erow[i] * nC] + nC, &Ad[(size_t)i * nC]);
+		{
+			int *d_er = nullptr, *d_rm = nullptr, *d_lf = nullptr;
+			if (erow.empty()) erow.push_back(0);
+			if (dev_upload(&d_er, erow.data(), erow.size(), own) || dev_upload(&d_rm, rowmap.data(), rowmap.size(), own) ||
+			    dev_upload(&d_lf, linflag.data(), linflag.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+			T.erow = d_er; T.rowmap = d_rm; T.linflag = d_lf;
+		}
+		if (nI > 0) {   // inequality rows: CSR (c = A_r x) and CSC (g += A_r' t), exact zeros dropped
+			std::vector<int> rptr(nI + 1, 0), rcol, cptr(nC + 1, 0), crow;
+			std::vector<double> rval, cval;
+			for (int j = 0; j < nI; j++) { const double *row = &Aall[(size_t)irow[j] * nC]; for (int c = 0; c < nC; c++) if (row[c] != 0.0) { rcol.push_back(c); rval.push_back(row[c]); } rptr[j + 1] = (int)rcol.size(); }
+			for (int c = 0; c < nC; c++) { for (int j = 0; j < nI; j++) { const double v = Aall[(size_t)irow[j] * nC + c]; if (v != 0.0) { crow.push_back(j); cval.push_back(v); } } cptr[c + 1] = (int)crow.size(); }
+			if (rcol.empty()) { rcol.push_back(0); rval.push_back(0.0); crow.push_back(0); cval.push_back(0.0); }
+			int *d_ir = nullptr, *d_rp = nullptr, *d_rc = nullptr, *d_cp = nullptr, *d_cr = nullptr; double *d_rv = nullptr, *d_cv = nullptr;
+			if (dev_upload(&d_ir, irow.data(), irow.size(), own) || dev_upload(&d_rp, rptr.data(), rptr.size(), own) ||
+			    dev_upload(&d_rc, rcol.data(), rcol.size(), own) || dev_upload(&d_rv, rval.data(), rval.size(), own) ||
+			    dev_upload(&d_cp, cptr.data(), cptr.size(), own) || dev_upload(&d_cr, crow.data(), crow.size(), own) ||
+			    dev_upload(&d_cv, cval.data(), cval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+			T.irow = d_ir; T.icsr_ptr = d_rp; T.icsr_col = d_rc; T.icsr_val = d_rv; T.icsc_ptr = d_cp; T.icsc_row = d_cr; T.icsc_val = d_cv;
+		}
+		// S = A_E A_E' -> S^-1
 		std::vector<double> S((size_t)m * m, 0.0);
 		for (int i = 0; i < m; i++) for (int j = 0; j <= i; j++) {
 			double a = 0.0;
@@ -346,7 +366,8 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		}
 		// the general three-step operator (A g, (AA')^-1, A' lam) is staged in LDS only when Q is not used
 		D.lin_lds = (!D.q_use && ((size_t)D.lin_nnz * 24 + (size_t)D.sinv_nnz * 12 + (size_t)(2 * m + nC + 3) * 4) <= 24 * 1024) ? 1 : 0;
-		p->h_Adense.swap(Ad);
+		p->h_Adense.swap(Aall);
+		p->h_AE.swap(Ad);
 	} else {
 		p->lin_ok = true;
 	}
@@ -464,7 +485,7 @@ static int precond_block(const std::vector<double> &H0, const std::vector<double
 static int build_precond(ntg_plan *p)
 {
 	const NtgDims &D = p->D;
-	const int n = D.nC, m = D.nclin, P = D.P;
+	const int n = D.nC, m = D.mE, P = D.P;
 	if (n - m <= 0) return fail(NTG_E_UNSUPPORTED, "no free directions");
 	if (n > 65535) return fail(NTG_E_UNSUPPORTED, "preconditioner: more than 65535 coefficients");
 	// components of outputs under "some row of A touches both"
@@ -472,7 +493,7 @@ static int build_precond(ntg_plan *p)
 	for (int o = 0; o < D.nout; o++) { comp[o] = o; for (int j = 0; j < D.ncoef[o]; j++) outof[D.iC[o] + j] = o; }
 	for (int r = 0; r < m; r++) {
 		int first = -1;
-		for (int j = 0; j < n; j++) if (p->h_Adense[(size_t)r * n + j] != 0.0) {
+		for (int j = 0; j < n; j++) if (p->h_AE[(size_t)r * n + j] != 0.0) {
 			const int c = comp[outof[j]];
 			if (first < 0) first = c;
 			else if (c != first) { const int lo = std::min(c, first), hi = std::max(c, first); for (int o = 0; o < D.nout; o++) if (comp[o] == hi) comp[o] = lo; first = lo; }
@@ -484,7 +505,7 @@ static int build_precond(ntg_plan *p)
 		if (comp[o0] != o0) continue;
 		std::vector<int> idx, rsel, loc(n, -1);
 		for (int j = 0; j < n; j++) if (comp[outof[j]] == o0) { loc[j] = (int)idx.size(); idx.push_back(j); }
-		for (int r = 0; r < m; r++) { bool hit = false; for (int j : idx) if (p->h_Adense[(size_t)r * n + j] != 0.0) { hit = true; break; } if (hit) rsel.push_back(r); }
+		for (int r = 0; r < m; r++) { bool hit = false; for (int j : idx) if (p->h_AE[(size_t)r * n + j] != 0.0) { hit = true; break; } if (hit) rsel.push_back(r); }
 		const int nb = (int)idx.size(), mb = (int)rsel.size();
 		std::vector<double> H0((size_t)nb * nb, 0.0), Ab((size_t)std::max(mb, 1) * nb, 0.0), Wb;
 		auto add = [&](const std::vector<ntg_av> &av, int bp, double w) {
@@ -505,7 +526,7 @@ static int build_precond(ntg_plan *p)
 		}
 		if (D.nicf) add(p->icostav, 0, 1.0);
 		if (D.nfcf) add(p->fcostav, P - 1, 1.0);
-		for (int i = 0; i < mb; i++) for (int j = 0; j < nb; j++) Ab[(size_t)i * nb + j] = p->h_Adense[(size_t)rsel[i] * n + idx[j]];
+		for (int i = 0; i < mb; i++) for (int j = 0; j < nb; j++) Ab[(size_t)i * nb + j] = p->h_AE[(size_t)rsel[i] * n + idx[j]];
 		const int rc = precond_block(H0, Ab, mb, nb, Wb);
 		if (rc) return rc;
 		{
@@ -578,7 +599,7 @@ static int solve_layout(const NtgDims &D, int nt, SmemLayout *L, int *big)
 	return L->total <= 160 * 1024 ? 0 : -1;
 }
 static size_t hist_doubles(const NtgDims &D, int batch, const SolveParams &sp) { return (size_t)batch * sp.memcap * (2 * D.nC + 2); }
-static size_t al_doubles(const NtgDims &D, int batch) { return (size_t)batch * 2 * D.ncnln; }
+static size_t al_doubles(const NtgDims &D, int batch) { return (size_t)batch * 2 * (D.ncnln + D.nI); }
 
 extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, const ntg_solve_opts *o)
 {

@@ -12,7 +12,7 @@ struct ntg_plan {
 	bool precond_ready = false;                 // W0 tables (T.n0 or T.n0b) built
 	std::vector<void *> owned;                  // device allocations
 	std::vector<std::vector<double>> h_knots;   // host mirrors of the setup tables
-	std::vector<double> h_bps, h_blk, h_aband, h_Adense;
+	std::vector<double> h_bps, h_blk, h_aband, h_Adense, h_AE;   // h_Adense: all linear rows; h_AE: the equality rows
 	std::vector<int> h_off, h_rbp, class_rep;
 	std::vector<ntg_av> icostav, tcostav, fcostav;
 	double *d_lic = nullptr;                    // [nlic][nz] kept for the receding-horizon shift

@@ -167,7 +167,7 @@ __device__ __forceinline__ void for_vec(int n, F f)
 // ------------------------------------------------------------------------------------------
 struct Smem {
 	double *rowv; unsigned int *colp; int *chrow, *chcol;
-	int *off; double *bps, *wts; int *ivl_lo, *ivl_hi;
+	int *off; double *bps, *wts;
 	double *x, *dfz, *fvals, *red, *dfi, *dff, *vecs, *lam, *rho, *c2;
 	// sparse linear-constraint operator: LDS copies when they fit, HBM/L2 otherwise
 	const int *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col; const double *csr_val, *csc_val, *sinv_val;
@@ -179,7 +179,6 @@ struct Smem {
 		chrow = (int *)(base + L.chrow); chcol = (int *)(base + L.chcol);
 		off = (int *)(base + L.off); bps = (double *)(base + L.bps);
 		wts = (double *)(base + L.wts);
-		ivl_lo = (int *)(base + L.ivl_lo); ivl_hi = (int *)(base + L.ivl_hi);
 		x = (double *)(base + L.x); dfz = (double *)(base + L.dfz); fvals = (double *)(base + L.fvals);
 		red = (double *)(base + L.red); dfi = (double *)(base + L.dfi); dff = (double *)(base + L.dff);
 		vecs = (double *)(base + L.vecs); lam = (double *)(base + L.lam); rho = (double *)(base + L.rho);
@@ -218,13 +217,13 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 		int *rp = (int *)(base + L.csr_ptr), *rc = (int *)(base + L.csr_col), *cp = (int *)(base + L.csc_ptr), *cr = (int *)(base + L.csc_row);
 		double *rv = (double *)(base + L.csr_val), *cv = (double *)(base + L.csc_val), *sv = (double *)(base + L.sinv_val);
 		int *sp_ = (int *)(base + L.sinv_ptr), *sc = (int *)(base + L.sinv_col);
-		for (int i = tid; i <= D.nclin; i += NT) rp[i] = T.csr_ptr[i];
+		for (int i = tid; i <= D.mE; i += NT) rp[i] = T.csr_ptr[i];
 		for (int i = tid; i <= D.nC; i += NT) cp[i] = T.csc_ptr[i];
 		for (int i = tid; i < D.lin_nnz; i += NT) { rc[i] = T.csr_col[i]; rv[i] = T.csr_val[i]; cr[i] = T.csc_row[i]; cv[i] = T.csc_val[i]; }
-		for (int i = tid; i <= D.nclin; i += NT) sp_[i] = T.sinv_ptr[i];
+		for (int i = tid; i <= D.mE; i += NT) sp_[i] = T.sinv_ptr[i];
 		for (int i = tid; i < D.sinv_nnz; i += NT) { sc[i] = T.sinv_col[i]; sv[i] = T.sinv_val[i]; }
 	}
-	// per-output scalars: k, m, preconditioner block, d, iC, iz, class blk offset, class off offset, class ivl offset, ncoef
+	// per-output scalars: k, m, preconditioner block, d, iC, iz, channel base, offset-table base, column-form width, ncoef
 	for (int o = tid; o < D.nout; o += NT) {
 		int *q = S.oinfo + o * 10;
 		q[0] = D.order[o]; q[1] = D.mult[o]; q[2] = D.n0_blk[o]; q[3] = D.d[o]; q[4] = D.iC[o]; q[5] = D.iz[o];
@@ -353,6 +352,46 @@ struct ALState {
 	const double *lo, *up; // this problem's rows of lowerb/upperb [nbounds]
 };
 
+// one constraint value -> multiplier estimate t; adds the row's augmented-Lagrangian term and squared scaled residual
+__device__ __forceinline__ double al_row(double mu, double lamj, double l, double u, double cj, double &psi, double &rv2)
+{
+	const double v = cj + lamj / mu;
+	const double pj = v < l ? l : (v > u ? u : v);
+	// c - p: |c - b| for an active row, min(slack, lam/mu) for a feasible one -- zero only when feasibility AND
+	// complementarity hold (the measure of LANCELOT / ALGENCAN)
+	const double t = mu * (v - pj), rj = (cj - pj) / (1.0 + fabs(cj));
+	psi += (t - lamj) * (t + lamj) / (2.0 * mu);   // factored: no cancellation when c is tiny
+	rv2 += rj * rj;
+	return t;
+}
+
+// bound slot (index into lowerb/upperb) of linear row r: [lic; ltc constraint-major x breakpoint; lfc] (constraints.c:5-33)
+__device__ __forceinline__ int lin_slot(const NtgDims &D, int r)
+{
+	if (r < D.nlic) return r;
+	if (r < D.nlic + D.nltc * D.P) return D.nlic + (r - D.nlic) / D.P;
+	return D.nlic + D.nltc + (r - D.nlic - D.nltc * D.P);
+}
+
+// Linear rows declared as inequalities (ntg_spec.lin_ineq): c_j = A_j x enters the augmented Lagrangian like a
+// nonlinear row with a constant Jacobian.  Lanes take rows; t_j goes to LDS (tI) for the gradient pass and to HBM
+// (the next multiplier estimate).  Runs between the functor pass and the quadrature / gather pass.
+struct LinIneq {
+	int nI; const int *irow, *rptr, *rcol, *cptr, *crow; const double *rval, *cval; double *tI;
+};
+template <int NT>
+__device__ __forceinline__ void lin_ineq_phase(const NtgDims &D, const LinIneq &li, const double *sx, const ALState &al, double &psi, double &rv2)
+{
+	for (int j = threadIdx.x; j < li.nI; j += NT) {
+		double cj = 0.0;
+		for (int e = li.rptr[j]; e < li.rptr[j + 1]; e++) cj += li.rval[e] * sx[li.rcol[e]];
+		const int slot = lin_slot(D, li.irow[j]), row = D.ncnln + j;
+		const double t = al_row(al.mu, al.lam[row], al.lo[slot], al.up[slot], cj, psi, rv2);
+		al.tnew[row] = t;
+		li.tI[j] = t;
+	}
+}
+
 // per-breakpoint cost functor pass: Z = M C, then ucf/icf/fcf -> fvals, dfz, dfi, dff in LDS
 template <int FAM, int NOUT, int K, int NT>
 __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx, const ALState &al,
@@ -369,12 +408,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 	psi = 0.0; rv2 = 0.0;
 	// one constraint value -> AL term, violation, multiplier estimate; returns t
 	auto al_term = [&](double cj, int row, int slot) -> double {
-		const double lamj = al.lam[row], l = al.lo[slot], u = al.up[slot];
-		const double v = cj + lamj / al.mu;
-		const double pj = v < l ? l : (v > u ? u : v), cc = cj < l ? l : (cj > u ? u : cj);
-		const double t = al.mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
-		psi += (t - lamj) * (t + lamj) / (2.0 * al.mu);   // factored: no cancellation when c is tiny
-		rv2 += rj * rj;
+		const double t = al_row(al.mu, al.lam[row], al.lo[slot], al.up[slot], cj, psi, rv2);
 		al.tnew[row] = t;
 		return t;
 	};
@@ -434,7 +468,8 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 // dfi, dff); shared by the device-functor path and the host-callback path of ntg()
 template <int NOUT, int K, int NT, int DM, int EPT>
 __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<EPT> &cm,
-                                              bool hasI, bool hasF, double psi, double rv2, double *Fpure, double *rv2_out)
+                                              bool hasI, bool hasF, double psi, double rv2, double *Fpure, double *rv2_out,
+                                              const LinIneq *li = nullptr)
 {
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
@@ -515,7 +550,12 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 					if (hasF && cl >= ol && cl < ol + k) dF += S.dff[iz + r] * S.rowv[chr + (cl - ol) * P + P - 1];   // colloc.c:287-316
 				}
 			}
-			const double g = dI + dIn + dF;                       // Vector3Add (matrix.c:177)
+			double g = dI + dIn + dF;                             // Vector3Add (matrix.c:177)
+			if (NOUT == 0 && li) {                                // + A_I' t of the linear inequality rows (generic instances only)
+				double a = 0.0;
+				for (int e = li->cptr[c]; e < li->cptr[c + 1]; e++) a += li->cval[e] * li->tI[li->crow[e]];
+				g += a;
+			}
 			sg[c] = g;
 			acc[1] += g * g;
 		}
@@ -534,7 +574,7 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 template <int FAM, int NOUT, int K, int NT, int EPT>
 __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
                                             const CoefMap<EPT> &cm, const ALState &al, double *Fpure = nullptr,
-                                            double *rv2_out = nullptr, unsigned long long *tk = nullptr)
+                                            double *rv2_out = nullptr, unsigned long long *tk = nullptr, const LinIneq *li = nullptr)
 {
 	using Fam = Family<FAM>;
 	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
@@ -543,9 +583,11 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	if (tk) t0 = __builtin_amdgcn_s_memtime();
 	double psi, rv2;
 	cost_phase1<FAM, NOUT, K, NT>(D, S, sx, al, psi, rv2);
+	const bool lin_on = NOUT == 0 && li && li->nI > 0 && al.mu > 0.0;
+	if (lin_on) lin_ineq_phase<NT>(D, *li, sx, al, psi, rv2);   // sx was complete before the functor pass
 	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
 	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
-	                                          psi, rv2, Fpure, rv2_out);
+	                                          psi, rv2, Fpure, rv2_out, lin_on ? li : nullptr);
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
 }
@@ -666,7 +708,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 template <int NT, bool BIG>
 __device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */)
 {
-	const int m = D.nclin, tid = threadIdx.x;
+	const int m = D.mE, tid = threadIdx.x;
 	if (BIG) __syncthreads();   // g lives in HBM/L2 and is read across lanes
 	else lds_sync();
 	if (m == 0) { for (int c = tid; c < D.nC; c += NT) sgp[c] = sg[c]; lds_sync(); return; }
@@ -774,9 +816,16 @@ __device__ __attribute__((noinline)) void apply_n0_block(int nout, int nco, int 
 #pragma unroll
 	for (int j = 0; j < OPP; j++) { if (j < no) out[base[j] + row] = acc[j]; }
 }
+// One out-of-line entry per workgroup size (like apply_n0: it runs once or twice per major and must not add to the
+// register pressure of the main loop): stage v in LDS, pick the outputs-per-lane instance, multiply.
 template <int NT>
-__device__ __forceinline__ void apply_n0_block_any(int nout, int nco, int spad, int nblk, const double *wb, lds_cip oinfo, lds_cdp stage, double *out)
+__device__ __attribute__((noinline)) void apply_n0_block_any(int nC, int nout, int nco, int spad, int nblk, const double *wb, lds_cip oinfo,
+                                                             const double *v, double *stage_w, double *out)
 {
+	lds_sync();   // previous readers of stage are done
+	for (int c = threadIdx.x; c < nC; c += NT) stage_w[c] = v[c];   // owner lanes: v may live in HBM
+	lds_sync();
+	lds_cdp stage = (lds_cdp)stage_w;
 	const int parts = min(NT / nco, nout), opp = (nout + parts - 1) / parts;
 	if (opp <= 2) apply_n0_block<NT, 2>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
 	else if (opp <= 4) apply_n0_block<NT, 4>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
@@ -787,14 +836,19 @@ __device__ __forceinline__ void apply_n0_block_any(int nout, int nco, int spad, 
 
 // out = W0 v : identity on null(A) (cold start) or the collocation preconditioner.  `stage` is an LDS buffer of
 // nC doubles that is free at every call site (the trial point: it is rebuilt from x and d afterwards).
-template <int NT, bool BIG>
+// HESS = false: the instance is only ever launched with the identity cold start (NPSOL's mode, the fixed-work
+// benchmark): no preconditioner code, in particular no out-of-line calls, in its main loop.
+template <int NT, bool BIG, bool HESS>
 __device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out, double *stage, const int *oinfo)
 {
-	if (hessian == 1 && T.n0b && T.n0b_n <= NT) {
-		lds_sync();   // previous readers of stage are done
-		for_vec<NT>(D.nC, [&](int c) { stage[c] = v[c]; });   // owner lanes: v may live in HBM
+	if (!HESS) {
 		lds_sync();
-		apply_n0_block_any<NT>(D.nout, T.n0b_n, T.n0b_sp, T.n0b_nblk, T.n0b, (lds_cip)oinfo, (lds_cdp)stage, out);
+		for_vec<NT>(D.nC, [&](int c) { out[c] = v[c]; });
+		lds_sync();
+		return;
+	}
+	if (hessian == 1 && T.n0b && T.n0b_n <= NT) {
+		apply_n0_block_any<NT>(D.nC, D.nout, T.n0b_n, T.n0b_sp, T.n0b_nblk, T.n0b, (lds_cip)oinfo, v, stage, out);
 		if (BIG) __syncthreads();   // out may live in HBM and was written by row, not by owner lane
 		else lds_sync();
 		return;
@@ -895,7 +949,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 // (read across lanes by Z = M C at every evaluation) stays in LDS; x, gp, gp+, d and g live in a per-problem HBM/L2
 // workspace `vec_all`.  They are touched element-wise by their owner lane, except in the projection, the feasibility
 // step and the preconditioner, which read a handful of entries across lanes behind a full barrier.
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS>
 __global__ void __launch_bounds__(NT, NTG_SQP_WAVES)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
@@ -905,7 +959,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	Smem S(smem_raw, L, D, T);
-	const int b = blockIdx.x, tid = threadIdx.x, n = D.nC, m = D.nclin, P = D.P;
+	const int b = blockIdx.x, tid = threadIdx.x, n = D.nC, m = D.mE /* rows kept by projection */, P = D.P;
 	if (b >= batch) return;
 	const int npad = (n + 1) & ~1;
 	double *gv = BIG ? vec_all + (size_t)b * 5 * npad : nullptr;
@@ -924,27 +978,35 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	using Fam = Family<FAM>;
 	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
 	const int ncn = D.ncnln;
-	// augmented-Lagrangian state (nonlinear constraints): multipliers and their estimates live in HBM
-	double *al_lam = al_all + (size_t)b * 2 * ncn, *al_t = al_lam + ncn;
-	ALState al{(HASCON && ncn > 0) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
+	// linear rows declared as inequalities ride the same loop; only the generic instances carry that code
+	constexpr bool LIN = NOUT == 0;
+	const int nI = LIN ? D.nI : 0, nal = ncn + nI;
+	// augmented-Lagrangian state (nonlinear rows, then linear inequality rows): multipliers and their estimates live in HBM
+	double *al_lam = al_all + (size_t)b * 2 * (ncn + D.nI), *al_t = al_lam + ncn + D.nI;
+	ALState al{((HASCON && ncn > 0) || nI > 0) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
+	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};
 	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
 	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history / rest
 	unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define NTG_STAMP(slot) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot] += now_ - tlast; tlast = now_; } } while (0)
 	if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
-	// ---- scope check (uniform): linear equalities only ----
+	// ---- scope check (uniform): linear rows are equalities unless the plan declared them inequalities ----
 	{
 		double bad[1] = {0.0};
-		for (int s = tid; s < D.nlic + D.nltc + D.nlfc; s += NT)      // linear rows must be equalities
-			if (lower[(size_t)b * D.nbounds + s] != upper[(size_t)b * D.nbounds + s]) bad[0] += 1.0;
+		for (int s = tid; s < D.nlic + D.nltc + D.nlfc; s += NT) {
+			const double l = lower[(size_t)b * D.nbounds + s], u = upper[(size_t)b * D.nbounds + s];
+			const bool ineq = D.nI > 0 && T.linflag[s] != 0;
+			if (ineq ? !(l <= u) : l != u) bad[0] += 1.0;
+		}
 		block_sum<NT, 1>(bad, S.red);
-		if (bad[0] != 0.0 || (ncn > 0 && (!HASCON || sp.fixed_iters))) inform = 9;
+		if (bad[0] != 0.0 || (ncn > 0 && !HASCON) || (D.nI > 0 && !LIN) || (nal > 0 && sp.fixed_iters)) inform = 9;
 	}
 	double F = 0.0, Fp = 0.0, gn2 = 0.0, rv2 = 0.0, alpha = 0.0, pnorm = 0.0;
 	double sri = sp.sr, rvprev = HUGE_VAL;   // inner tolerance and best violation so far (AL outer loop)
 	int outer = 0, inner_inform = 4;
 	bool at_x = true, weak = false;
 	double mfres = 0.0;   // diagnostic: linear residual seen by the last feasibility step
+	bool final_pass = false;   // the multiplier pass ran: S.lam belongs to the gradient with the estimates al_t, report those
 	if (inform != 9) {
 		// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
 		auto make_feasible = [&]() {
@@ -952,10 +1014,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (BIG) __syncthreads();   // x lives in HBM/L2 and the rows of A read it across lanes
 			else lds_sync();
 			for (int r = tid; r < m; r += NT) {
-				int s;
-				if (r < D.nlic) s = r;
-				else if (r < D.nlic + D.nltc * P) s = D.nlic + (r - D.nlic) / P;
-				else s = D.nlic + D.nltc + (r - D.nlic - D.nltc * P);
+				const int s = lin_slot(D, D.nI > 0 ? T.erow[r] : r);
 				double a = 0.0;
 				for (int e = S.csr_ptr[r]; e < S.csr_ptr[r + 1]; e++) a += S.csr_val[e] * sx[S.csr_col[e]];
 				tmp[r] = lower[(size_t)b * D.nbounds + s] - a;
@@ -978,7 +1037,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		make_feasible();
 		for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 		if (al.mu > 0.0) {
-			for (int j = tid; j < ncn; j += NT) al_lam[j] = 0.0;
+			for (int j = tid; j < nal; j += NT) al_lam[j] = 0.0;
 			sri = fmax(sp.sr, 1e-3);
 			__syncthreads();   // multipliers cross lanes through HBM: full barrier
 		}
@@ -992,7 +1051,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		for (;;) {
 			// ================= the one evaluation site =================
 			double gn2n, Fpn, rv2n;
-			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr);
+			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr, LIN ? &lin : nullptr);
 			NTG_STAMP(1);
 			if (state == ST_FINAL) {
 				// multipliers estimate lam = (AA')^-1 A g at the final point
@@ -1009,6 +1068,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					S.lam[r] = a;
 				}
 				lds_sync();
+				final_pass = true;
 				break;
 			}
 			nfev++;
@@ -1021,7 +1081,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (state == ST_INIT) {
 				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
-				apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+				apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
 				for_vec<NT>(n, [&](int c) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; });
 				block_sum<NT, 4>(r4, S.red);
@@ -1051,7 +1111,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (npairs > 0 && sqrt(r4[3]) > tolg) {
 						// line search failed with a non-trivial W: drop the pairs and retry from the same point with W0
 						npairs = 0;
-						apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+						apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 						double r2[2] = {0, 0};
 						for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 						block_sum<NT, 2>(r2, S.red);
@@ -1070,9 +1130,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					alpha = lsm->a;
 					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
 					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
-					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
+					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
 					NTG_STAMP(5);
-					apply_w0<NT, BIG>(D, T, sp.hessian, sgpt, st, sxt, S.oinfo);
+					apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgpt, st, sxt, S.oinfo);
 					NTG_STAMP(4);
 					apply_history<NT>(D, S, hist, npairs, sgpt, st);
 					NTG_STAMP(3);
@@ -1130,7 +1190,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (pnorm == 0.0 || !(dphi0 < 0.0)) {
 						if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
 							npairs = 0;
-							apply_w0<NT, BIG>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+							apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 							double r2[2] = {0, 0};
 							for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 							block_sum<NT, 2>(r2, S.red);
@@ -1173,7 +1233,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						outer++;
 						if (outer >= 30) { inform = 3; done_al = true; }
 					}
-					if (take) for (int j = tid; j < ncn; j += NT) al_lam[j] = al_t[j];
+					// on exit the multipliers stay as they are: x is stationary for the augmented Lagrangian of the CURRENT
+					// multipliers, whose estimates t (al_t) are the ones consistent with it and the ones reported
+					if (take && !done_al) for (int j = tid; j < nal; j += NT) al_lam[j] = al_t[j];
 					__syncthreads();   // multipliers cross lanes through HBM: full barrier
 					if (!done_al) {
 						sri = fmax(sp.sr, fmin(1e-3, 0.1 * rvprev));
@@ -1200,9 +1262,20 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	for (int i = tid; i < n; i += NT) xio[(size_t)b * n + i] = sx[i];
 	NTG_STAMP(5);
 	if (clambda) {
-		const int ntot = n + m + D.ncnln;
-		for (int i = tid; i < ntot; i += NT)
-			clambda[(size_t)b * ntot + i] = (inform == 9 || i < n) ? 0.0 : (i < n + m ? S.lam[i - n] : (al.mu > 0.0 ? -al_lam[i - n - m] : 0.0));
+		const int mall = D.nclin, ntot = n + mall + D.ncnln;   // NPSOL's layout: coefficients, all linear rows, nonlinear rows
+		const double *al_rep = al_t;     // estimates of the last evaluation at x: g = A_E' lam_E - [A_I; J]' t
+		(void)final_pass;
+		__syncthreads();                 // al_t was written by other lanes
+		for (int i = tid; i < ntot; i += NT) {
+			double v = 0.0;
+			if (inform != 9 && i >= n) {
+				if (i < n + mall) {
+					const int e = D.nI > 0 ? T.rowmap[i - n] : i - n;   // equality index, or -(j+1) for inequality row j
+					v = e >= 0 ? S.lam[e] : (al.mu > 0.0 ? -al_rep[ncn - e - 1] : 0.0);
+				} else if (al.mu > 0.0) v = -al_rep[i - n - mall];
+			}
+			clambda[(size_t)b * ntot + i] = v;
+		}
 		if (sp.stamps == 1 && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
 		if (sp.stamps == 2 && tid == 0) {   // diagnostic: state of the augmented-Lagrangian loop at exit
 			double *o = clambda + (size_t)b * ntot;
@@ -1229,10 +1302,10 @@ static hipError_t launch_eval_one(const NtgDims &D, const NtgTables &T, const Sm
 	hipLaunchKernelGGL(kfn, dim3(a.grid), dim3(NT), L.total, a.st, D, T, L, a.batch, a.mode, a.x, a.f, a.g, a.c, a.jb, a.cj);
 	return hipGetLastError();
 }
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true>
 static hipError_t launch_sqp_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
-	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG>;
+	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS>;
 	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
 	hipLaunchKernelGGL(kfn, dim3(a.batch), dim3(NT), L.total, a.st, D, T, L, sp, a.batch, a.lo, a.up, a.x, a.obj, a.inf, a.it, a.nf,
 	                   a.cl, a.hist, a.alw, a.vecw);
@@ -1250,8 +1323,13 @@ template <int FAM, int NOUT, int K>
 static hipError_t launch_sqp_small(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
 	if (a.big) return hipErrorInvalidValue;
-	if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false>(D, T, L, sp, a);
-	if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false>(D, T, L, sp, a);
+	if (sp.hessian != 1) {   // identity cold start: the instance without any preconditioner code
+		if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false, false>(D, T, L, sp, a);
+		if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false, false>(D, T, L, sp, a);
+		return hipErrorInvalidValue;
+	}
+	if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false, true>(D, T, L, sp, a);
+	if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false, true>(D, T, L, sp, a);
 	return hipErrorInvalidValue;
 }
 // the generic instance of a family (run-time nout / order) at every workgroup size, LDS-resident or BIG
@@ -1278,4 +1356,6 @@ static hipError_t launch_sqp_generic(const NtgDims &D, const NtgTables &T, const
 }
 // shape tests shared by the per-family dispatchers
 static inline bool ntg_all_d(const NtgDims &D, int d) { for (int o = 0; o < D.nout; o++) if (D.d[o] != d) return false; return true; }
-static inline int ntg_uniform_order(const NtgDims &D, int nt, int ept) { return (D.uniform && D.nC <= ept * nt) ? D.order[0] : 0; }
+// 0 unless a tuned instance may run: one basis class, nC within the lanes' slots, no linear inequality rows (those
+// are handled by the generic instances only)
+static inline int ntg_uniform_order(const NtgDims &D, int nt, int ept) { return (D.uniform && D.nC <= ept * nt && D.nI == 0) ? D.order[0] : 0; }

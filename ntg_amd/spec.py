@@ -57,6 +57,7 @@ class Spec:
     icostav: Sequence[AV] = ()
     tcostav: Sequence[AV] = ()
     fcostav: Sequence[AV] = ()
+    lin_ineq: Sequence[int] = ()         # optional [nlic+nltc+nlfc]: 1 = linear row is an inequality row in every problem
     name: str = ""
 
     # ---- derived sizes (colloc.c:34-52, ntg.c:155-157) ----

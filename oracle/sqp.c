@@ -309,7 +309,7 @@ static void project(const proj_t *pj, const double *g, double *gp, double *lam_o
  * the Powell-Hestenes-Rockafellar augmented-Lagrangian terms of  bl <= c(x) <= bu :
  *   v = c + lam/mu,  p = clamp(v, bl, bu),  t = mu (v - p)   (= next multiplier estimate)
  *   F_A = F + sum_j (t_j^2 - lam_j^2) / (2 mu),   grad F_A = g + J' t
- * Also returns the relative violation  rv = sqrt( sum_j ((c_j - clamp(c_j))/(1+|c_j|))^2 ). */
+ * Also returns  rv = sqrt( sum_j ((c_j - p_j)/(1+|c_j|))^2 ): constraint violation and complementarity in one number. */
 typedef struct {
 	orc_problem *p; int n, nc; double mu; double *lam, *tnew, *c; int nfev;
 	int nI; const int *irow;   /* linear INEQUALITY rows (indices into A): treated like constraints with a constant Jacobian */
@@ -339,8 +339,9 @@ static double al_eval(al_t *a, const double *x, double *g, double *rv_out, doubl
 		{
 			const double v = cj + a->lam[j] / a->mu;
 			const double pj = v < bl ? bl : (v > bu ? bu : v);
-			const double cc = cj < bl ? bl : (cj > bu ? bu : cj);
-			const double tj = a->mu * (v - pj), rj = (cj - cc) / (1.0 + fabs(cj));
+			/* distance to the clamped shifted value: |c - b| for an active row, min(slack, lam/mu) for a feasible one --
+			 * zero only when feasibility AND complementarity hold (the measure of LANCELOT / ALGENCAN) */
+			const double tj = a->mu * (v - pj), rj = (cj - pj) / (1.0 + fabs(cj));
 			a->tnew[j] = tj;
 			pen += (tj - a->lam[j]) * (tj + a->lam[j]) / (2.0 * a->mu);   /* factored: no cancellation when c is tiny */
 			rv2 += rj * rj;
