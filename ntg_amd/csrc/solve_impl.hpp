@@ -466,7 +466,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 
 // quadrature + banded gradient assembly from the per-breakpoint values in LDS (fvals, dfz,
 // dfi, dff); shared by the device-functor path and the host-callback path of ntg()
-template <int NOUT, int K, int NT, int DM, int EPT>
+template <int NOUT, int K, int NT, int DM, int EPT, bool SHARED = false>
 __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<EPT> &cm,
                                               bool hasI, bool hasF, double psi, double rv2, double *Fpure, double *rv2_out,
                                               const LinIneq *li = nullptr)
@@ -485,7 +485,65 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 	// sum node-wise, g[c] = sum_s colv[c][s] * (w_i df_i)[coli[c][s]], over the non-zeros of column c
 	// of the collocation matrix only.  The column form is s-major ([s][cl]): lanes with consecutive
 	// coefficients read consecutive LDS words.
-	if (NOUT > 0 && !hasI && !hasF) {
+	const int W4u = (SHARED && NOUT > 0 && D.uniform) ? D.cls_W[0] : 0;
+	if (NOUT > 0 && !hasI && !hasF && (W4u == 8 || W4u == 12 || W4u == 16)) {
+		// (SHARED: chosen per kernel where it measured faster -- the evaluation kernel with 3 or more outputs, the solve
+		// of the large configs.)  One basis class: column cl of the collocation matrix is the same for every output.  A lane takes one
+		// local coefficient cl for a share of the outputs: the packed (value index, breakpoint) entries and the
+		// basis values of the column are read ONCE and reused for each of its outputs; only the weighted gradient
+		// rows differ.  Per coefficient the sum runs over the derivative channels, then the column entries --
+		// the same order as the per-coefficient form below, so the two are bit-identical.
+		auto gather = [&](auto Wtag) {
+			constexpr int W = decltype(Wtag)::value;
+			constexpr int NO = NOUT > 0 ? NOUT : 1;
+			const int nco = D.ncoef[0];
+			const int G = max(1, min(NT / nco, NO)), OPG = (NO + G - 1) / G;   // lane groups, outputs per group
+			for (int i = tid; i < G * nco; i += NT) {
+				const int grp = i / nco, cl = i - grp * nco, o0 = grp * OPG;
+				double a[NO];
+#pragma unroll
+				for (int j = 0; j < NO; j++) a[j] = 0.0;
+#pragma unroll
+				for (int r = 0; r < DM; r++) {
+					if (!((D.tav_rmask >> r) & 1)) continue;                 // wave-uniform
+					const int chc = S.chcol[r];
+					if (chc < 0) continue;
+					const double *rv = S.rowv + S.chrow[r];
+					// W packed entries of this column, contiguous and 16-byte aligned: read as uint4
+					const uint4 *cp4 = (const uint4 *)(S.colp + chc + cl * W);
+					unsigned int pe[W];
+#pragma unroll
+					for (int s4 = 0; s4 < W / 4; s4++) { const uint4 t4 = cp4[s4]; pe[4 * s4] = t4.x; pe[4 * s4 + 1] = t4.y; pe[4 * s4 + 2] = t4.z; pe[4 * s4 + 3] = t4.w; }
+					double vv[W];
+#pragma unroll
+					for (int s2 = 0; s2 < W; s2++) { vv[s2] = rv[pe[s2] >> 16]; pe[s2] &= 0xffffu; }
+#pragma unroll
+					for (int j = 0; j < NO; j++) {
+						const int o = o0 + j;
+						if (j >= OPG || o >= NO) break;
+						const int row = S.tavrow[DM * o + r];
+						if (row < 0) continue;
+						const double *wdf = S.dfz + row * (P + 1);
+						double ww[W];
+#pragma unroll
+						for (int s2 = 0; s2 < W; s2++) ww[s2] = wdf[pe[s2]];
+#pragma unroll
+						for (int s2 = 0; s2 < W; s2++) a[j] += vv[s2] * ww[s2];
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < NO; j++) {
+					const int o = o0 + j;
+					if (j >= OPG || o >= NO) break;
+					sg[o * nco + cl] = a[j];
+					acc[1] += a[j] * a[j];
+				}
+			}
+		};
+		if (W4u == 8) gather(std::integral_constant<int, 8>());
+		else if (W4u == 12) gather(std::integral_constant<int, 12>());
+		else gather(std::integral_constant<int, 16>());
+	} else if (NOUT > 0 && !hasI && !hasF) {
 		// all (breakpoint, block column) pairs of a column are read first, then all values and
 		// weighted gradients, then the FMAs: two LDS round trips per coefficient, independent of W
 		auto gather = [&](auto Wtag) {
@@ -571,7 +629,7 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 
 // NPfunobj (ntg.c:274-335): F and the full gradient into LDS vector sg.  Returns F; *gnorm2
 // receives |g|^2.  Every lane of the workgroup must call it (it contains barriers).
-template <int FAM, int NOUT, int K, int NT, int EPT>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool SHARED = false>
 __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
                                             const CoefMap<EPT> &cm, const ALState &al, double *Fpure = nullptr,
                                             double *rv2_out = nullptr, unsigned long long *tk = nullptr, const LinIneq *li = nullptr)
@@ -586,7 +644,7 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	const bool lin_on = NOUT == 0 && li && li->nI > 0 && al.mu > 0.0;
 	if (lin_on) lin_ineq_phase<NT>(D, *li, sx, al, psi, rv2);   // sx was complete before the functor pass
 	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
-	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
+	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT, SHARED>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
 	                                          psi, rv2, Fpure, rv2_out, lin_on ? li : nullptr);
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
@@ -693,7 +751,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr);
 		}
 		double gn2;
-		const double F = eval_cost<FAM, NOUT, K, NT, EPT>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr});
+		const double F = eval_cost<FAM, NOUT, K, NT, EPT, (NOUT >= 3)>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr});
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
 		if (g && mode != 0)
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
@@ -1051,7 +1109,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		for (;;) {
 			// ================= the one evaluation site =================
 			double gn2n, Fpn, rv2n;
-			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr, LIN ? &lin : nullptr);
+			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256)>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr, LIN ? &lin : nullptr);
 			NTG_STAMP(1);
 			if (state == ST_FINAL) {
 				// multipliers estimate lam = (AA')^-1 A g at the final point
