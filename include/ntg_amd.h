@@ -137,6 +137,12 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
                     const double *d_knots, const double *d_bps, double *d_blk, int *d_off,
                     void *stream);
 
+/* SplineInterp (colloc.c:449-484) for a whole batch: the flat flag of every problem at ntimes points in time shared by
+ * the batch (d_times [ntimes], inside the knot range of every output) -> d_z [batch][ntimes][nz], entry iz[o]+r =
+ * D^r z_o(t).  This is the input of a flat-to-state map such as kincar_flat_reverse (kincar.c:68-92). */
+int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times, double *d_z,
+                     void *stream);
+
 /* Receding-horizon step (the warm-start use NPSOL's istate/clambda/R were meant for, ntg.h:64-68):
  * re-pin the linear initial-constraint bounds of every problem to the flat flag of its current
  * solution at breakpoint shift_bp, and shift the coefficients by shift_knots knot intervals

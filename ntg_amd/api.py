@@ -68,6 +68,7 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_longlong, C.c_void_p]
         L.ntg_basis_batch.argtypes = [C.c_int] * 6 + [C.c_void_p] * 5
+        L.ntg_batch_interp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ntg_batch_mpc_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -190,6 +191,14 @@ class Plan:
             if want_dense_jac:
                 out["cJac"] = cj.transpose(1, 2).contiguous()
         return out
+
+    def interp(self, x, times):
+        """Flat flag of every problem at the given times: x [batch, nC], times [ntimes] -> [batch, ntimes, nz]."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous() and times.is_cuda and times.dtype == torch.float64
+        z = torch.empty((x.shape[0], times.numel(), self.spec.nz), dtype=torch.float64, device=x.device)
+        _check(lib().ntg_batch_interp(self.h, x.shape[0], _ptr(x), times.numel(), _ptr(times.contiguous()), _ptr(z), self._stream()))
+        return z
 
     def mpc_shift(self, x, lower, upper, shift_bp: int, shift_knots: int):
         """Receding-horizon step in place: re-pin initial bounds to the solution's flag at breakpoint

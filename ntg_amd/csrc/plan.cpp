@@ -193,7 +193,8 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		hipError_t e = ntg_launch_basis(1, D.ninterv[o], D.order[o], D.mult[o], D.d[o], s->nbps, d_kn, d_bps, 0, 0,
 		                                d_blk + D.cls_blk[c], d_off + (size_t)c * s->nbps, nullptr);
 		hipError_t e2 = hipDeviceSynchronize();
-		hipFree(d_kn);
+		own.insert(own.end(), tmp_own.begin(), tmp_own.end());   // kept: ntg_batch_interp evaluates the basis at other times
+		p->d_knots.push_back(d_kn);
 		if (e != hipSuccess || e2 != hipSuccess) { ntg_plan_destroy(p); return fail(NTG_E_HIP, "basis kernel failed"); }
 	}
 	p->h_blk.resize(blk_total); p->h_off.resize((size_t)D.nclass * s->nbps);
@@ -672,6 +673,35 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	SqpArgs sa{nt, big, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev, d_clambda, (double *)d_work, alw,
 	           big ? vecw : nullptr, (hipStream_t)stream};
 	HIPCHK(ntg_launch_sqp(p->D, p->T, L, sp, sa));
+	return 0;
+}
+
+extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times, double *d_z,
+                                void *stream)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0 || ntimes <= 0) return 0;
+	if (!d_x || !d_times || !d_z) return fail(NTG_E_BADARG, "null argument");
+	HIPCHK(hipSetDevice(p->device));
+	const NtgDims &D = p->D;
+	hipStream_t st = (hipStream_t)stream;
+	// basis of every class at the requested times (the same kernel that builds the collocation tables), stream ordered
+	double *d_tblk = nullptr; int *d_toff = nullptr, *d_base = nullptr;
+	std::vector<int> base(D.nclass);
+	size_t tot = 0;
+	for (int c = 0; c < D.nclass; c++) { base[c] = (int)tot; tot += (size_t)ntimes * D.cls_k[c] * D.cls_d[c]; }
+	HIPCHK(hipMallocAsync((void **)&d_tblk, tot * 8, st));
+	HIPCHK(hipMallocAsync((void **)&d_toff, (size_t)D.nclass * ntimes * 4, st));
+	HIPCHK(hipMallocAsync((void **)&d_base, (size_t)D.nclass * 4, st));
+	HIPCHK(hipMemcpyAsync(d_base, base.data(), (size_t)D.nclass * 4, hipMemcpyHostToDevice, st));
+	hipError_t e = hipSuccess;
+	for (int c = 0; c < D.nclass && e == hipSuccess; c++)
+		e = ntg_launch_basis(1, D.cls_l[c], D.cls_k[c], D.cls_m[c], D.cls_d[c], ntimes, p->d_knots[c], d_times, 0, 0,
+		                     d_tblk + base[c], d_toff + (size_t)c * ntimes, st);
+	if (e == hipSuccess) e = ntg_launch_interp(D, batch, ntimes, d_x, d_tblk, d_toff, d_base, d_z, st);
+	HIPCHK(hipStreamSynchronize(st));   // `base` is read by the async copy above
+	(void)hipFreeAsync(d_tblk, st); (void)hipFreeAsync(d_toff, st); (void)hipFreeAsync(d_base, st);
+	HIPCHK(e);
 	return 0;
 }
 

@@ -16,6 +16,7 @@ struct ntg_plan {
 	std::vector<int> h_off, h_rbp, class_rep;
 	std::vector<ntg_av> icostav, tcostav, fcostav;
 	double *d_lic = nullptr;                    // [nlic][nz] kept for the receding-horizon shift
+	std::vector<double *> d_knots;              // break sequence of every basis class (ntg_batch_interp)
 };
 
 void ntg_plan_dense_A(const ntg_plan *p, double *A);
@@ -29,6 +30,8 @@ hipError_t ntg_launch_eval(const NtgDims &D, const NtgTables &T, const SmemLayou
 hipError_t ntg_launch_sqp(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a);
 hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,
                             long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st);
+hipError_t ntg_launch_interp(const NtgDims &D, int batch, int ntimes, const double *x, const double *tblk, const int *toff,
+                             const int *tblk_base, double *z, hipStream_t st);
 hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,
                               const double *lfc, double *aband, int *rbp, hipStream_t st);
 hipError_t ntg_launch_bounds(const NtgDims &D, int batch, const double *lo, const double *up, double *bl, double *bu,

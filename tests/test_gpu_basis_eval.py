@@ -116,3 +116,30 @@ def test_basis_batch_per_problem_grids():
         tab = orc.export_tables(spec)
         assert np.array_equal(off[gi], tab["off"][0])
         assert rel(blk[gi].reshape(-1), tab["blk"][:P * k * d]) <= 1e-13
+
+
+@pytest.mark.parametrize("name", ["K0", "M", "T", "D8"])
+def test_batch_interp_matches_spline_interp(name):
+    """ntg_batch_interp == SplineInterp (colloc.c:449-484, restated in the oracle) for every problem, output,
+    derivative and time, including both ends of the horizon and knot positions."""
+    import ctypes as C
+    spec = SPECS[name]()
+    rng = np.random.default_rng(21)
+    nb = 5
+    x = rng.normal(size=(nb, spec.nC))
+    t0, t1 = float(spec.bps[0]), float(spec.bps[-1])
+    times = np.concatenate([[t0, t1], spec.knots[0][1:-1][:3], rng.uniform(t0, t1, 20)])
+    z = plan_for(name).interp(dev(x), dev(times)).cpu().numpy()
+    assert z.shape == (nb, len(times), spec.nz)
+    dp = C.POINTER(C.c_double)
+    ref = np.zeros_like(z)
+    iz = np.concatenate([[0], np.cumsum(spec.maxderiv)]); iC = np.concatenate([[0], np.cumsum(spec.ncoef)])
+    for b in range(nb):
+        for o in range(spec.nout):
+            kn = np.ascontiguousarray(spec.knots[o]); co = np.ascontiguousarray(x[b, iC[o]:iC[o + 1]])
+            for ti, t in enumerate(times):
+                f = np.zeros(spec.maxderiv[o])
+                orc.lib().orc_spline_interp(f.ctypes.data_as(dp), C.c_double(float(t)), kn.ctypes.data_as(dp), int(spec.kninterv[o]),
+                                            co.ctypes.data_as(dp), int(spec.ncoef[o]), int(spec.order[o]), int(spec.mult[o]), int(spec.maxderiv[o]))
+                ref[b, ti, iz[o]:iz[o + 1]] = f
+    assert rel(z, ref) <= 1e-13
