@@ -360,7 +360,8 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
 	L.bps = p; p = align16(p + D.P * 8);
 	L.wts = p; p = align16(p + D.P * 8);
 	L.x = p; if (with_x) p = align16(p + npad * 8);
-	L.dfz = p; p = align16(p + (D.ntav > 0 ? D.ntav : 1) * (D.P + 1) * 8);   // [row][P+1], last entry stays 0 (padding target)
+	// [row][P+1] + a zero tail: the column form reads W consecutive entries from a column's first breakpoint
+	L.dfz = p; p = align16(p + ((D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + ntg_dfz_tail(D)) * 8);
 	L.fvals = p; p = align16(p + D.P * 8);
 	L.red = p; p = align16(p + 16 * (nthreads / 64 + 1) * 8);
 	L.dfi = p; p = align16(p + (D.nz + 1) * 8);

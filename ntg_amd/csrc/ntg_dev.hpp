@@ -61,8 +61,9 @@ struct NtgTables {
 	const int *csc_ptr, *csc_row; const double *csc_val;
 	const int *sinv_ptr, *sinv_col; const double *sinv_val;   // CSR of (A A')^-1
 	// rowv[chrow + q*P + bp]  = D^r B_{off(bp)+q}(bps[bp])      (by breakpoint: Z = M C, Jacobian rows)
-	// colp[chcol + cl*W + s] = packed (q*P+i)<<16 | i of the s-th non-zero of column cl of the same
-	// matrix: value = rowv[chrow + q*P + i], breakpoint i; padding entries are (P)<<16 | P -> weight 0
+	// colp[chcol + cl*WW ..] = column cl of the same matrix (its non-zeros sit at consecutive breakpoints): word 0 = the
+	// first breakpoint i0, then W 16-bit value indices (q*P+i relative to chrow, two per word; padding = k*P, a stored
+	// zero); the s-th entry multiplies the weighted gradient at breakpoint i0+s.  WW = colp_words(W) words per column.
 	// chrow/chcol[class*NTG_MAX_ORDER + r] = channel offsets, -1 when no active variable uses D^r
 	const double *rowv; const unsigned int *colp; const int *chrow, *chcol;
 	// linear rows: erow[mE] = original row of equality e; rowmap[nclin] = e, or -(j+1) for inequality j; linflag[slot]
@@ -73,6 +74,11 @@ struct NtgTables {
 	const int *q_col;      // [q_nt][q_w]
 	const double *q_val;   // [q_nt][q_w], zero padded
 };
+
+// words per column of the column form (see NtgTables::colp)
+__host__ __device__ constexpr int colp_words(int W) { return (W / 2 + 1 + 3) & ~3; }
+// zero doubles kept after the last weighted-gradient row: a column's W reads start at its first breakpoint and may run past P
+__host__ __device__ inline int ntg_dfz_tail(const NtgDims &D) { int w = 16; for (int c = 0; c < D.nclass; c++) w = D.cls_W[c] > w ? D.cls_W[c] : w; return w; }
 
 // byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
 struct SmemLayout {

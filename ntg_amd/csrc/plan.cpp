@@ -227,19 +227,29 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 				chrow[(size_t)c * NTG_MAX_ORDER + r] = (int)rowv.size();
 				chcol[(size_t)c * NTG_MAX_ORDER + r] = (int)colp.size();
 				for (int q = 0; q < k; q++) for (int i = 0; i < P; i++) rowv.push_back(blk[((size_t)i * k + q) * dd + r]);
+				rowv.push_back(0.0);   // value index k*P: the zero the padding entries of a column point to
+				// column cl: word 0 = its first breakpoint (the breakpoints of a column are consecutive because the block
+				// offsets are non-decreasing), then W4 16-bit value indices q*P+i, two per word, padded with k*P
+				if ((size_t)k * P >= 65535) { ntg_plan_destroy(p); return fail(NTG_E_UNSUPPORTED, "order*nbps exceeds the 16-bit column index"); }
 				const size_t base = colp.size();
-				// [cl][W4] packed (q*P+i)<<16 | i; padding = (P<<16)|P: rowv[ch+P] (finite) times the zero tail of a dfz row
-				if ((size_t)k * P >= 65536) { ntg_plan_destroy(p); return fail(NTG_E_UNSUPPORTED, "order*nbps exceeds the 16-bit packed column index"); }
-				colp.resize(base + (size_t)W4 * nc, ((unsigned int)P << 16) | (unsigned int)P);
-				std::vector<int> fill(nc, 0);
+				const int WW = (W4 / 2 + 1 + 3) & ~3;   // == colp_words(W4) of solve_impl.hpp
+				colp.resize(base + (size_t)WW * nc, 0u);
+				std::vector<int> fill(nc, 0), first(nc, 0);
+				std::vector<unsigned int> idx((size_t)nc * W4, (unsigned int)(k * P));
 				for (int i = 0; i < P; i++) for (int q = 0; q < k; q++) {
 					const int cl = off[i] + q, sidx = fill[cl]++;
-					colp[base + (size_t)cl * W4 + sidx] = ((unsigned int)(q * P + i) << 16) | (unsigned int)i;
+					if (sidx == 0) first[cl] = i;
+					else if (first[cl] + sidx != i) { ntg_plan_destroy(p); return fail(NTG_E_UNSUPPORTED, "breakpoints of a basis function are not consecutive"); }
+					idx[(size_t)cl * W4 + sidx] = (unsigned int)(q * P + i);
+				}
+				for (int cl = 0; cl < nc; cl++) {
+					unsigned int *w = &colp[base + (size_t)cl * WW];
+					w[0] = (unsigned int)first[cl];
+					for (int s2 = 0; s2 < W4; s2++) w[1 + s2 / 2] |= idx[(size_t)cl * W4 + s2] << (16 * (s2 & 1));
 				}
 			}
 		}
-		D.row_total = (int)rowv.size() + 1; D.col_total = (int)colp.size();   // +1: padding entries read rowv[ch + P] (finite, times 0)
-		rowv.push_back(0.0);
+		D.row_total = (int)rowv.size(); D.col_total = (int)colp.size();
 		if (colp.empty()) colp.push_back(0);
 		double *d_rowv = nullptr; unsigned int *d_colp = nullptr; int *d_chrow = nullptr, *d_chcol = nullptr;
 		if (dev_upload(&d_rowv, rowv.data(), rowv.size(), own) || dev_upload(&d_colp, colp.data(), colp.size(), own) ||

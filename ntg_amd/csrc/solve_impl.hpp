@@ -230,7 +230,8 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 		q[6] = D.cls[o] * NTG_MAX_ORDER; q[7] = D.cls[o] * D.P; q[8] = D.cls_W[D.cls[o]]; q[9] = D.ncoef[o];
 	}
 	for (int v = tid; v < D.nz; v += NT) S.tavrow[v] = D.tav_row[v];
-	for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;   // padding target of the column form
+	for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;   // the row's extra element stays 0
+	for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[(D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + i] = 0.0;   // overrun of the last columns' reads (times 0)
 	if (D.q_use) {
 		for (int i = tid; i < D.nC; i += NT) S.q_idx[i] = T.q_idx[i];
 		for (int i = tid; i < D.q_nt * D.q_w; i += NT) { S.q_col[i] = T.q_col[i]; S.q_val[i] = T.q_val[i]; }
@@ -319,6 +320,22 @@ __device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const
 			z[iz + r] = acc;
 		}
 	}
+}
+
+// column form of one collocation-matrix column (W entries, W a multiple of 4), see NtgTables::colp:
+// word 0 = first breakpoint i0 of the column (its breakpoints are consecutive), then W/2 words of two 16-bit value
+// indices each; a column occupies colp_words(W) words (multiple of 4: read as uint4)
+template <int W>
+__device__ __forceinline__ void colp_load(const unsigned int *cp, int &i0, unsigned int (&idx)[W])
+{
+	constexpr int WW = colp_words(W);
+	unsigned int w[WW];
+	const uint4 *cp4 = (const uint4 *)cp;
+#pragma unroll
+	for (int s4 = 0; s4 < WW / 4; s4++) { const uint4 t4 = cp4[s4]; w[4 * s4] = t4.x; w[4 * s4 + 1] = t4.y; w[4 * s4 + 2] = t4.z; w[4 * s4 + 3] = t4.w; }
+	i0 = (int)w[0];
+#pragma unroll
+	for (int s = 0; s < W; s++) idx[s] = (w[1 + s / 2] >> (16 * (s & 1))) & 0xffffu;
 }
 
 // which coefficients a lane owns (c = tid + e*NT) and where their column-form data sit: decoded
@@ -509,24 +526,21 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 					const int chc = S.chcol[r];
 					if (chc < 0) continue;
 					const double *rv = S.rowv + S.chrow[r];
-					// W packed entries of this column, contiguous and 16-byte aligned: read as uint4
-					const uint4 *cp4 = (const uint4 *)(S.colp + chc + cl * W);
-					unsigned int pe[W];
-#pragma unroll
-					for (int s4 = 0; s4 < W / 4; s4++) { const uint4 t4 = cp4[s4]; pe[4 * s4] = t4.x; pe[4 * s4 + 1] = t4.y; pe[4 * s4 + 2] = t4.z; pe[4 * s4 + 3] = t4.w; }
+					int i0; unsigned int pe[W];
+					colp_load<W>(S.colp + chc + cl * colp_words(W), i0, pe);
 					double vv[W];
 #pragma unroll
-					for (int s2 = 0; s2 < W; s2++) { vv[s2] = rv[pe[s2] >> 16]; pe[s2] &= 0xffffu; }
+					for (int s2 = 0; s2 < W; s2++) vv[s2] = rv[pe[s2]];
 #pragma unroll
 					for (int j = 0; j < NO; j++) {
 						const int o = o0 + j;
 						if (j >= OPG || o >= NO) break;
 						const int row = S.tavrow[DM * o + r];
 						if (row < 0) continue;
-						const double *wdf = S.dfz + row * (P + 1);
+						const double *wdf = S.dfz + row * (P + 1) + i0;   // consecutive breakpoints: constant offsets
 						double ww[W];
 #pragma unroll
-						for (int s2 = 0; s2 < W; s2++) ww[s2] = wdf[pe[s2]];
+						for (int s2 = 0; s2 < W; s2++) ww[s2] = wdf[s2];
 #pragma unroll
 						for (int s2 = 0; s2 < W; s2++) a[j] += vv[s2] * ww[s2];
 					}
@@ -563,19 +577,18 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 					if (row < 0 || chc < 0) continue;
 					const double *rv = S.rowv + S.chrow[chb + r]; const double *wdf = S.dfz + row * (P + 1);
 					if (W > 0) {
-						// W packed entries of this column, contiguous and 16-byte aligned: read as uint4
-						const uint4 *cp4 = (const uint4 *)(S.colp + chc + cl * Wr);
-						unsigned int pe[W > 0 ? W : 4];
+						constexpr int WC = W > 0 ? W : 4;
+						int i0; unsigned int pe[WC];
+						colp_load<WC>(S.colp + chc + cl * colp_words(WC), i0, pe);
+						double vv[WC], ww[WC];
 #pragma unroll
-						for (int s4 = 0; s4 < W / 4; s4++) { const uint4 t4 = cp4[s4]; pe[4 * s4] = t4.x; pe[4 * s4 + 1] = t4.y; pe[4 * s4 + 2] = t4.z; pe[4 * s4 + 3] = t4.w; }
-						double vv[W > 0 ? W : 1], ww[W > 0 ? W : 1];
+						for (int s2 = 0; s2 < WC; s2++) { vv[s2] = rv[pe[s2]]; ww[s2] = wdf[i0 + s2]; }
 #pragma unroll
-						for (int s2 = 0; s2 < W; s2++) { vv[s2] = rv[pe[s2] >> 16]; ww[s2] = wdf[pe[s2] & 0xffffu]; }
-#pragma unroll
-						for (int s2 = 0; s2 < W; s2++) dIn += vv[s2] * ww[s2];
+						for (int s2 = 0; s2 < WC; s2++) dIn += vv[s2] * ww[s2];
 					} else {
-						const unsigned int *cp = S.colp + chc + cl * Wr;
-						for (int s2 = 0; s2 < Wr; s2++) { const unsigned int pe = cp[s2]; dIn += rv[pe >> 16] * wdf[pe & 0xffffu]; }
+						const unsigned int *cp = S.colp + chc + cl * colp_words(Wr);
+						const int i0 = (int)cp[0];
+						for (int s2 = 0; s2 < Wr; s2++) dIn += rv[(cp[1 + s2 / 2] >> (16 * (s2 & 1))) & 0xffffu] * wdf[i0 + s2];
 					}
 				}
 				sg[c] = dIn;
@@ -599,8 +612,8 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 			for (int r = 0; r < d; r++) {
 				const int row = S.tavrow[iz + r], chc = S.chcol[chb + r], chr = S.chrow[chb + r];
 				if (row >= 0 && chc >= 0) {
-					const unsigned int *cp = S.colp + chc + cl * W4; const double *wdf = S.dfz + row * (P + 1);
-					for (int s = 0; s < W4; s++) { const unsigned int pe = cp[s]; dIn += S.rowv[chr + (pe >> 16)] * wdf[pe & 0xffffu]; }
+					const unsigned int *cp = S.colp + chc + cl * colp_words(W4); const double *wdf = S.dfz + row * (P + 1) + (int)cp[0];
+					for (int s = 0; s < W4; s++) dIn += S.rowv[chr + ((cp[1 + s / 2] >> (16 * (s & 1))) & 0xffffu)] * wdf[s];
 				}
 				if (chr >= 0) {
 					if (hasI && cl < k) dI += S.dfi[iz + r] * S.rowv[chr + cl * P];                // colloc.c:243-260 (block 0)
