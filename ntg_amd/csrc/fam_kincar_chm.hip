@@ -1,0 +1,19 @@
+// fam_kincar_chm.hip -- kincar instances with a compile-time channel mask (CHM = 4: the trajectory-cost active
+// variables are the second derivative of every output, examples/kincar.c:133-137): the shipped example's shape with
+// order-6 splines (config B, 2 outputs) and the headline workload (config M, 6 outputs).  Own translation unit so that it
+// compiles next to fam_kincar.hip.
+#include "solve_impl.hpp"
+
+hipError_t ntg_launch_eval_kincar_chm(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
+{
+	if (D.nout == 2) return launch_eval_small<NTG_FAM_KINCAR, 2, 6, 4>(D, T, L, a);
+	if (D.nout == 6) return launch_eval_small<NTG_FAM_KINCAR, 6, 6, 4>(D, T, L, a);
+	return hipErrorInvalidValue;
+}
+
+hipError_t ntg_launch_sqp_kincar_chm(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
+{
+	if (D.nout == 2) return launch_sqp_small<NTG_FAM_KINCAR, 2, 6, 4>(D, T, L, sp, a);
+	if (D.nout == 6) return launch_sqp_small<NTG_FAM_KINCAR, 6, 6, 4>(D, T, L, sp, a);
+	return hipErrorInvalidValue;
+}

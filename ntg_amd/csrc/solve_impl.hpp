@@ -240,11 +240,53 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 
 // Z = M C at one breakpoint for the declared active variables (colloc.c:318-326,344-367);
 // entries that are not active stay 0 like the reference's calloc'd GZ (ntg.c:119).
-template <int NOUT, int K, int DM>
+// CHM (channel mask, compile time): the instance was picked because the trajectory-cost active variables are exactly
+// "derivative r of EVERY output, for the r in CHM" (kincar: CHM = 4, the second derivatives).  Rows, masks and channel
+// tests that the general code looks up at run time are then constants.
+__host__ __device__ constexpr int chm_count(int chm) { return (chm & 1) + ((chm >> 1) & 1) + ((chm >> 2) & 1) + ((chm >> 3) & 1) + ((chm >> 4) & 1); }
+__host__ __device__ constexpr int chm_rank(int chm, int r) { return chm_count(chm & ((1 << r) - 1)); }
+__host__ __device__ inline u64 chm_full_mask(int chm, int nout, int dm)
+{
+	u64 m = 0;
+	for (int o = 0; o < nout; o++) for (int r = 0; r < dm; r++) if ((chm >> r) & 1) m |= 1ull << (dm * o + r);
+	return m;
+}
+
+template <int NOUT, int K, int DM, int CHM = 0>
 __device__ __forceinline__ void compute_z(const NtgDims &D, const Smem &S, const double *sx, int bp,
-                                          u64 mask, double *z)
+                                          u64 mask, double *z, bool chm_ok = false)
 {
 	const int nout = NOUT > 0 ? NOUT : D.nout, P = D.P;
+	if (NOUT > 0 && K > 0 && CHM != 0 && chm_ok) {
+		// every output, the derivative channels of CHM, nothing else: no masks, no channel tests
+		constexpr int KK = K > 0 ? K : 1, NCH = chm_count(CHM);
+		double b[NCH > 0 ? NCH : 1][KK];
+#pragma unroll
+		for (int r = 0; r < DM; r++) {
+			if (!((CHM >> r) & 1)) continue;
+			const int ch = S.chrow[r];
+#pragma unroll
+			for (int q = 0; q < KK; q++) b[chm_rank(CHM, r)][q] = S.rowv[ch + q * P + bp];
+		}
+		const int ofs = S.off[bp], nco = D.ncoef[0];
+#pragma unroll
+		for (int o = 0; o < (NOUT > 0 ? NOUT : 1); o++) {
+			const double *cx = sx + o * nco + ofs;
+			double xv[KK];
+#pragma unroll
+			for (int q = 0; q < KK; q++) xv[q] = cx[q];
+#pragma unroll
+			for (int r = 0; r < DM; r++) {
+				double acc = 0.0;
+				if ((CHM >> r) & 1) {
+#pragma unroll
+					for (int q = 0; q < KK; q++) acc += b[chm_rank(CHM, r)][q] * xv[q];
+				}
+				z[DM * o + r] = acc;
+			}
+		}
+		return;
+	}
 	if (NOUT > 0 && K > 0 && DM > 3 && D.uniform) {
 		// one basis class, compile-time order, many derivatives: the coefficients of one output stay in
 		// registers while its active derivative rows stream from LDS (keeping all DM rows would not fit)
@@ -410,9 +452,9 @@ __device__ __forceinline__ void lin_ineq_phase(const NtgDims &D, const LinIneq &
 }
 
 // per-breakpoint cost functor pass: Z = M C, then ucf/icf/fcf -> fvals, dfz, dfi, dff in LDS
-template <int FAM, int NOUT, int K, int NT>
+template <int FAM, int NOUT, int K, int NT, int CHM = 0>
 __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, const double *sx, const ALState &al,
-                                            double &psi, double &rv2)
+                                            double &psi, double &rv2, bool chm_ok = false)
 {
 	using Fam = Family<FAM>;
 	constexpr int DM = Fam::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
@@ -434,7 +476,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 		const u64 zmask = alon ? (D.tcost_mask | D.tcon_mask) : D.tcost_mask;
 		for (int i = tid; i < P; i += NT) {                       // cost.c:103-109
 			double z[NZ], df[NZ], f = 0.0;
-			compute_z<NOUT, K, DM>(D, S, sx, i, zmask, z);
+			compute_z<NOUT, K, DM, CHM>(D, S, sx, i, zmask, z, chm_ok && !alon);
 			if (D.nucf) Fam::ucf(nout, i, z, f, df);
 			else {
 #pragma unroll
@@ -451,8 +493,17 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 				for (int j = 0; j < NTc; j++) t[j] = j < D.nnltc ? al_term(c[j], D.nnlic + j * P + i, b0 + D.nnlic + j) : 0.0;
 				Fam::template nltc_vjp<NZ>(nout, nz, i, z, t, df);   // df += J' t, constraint-major like the dense loop
 			}
+			if (NOUT > 0 && CHM != 0 && chm_ok && !alon) {
+				// the weighted-gradient rows are (output, channel of CHM) in flag order: row = o NCH + rank(r)
+				constexpr int NCH = chm_count(CHM);
 #pragma unroll
-			for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = df[v]; }
+				for (int o = 0; o < (NOUT > 0 ? NOUT : 1); o++)
+#pragma unroll
+					for (int r = 0; r < DM; r++) { if ((CHM >> r) & 1) S.dfz[(o * NCH + chm_rank(CHM, r)) * (P + 1) + i] = df[DM * o + r]; }
+			} else {
+#pragma unroll
+				for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = df[v]; }
+			}
 		}
 	}
 	if ((D.nicf || (alon && D.nnlic)) && tid == 0) {              // cost.c:4-36, constraints.c:88-117
@@ -483,10 +534,10 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 
 // quadrature + banded gradient assembly from the per-breakpoint values in LDS (fvals, dfz,
 // dfi, dff); shared by the device-functor path and the host-callback path of ntg()
-template <int NOUT, int K, int NT, int DM, int EPT, bool SHARED = false>
+template <int NOUT, int K, int NT, int DM, int EPT, bool SHARED = false, int CHM = 0>
 __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<EPT> &cm,
                                               bool hasI, bool hasF, double psi, double rv2, double *Fpure, double *rv2_out,
-                                              const LinIneq *li = nullptr)
+                                              const LinIneq *li = nullptr, bool chm_ok = false)
 {
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
@@ -522,9 +573,10 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 				for (int j = 0; j < NO; j++) a[j] = 0.0;
 #pragma unroll
 				for (int r = 0; r < DM; r++) {
-					if (!((D.tav_rmask >> r) & 1)) continue;                 // wave-uniform
+					const bool fixed = CHM != 0 && chm_ok;               // wave-uniform; with CHM the channel set is a constant
+					if (fixed ? !((CHM >> r) & 1) : !((D.tav_rmask >> r) & 1)) continue;
 					const int chc = S.chcol[r];
-					if (chc < 0) continue;
+					if (!fixed && chc < 0) continue;
 					const double *rv = S.rowv + S.chrow[r];
 					int i0; unsigned int pe[W];
 					colp_load<W>(S.colp + chc + cl * colp_words(W), i0, pe);
@@ -535,7 +587,7 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 					for (int j = 0; j < NO; j++) {
 						const int o = o0 + j;
 						if (j >= OPG || o >= NO) break;
-						const int row = S.tavrow[DM * o + r];
+						const int row = fixed ? o * chm_count(CHM) + chm_rank(CHM, r) : S.tavrow[DM * o + r];
 						if (row < 0) continue;
 						const double *wdf = S.dfz + row * (P + 1) + i0;   // consecutive breakpoints: constant offsets
 						double ww[W];
@@ -572,9 +624,10 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 				const int chb = oi[6], nc = oi[9], Wr = oi[8];
 #pragma unroll
 				for (int r = 0; r < DM; r++) {
-					if (!((D.tav_rmask >> r) & 1)) continue;                 // wave-uniform
-					const int row = S.tavrow[DM * o + r], chc = S.chcol[chb + r];
-					if (row < 0 || chc < 0) continue;
+					const bool fixed = CHM != 0 && chm_ok;               // wave-uniform; with CHM the channel set is a constant
+					if (fixed ? !((CHM >> r) & 1) : !((D.tav_rmask >> r) & 1)) continue;
+					const int row = fixed ? o * chm_count(CHM) + chm_rank(CHM, r) : S.tavrow[DM * o + r], chc = S.chcol[chb + r];
+					if (!fixed && (row < 0 || chc < 0)) continue;
 					const double *rv = S.rowv + S.chrow[chb + r]; const double *wdf = S.dfz + row * (P + 1);
 					if (W > 0) {
 						constexpr int WC = W > 0 ? W : 4;
@@ -642,10 +695,11 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 
 // NPfunobj (ntg.c:274-335): F and the full gradient into LDS vector sg.  Returns F; *gnorm2
 // receives |g|^2.  Every lane of the workgroup must call it (it contains barriers).
-template <int FAM, int NOUT, int K, int NT, int EPT, bool SHARED = false>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool SHARED = false, int CHM = 0>
 __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
                                             const CoefMap<EPT> &cm, const ALState &al, double *Fpure = nullptr,
-                                            double *rv2_out = nullptr, unsigned long long *tk = nullptr, const LinIneq *li = nullptr)
+                                            double *rv2_out = nullptr, unsigned long long *tk = nullptr, const LinIneq *li = nullptr,
+                                            bool chm_ok = false)
 {
 	using Fam = Family<FAM>;
 	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
@@ -653,12 +707,12 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	unsigned long long t0 = 0;
 	if (tk) t0 = __builtin_amdgcn_s_memtime();
 	double psi, rv2;
-	cost_phase1<FAM, NOUT, K, NT>(D, S, sx, al, psi, rv2);
+	cost_phase1<FAM, NOUT, K, NT, CHM>(D, S, sx, al, psi, rv2, chm_ok);
 	const bool lin_on = NOUT == 0 && li && li->nI > 0 && al.mu > 0.0;
 	if (lin_on) lin_ineq_phase<NT>(D, *li, sx, al, psi, rv2);   // sx was complete before the functor pass
 	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
-	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT, SHARED>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
-	                                          psi, rv2, Fpure, rv2_out, lin_on ? li : nullptr);
+	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT, SHARED, CHM>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
+	                                          psi, rv2, Fpure, rv2_out, lin_on ? li : nullptr, chm_ok && !alon);
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
 }
@@ -722,7 +776,7 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 }
 
 // Persistent workgroups stride over the batch; tables are staged once per workgroup.
-template <int FAM, int NOUT, int K, int NT, int EPT>
+template <int FAM, int NOUT, int K, int NT, int EPT, int CHM>
 __global__ void __launch_bounds__(NT, NTG_EVAL_WAVES)
 eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const double *__restrict__ x,
             double *__restrict__ f, double *__restrict__ g, double *__restrict__ c,
@@ -764,7 +818,8 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr);
 		}
 		double gn2;
-		const double F = eval_cost<FAM, NOUT, K, NT, EPT, (NOUT >= 3)>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr});
+		const double F = eval_cost<FAM, NOUT, K, NT, EPT, (NOUT >= 3), CHM>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr},
+		                                                                   nullptr, nullptr, nullptr, nullptr, CHM != 0);
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
 		if (g && mode != 0)
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
@@ -1020,7 +1075,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 // (read across lanes by Z = M C at every evaluation) stays in LDS; x, gp, gp+, d and g live in a per-problem HBM/L2
 // workspace `vec_all`.  They are touched element-wise by their owner lane, except in the projection, the feasibility
 // step and the preconditioner, which read a handful of entries across lanes behind a full barrier.
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS, int CHM>
 __global__ void __launch_bounds__(NT, NTG_SQP_WAVES)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
@@ -1122,7 +1177,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		for (;;) {
 			// ================= the one evaluation site =================
 			double gn2n, Fpn, rv2n;
-			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256)>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr, LIN ? &lin : nullptr);
+			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr, LIN ? &lin : nullptr, CHM != 0);
 			NTG_STAMP(1);
 			if (state == ST_FINAL) {
 				// multipliers estimate lam = (AA')^-1 A g at the final point
@@ -1365,43 +1420,50 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 // ------------------------------------------------------------------------------------------
 // launchers: one (family, nout, order) instance at the workgroup size the host picked
 // ------------------------------------------------------------------------------------------
-template <int FAM, int NOUT, int K, int NT, int EPT>
+template <int FAM, int NOUT, int K, int NT, int EPT, int CHM = 0>
 static hipError_t launch_eval_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
 {
-	auto kfn = eval_kernel<FAM, NOUT, K, NT, EPT>;
+	auto kfn = eval_kernel<FAM, NOUT, K, NT, EPT, CHM>;
 	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
 	hipLaunchKernelGGL(kfn, dim3(a.grid), dim3(NT), L.total, a.st, D, T, L, a.batch, a.mode, a.x, a.f, a.g, a.c, a.jb, a.cj);
 	return hipGetLastError();
 }
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true, int CHM = 0>
 static hipError_t launch_sqp_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
-	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS>;
+	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS, CHM>;
 	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
 	hipLaunchKernelGGL(kfn, dim3(a.batch), dim3(NT), L.total, a.st, D, T, L, sp, a.batch, a.lo, a.up, a.x, a.obj, a.inf, a.it, a.nf,
 	                   a.cl, a.hist, a.alw, a.vecw);
 	return hipGetLastError();
 }
 // the small-problem instances: 128 or 256 lanes, all vectors in LDS
-template <int FAM, int NOUT, int K>
+template <int FAM, int NOUT, int K, int CHM = 0>
 static hipError_t launch_eval_small(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
 {
-	if (a.nt == 128) return launch_eval_one<FAM, NOUT, K, 128, 4>(D, T, L, a);
-	if (a.nt == 256) return launch_eval_one<FAM, NOUT, K, 256, 4>(D, T, L, a);
+	if (a.nt == 128) return launch_eval_one<FAM, NOUT, K, 128, 4, CHM>(D, T, L, a);
+	if (a.nt == 256) return launch_eval_one<FAM, NOUT, K, 256, 4, CHM>(D, T, L, a);
 	return hipErrorInvalidValue;
 }
-template <int FAM, int NOUT, int K>
+template <int FAM, int NOUT, int K, int CHM = 0>
 static hipError_t launch_sqp_small(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
 	if (a.big) return hipErrorInvalidValue;
 	if (sp.hessian != 1) {   // identity cold start: the instance without any preconditioner code
-		if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false, false>(D, T, L, sp, a);
-		if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false, false>(D, T, L, sp, a);
+		if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false, false, CHM>(D, T, L, sp, a);
+		if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false, false, CHM>(D, T, L, sp, a);
 		return hipErrorInvalidValue;
 	}
-	if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false, true>(D, T, L, sp, a);
-	if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false, true>(D, T, L, sp, a);
+	if (a.nt == 128) return launch_sqp_one<FAM, NOUT, K, 128, 4, false, true, CHM>(D, T, L, sp, a);
+	if (a.nt == 256) return launch_sqp_one<FAM, NOUT, K, 256, 4, false, true, CHM>(D, T, L, sp, a);
 	return hipErrorInvalidValue;
+}
+// does the plan match a channel-mask instance?  Running cost only, its active variables = derivative channels CHM of every
+// output, no other weighted-gradient rows
+static inline bool ntg_chm_match(const NtgDims &D, int chm, int dm)
+{
+	return D.nucf && !D.nicf && !D.nfcf && D.ncnln == 0 && D.tcost_mask == chm_full_mask(chm, D.nout, dm) &&
+	       D.ntav == D.nout * chm_count(chm);
 }
 // the generic instance of a family (run-time nout / order) at every workgroup size, LDS-resident or BIG
 template <int FAM>
