@@ -245,7 +245,7 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 // tests that the general code looks up at run time are then constants.
 __host__ __device__ constexpr int chm_count(int chm) { return (chm & 1) + ((chm >> 1) & 1) + ((chm >> 2) & 1) + ((chm >> 3) & 1) + ((chm >> 4) & 1); }
 __host__ __device__ constexpr int chm_rank(int chm, int r) { return chm_count(chm & ((1 << r) - 1)); }
-__host__ __device__ inline u64 chm_full_mask(int chm, int nout, int dm)
+__host__ __device__ constexpr u64 chm_full_mask(int chm, int nout, int dm)
 {
 	u64 m = 0;
 	for (int o = 0; o < nout; o++) for (int r = 0; r < dm; r++) if ((chm >> r) & 1) m |= 1ull << (dm * o + r);
@@ -474,9 +474,11 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 	lds_sync(); // sx complete, previous users of dfz/fvals done
 	if ((D.nucf || (alon && D.nnltc))) {
 		const u64 zmask = alon ? (D.tcost_mask | D.tcon_mask) : D.tcost_mask;
+		// the channel-mask shortcuts apply when this pass uses exactly "channels CHM of every output" (wave-uniform)
+		const bool chm_now = NOUT > 0 && CHM != 0 && chm_ok && zmask == chm_full_mask(CHM, NOUT > 0 ? NOUT : 1, DM);
 		for (int i = tid; i < P; i += NT) {                       // cost.c:103-109
 			double z[NZ], df[NZ], f = 0.0;
-			compute_z<NOUT, K, DM, CHM>(D, S, sx, i, zmask, z, chm_ok && !alon);
+			compute_z<NOUT, K, DM, CHM>(D, S, sx, i, zmask, z, chm_now);
 			if (D.nucf) Fam::ucf(nout, i, z, f, df);
 			else {
 #pragma unroll
@@ -493,7 +495,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 				for (int j = 0; j < NTc; j++) t[j] = j < D.nnltc ? al_term(c[j], D.nnlic + j * P + i, b0 + D.nnlic + j) : 0.0;
 				Fam::template nltc_vjp<NZ>(nout, nz, i, z, t, df);   // df += J' t, constraint-major like the dense loop
 			}
-			if (NOUT > 0 && CHM != 0 && chm_ok && !alon) {
+			if (chm_now) {
 				// the weighted-gradient rows are (output, channel of CHM) in flag order: row = o NCH + rank(r)
 				constexpr int NCH = chm_count(CHM);
 #pragma unroll
@@ -712,7 +714,8 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	if (lin_on) lin_ineq_phase<NT>(D, *li, sx, al, psi, rv2);   // sx was complete before the functor pass
 	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
 	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT, SHARED, CHM>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
-	                                          psi, rv2, Fpure, rv2_out, lin_on ? li : nullptr, chm_ok && !alon);
+	                                          psi, rv2, Fpure, rv2_out, lin_on ? li : nullptr,
+	                                          chm_ok && (alon ? (D.tcost_mask | D.tcon_mask) : D.tcost_mask) == chm_full_mask(CHM, NOUT > 0 ? NOUT : 1, Fam::DM));
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
 }
@@ -1462,7 +1465,8 @@ static hipError_t launch_sqp_small(const NtgDims &D, const NtgTables &T, const S
 // output, no other weighted-gradient rows
 static inline bool ntg_chm_match(const NtgDims &D, int chm, int dm)
 {
-	return D.nucf && !D.nicf && !D.nfcf && D.ncnln == 0 && D.tcost_mask == chm_full_mask(chm, D.nout, dm) &&
+	// (with trajectory constraints the mask is the one of the augmented-Lagrangian evaluation: cost and constraint variables)
+	return D.nucf && !D.nicf && !D.nfcf && D.nnlic == 0 && D.nnlfc == 0 && (D.tcost_mask | D.tcon_mask) == chm_full_mask(chm, D.nout, dm) &&
 	       D.ntav == D.nout * chm_count(chm);
 }
 // the generic instance of a family (run-time nout / order) at every workgroup size, LDS-resident or BIG
