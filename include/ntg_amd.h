@@ -81,7 +81,8 @@ typedef struct {
 	int ls_maxfev;      /* 20 */
 	int hessian;        /* 0 identity cold start (NPSOL), 1 collocation preconditioner */
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
-	int block_threads;  /* 0 = auto (64/128/256) */
+	int block_threads;  /* 0 = auto (128/256/512) */
+	int qn_memory;      /* quasi-Newton updates kept before the approximation restarts from W0; <= 0: 256 */
 } ntg_solve_opts;
 
 typedef struct ntg_plan ntg_plan;

@@ -476,6 +476,11 @@ extern "C" void ntg(int nout, double *bps, int nbps, int *kninterv, double **kno
 				alpha = ls.a;
 				for (int i = 0; i < n; i++) { sv[i] = alpha * p[i]; y[i] = gpn[i] - gp[i]; }
 				x = xt;
+				if (nupd == 256) {   // memory of the batched solver's pair history: restart from W0 (identity here) like it does
+					nupd = 0;
+					std::fill(W.begin(), W.end(), 0.0); for (int i = 0; i < n; i++) W[(size_t)i * n + i] = 1.0;
+					d = gp;
+				}
 				for (int i = 0; i < n; i++) { double a = 0; for (int j = 0; j < n; j++) a += W[(size_t)i * n + j] * gpn[j]; t[i] = a; }
 				for (int i = 0; i < n; i++) u[i] = t[i] - d[i];
 				const double sy = dot(sv, y);

@@ -33,7 +33,7 @@ extern "C" int ntg_device_count(void)
 extern "C" void ntg_default_opts(ntg_solve_opts *o)
 {
 	o->itlim = 0; o->opttol = 0.0; o->steplimit = 2.0; o->ls_mu = 1e-4; o->ls_eta = 0.9;
-	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->block_threads = 0;
+	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->block_threads = 0; o->qn_memory = 0;
 }
 extern "C" const char *ntg_solve_kernel_name(void) { return "sqp_kernel"; }
 // diagnostic: LDS bytes and block size the solve / eval launches of this plan use
@@ -585,7 +585,7 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	ntg_solve_opts def; ntg_default_opts(&def);
 	if (!o) o = &def;
 	sp->itlim = o->itlim > 0 ? o->itlim : std::max(50, 3 * (D.nC + D.nclin) + 10 * D.ncnln);
-	sp->memcap = std::min(sp->itlim, 256);
+	sp->memcap = std::min(sp->itlim, o->qn_memory > 0 ? o->qn_memory : 256);
 	sp->ls_maxfev = o->ls_maxfev > 0 ? o->ls_maxfev : 20;
 	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters;
 	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;

@@ -109,6 +109,7 @@ typedef struct {
 	int hessian;         /* 0: identity cold start (NPSOL), 1: collocation preconditioner */
 	int fixed_iters;     /* 1: run exactly itlim majors, no convergence exit */
 	int verbose;
+	int qn_memory;       /* BFGS updates kept before W restarts from W0 (the device's pair memory); <= 0: 256 */
 } orc_sqp_opts;
 void orc_sqp_default_opts(orc_sqp_opts *o);
 

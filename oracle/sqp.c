@@ -40,7 +40,7 @@
 void orc_sqp_default_opts(orc_sqp_opts *o)
 {
 	o->itlim = 0; o->opttol = 0.0; o->steplimit = 2.0; o->ls_mu = 1e-4; o->ls_eta = 0.9;
-	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->verbose = 0;
+	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->verbose = 0; o->qn_memory = 0;
 }
 
 /* ---------------- dense helpers (column-major, ld explicit) ---------------- */
@@ -492,6 +492,13 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			alpha = ls.a;
 			for (i = 0; i < n; i++) { s[i] = alpha * pdir[i]; y[i] = gpn[i] - gp[i]; }
 			memcpy(x, xt, n * sizeof(double));
+			if (nupd == (o->qn_memory > 0 ? o->qn_memory : 256)) {
+				/* memory full (the device keeps the updates as pairs): restart the approximation from W0 */
+				nupd = 0;
+				if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
+				else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
+				for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
+			}
 			/* t = W gp+,  u = W y = t - d */
 			for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gpn[j]; t[i] = sum; }
 			for (i = 0; i < n; i++) u[i] = t[i] - d[i];

@@ -108,3 +108,20 @@ def test_full_size_solve_kkt(name, l, nb):
     ref = orc.solve_one(spec, lo[1], up[1], np.ones(spec.nC), orc.default_opts(hessian=1))
     assert ref["inform"] in (0, 1)
     assert abs(obj[1] - ref["objective"]) <= 2e-5 * abs(ref["objective"])
+
+
+def test_short_quasi_newton_memory_matches_oracle():
+    """qn_memory: both implementations restart their approximation from W0 after the same number of updates, so a
+    short memory is still the same algorithm on both sides (reduced config D, memory 16)."""
+    spec, bounds = _case("D", 8)
+    p = api.Plan(spec, 0)
+    nb = 4
+    lo, up = bounds(nb)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=1, qn_memory=16), want_lambda=True)
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(hessian=1, qn_memory=16), nthreads=nb)
+    inf = out["inform"].cpu().numpy(); obj = out["objective"].cpu().numpy()
+    assert np.isin(inf, (0, 1)).all() and np.isin(ref["inform"], (0, 1)).all()
+    assert (np.abs(obj - ref["objective"]) <= 2e-5 * np.abs(ref["objective"])).all()
+    # and the restart really happened: more majors than the memory holds
+    assert out["iters"].min().item() > 16
