@@ -3,9 +3,16 @@
 // order-6 splines (config B, 2 outputs) and the headline workload (config M, 6 outputs).  Own translation unit so that it
 // compiles next to fam_kincar.hip.
 #include "solve_impl.hpp"
+#include "eval_fast.hpp"
 
 hipError_t ntg_launch_eval_kincar_chm(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
 {
+	// values and gradient only (no Jacobian outputs: the family has no constraints): the lean kernel
+	FastEvalDims F;
+	if (a.nt == 128 && !a.c && !a.jb && !a.cj && eval_fast_match(D, 4, 3, 128, &F)) {
+		if (D.nout == 2) return launch_eval_fast<NTG_FAM_KINCAR, 2, 6, 4, 128>(D, T, F, a);
+		if (D.nout == 6) return launch_eval_fast<NTG_FAM_KINCAR, 6, 6, 4, 128>(D, T, F, a);
+	}
 	if (D.nout == 2) return launch_eval_small<NTG_FAM_KINCAR, 2, 6, 4>(D, T, L, a);
 	if (D.nout == 6) return launch_eval_small<NTG_FAM_KINCAR, 6, 6, 4>(D, T, L, a);
 	return hipErrorInvalidValue;

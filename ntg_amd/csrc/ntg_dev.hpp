@@ -40,6 +40,7 @@ struct NtgDims {
 	int cls_W[NTG_MAX_OUT];             // padded (multiple of 4) support width of the column form, per class
 	int cls_nc[NTG_MAX_OUT];            // coefficients per output of the class
 	int n0_blk[NTG_MAX_OUT];            // which dense preconditioner block an output uses (NtgTables::n0b)
+	int ch_row0[NTG_MAX_ORDER], ch_col0[NTG_MAX_ORDER];   // host copy of class 0's channel offsets (NtgTables::chrow/chcol)
 	int tav_rmask;                      // union over outputs of the derivative indices with a cost AV
 };
 
@@ -93,7 +94,7 @@ struct SolveParams {
 };
 
 // launcher arguments (host side)
-struct EvalArgs { int nt, grid, batch, mode; const double *x; double *f, *g, *c, *jb, *cj; hipStream_t st; };
+struct EvalArgs { int nt, grid, ncu, batch, mode; const double *x; double *f, *g, *c, *jb, *cj; hipStream_t st; };
 struct SqpArgs {
 	int nt, big, batch; const double *lo, *up; double *x, *obj; int *inf, *it, *nf; double *cl, *hist, *alw, *vecw; hipStream_t st;
 };

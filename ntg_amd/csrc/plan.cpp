@@ -256,6 +256,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		    dev_upload(&d_chrow, chrow.data(), chrow.size(), own) ||
 		    dev_upload(&d_chcol, chcol.data(), chcol.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 		T.rowv = d_rowv; T.colp = d_colp; T.chrow = d_chrow; T.chcol = d_chcol;
+		for (int r = 0; r < NTG_MAX_ORDER; r++) { D.ch_row0[r] = chrow[r]; D.ch_col0[r] = chcol[r]; }
 	}
 
 	// ---- linear constraint rows on the device, (A A')^-1 on the host ----
@@ -655,7 +656,7 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	{ hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
 	const int wg_per_cu = std::max(1, std::min(std::min(8, 32 / (nt / 64)), (160 * 1024) / std::max(L.total, 1)));
 	const int grid = std::min(batch, ncu * wg_per_cu);
-	EvalArgs ea{nt, grid, batch, mode, d_x, d_f, d_g, d_c, d_jband, d_cjac, st};
+	EvalArgs ea{nt, grid, ncu, batch, mode, d_x, d_f, d_g, d_c, d_jband, d_cjac, st};
 	HIPCHK(ntg_launch_eval(D, p->T, L, ea));
 	return 0;
 }
