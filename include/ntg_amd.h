@@ -79,7 +79,8 @@ typedef struct {
 	double steplimit;   /* NPSOL "step limit", 2.0 */
 	double ls_mu, ls_eta; /* 1e-4, 0.9 (NPSOL "line search tolerance") */
 	int ls_maxfev;      /* 20 */
-	int hessian;        /* 0 identity cold start (NPSOL), 1 collocation preconditioner */
+	int hessian;        /* 0 identity cold start (NPSOL), 1 collocation preconditioner (ignored when the cost model is
+	                     * singular on the null space of the equality rows, e.g. a plan without equality rows) */
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
 	int block_threads;  /* 0 = auto (128/256/512) */
 	int qn_memory;      /* quasi-Newton updates kept before the approximation restarts from W0; <= 0: 256 */

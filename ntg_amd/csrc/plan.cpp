@@ -474,6 +474,13 @@ static int precond_block(const std::vector<double> &H0, const std::vector<double
 	};
 	form_hr(1e-12);
 	if (!chol_lower(Hr, nr)) { form_hr(1e-6); if (!chol_lower(Hr, nr)) return fail(NTG_E_UNSUPPORTED, "preconditioner not positive definite"); }
+	else {
+		// H0 singular on null(A) (no equality rows: constants and ramps cost nothing): the regularised inverse would scale
+		// those directions by 1e12 -- no preconditioner then, the solve starts from the identity
+		double lo = 1e300, hi = 0.0;
+		for (int i = 0; i < nr; i++) { const double dd = Hr[(size_t)i * nr + i] * Hr[(size_t)i * nr + i]; lo = std::min(lo, dd); hi = std::max(hi, dd); }
+		if (lo < 1e-9 * hi) return 1;
+	}
 	// X[:, c] = Hr^-1 Zt[:, c] ; W0 = Zt' X
 	std::vector<double> X((size_t)n * nr), col(nr), Zc((size_t)n * nr);
 	for (int c = 0; c < n; c++) { for (int i = 0; i < nr; i++) { col[i] = Zt[(size_t)i * n + c]; Zc[(size_t)c * nr + i] = col[i]; } chol_solve(Hr, nr, col.data()); for (int i = 0; i < nr; i++) X[(size_t)c * nr + i] = col[i]; }
@@ -540,6 +547,7 @@ static int build_precond(ntg_plan *p)
 		if (D.nfcf) add(p->fcostav, P - 1, 1.0);
 		for (int i = 0; i < mb; i++) for (int j = 0; j < nb; j++) Ab[(size_t)i * nb + j] = p->h_AE[(size_t)rsel[i] * n + idx[j]];
 		const int rc = precond_block(H0, Ab, mb, nb, Wb);
+		if (rc > 0) { p->precond_ready = true; p->precond_singular = true; return 0; }   // singular model: identity start instead
 		if (rc) return rc;
 		{
 			int nouts = 0; for (int o = 0; o < D.nout; o++) if (comp[o] == o0) nouts++;
@@ -677,6 +685,7 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	resolve_params(p, o, &sp, &nt);
 	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
 	if (sp.hessian == 1 && !p->precond_ready) { int rc = build_precond(p); if (rc) return rc; }
+	if (sp.hessian == 1 && p->precond_singular) sp.hessian = 0;
 	SmemLayout L; int big;
 	if (solve_layout(p->D, nt, &L, &big)) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
 	double *alw = (double *)d_work + hist_doubles(p->D, batch, sp);   // [batch][2][ncnln] multipliers, estimates

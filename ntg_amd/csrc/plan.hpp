@@ -10,6 +10,7 @@ struct ntg_plan {
 	NtgTables T;
 	bool lin_ok = true;
 	bool precond_ready = false;                 // W0 tables (T.n0 or T.n0b) built
+	bool precond_singular = false;              // the cost Hessian model is singular on null(A_E): hessian = 1 falls back to the identity
 	std::vector<void *> owned;                  // device allocations
 	std::vector<std::vector<double>> h_knots;   // host mirrors of the setup tables
 	std::vector<double> h_bps, h_blk, h_aband, h_Adense, h_AE;   // h_Adense: all linear rows; h_AE: the equality rows

@@ -97,3 +97,26 @@ def test_all_rows_equalities_is_the_old_path():
         api.Plan(s, 0).solve(dev(lo), dev(up), x, api.default_opts(hessian=1))
         xs.append(x.clone())
     assert torch.equal(xs[0], xs[1])
+
+
+@pytest.mark.parametrize("hessian", [0, 1])
+def test_every_linear_row_a_range(hessian):
+    """No equality row left: nothing to project, every linear row goes through the augmented Lagrangian."""
+    flags = [1] * 12
+    spec = _spec("K0", flags)
+    p = api.Plan(spec, 0)
+    lo0, up0 = cf.bounds_K0_shipped()
+    nb = 4
+    lo = np.tile(lo0, (nb, 1)) - 0.05 * (1 + np.arange(nb))[:, None]
+    up = np.tile(up0, (nb, 1)) + 0.05 * (1 + np.arange(nb))[:, None]
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=hessian, itlim=3000), want_lambda=True)
+    inf = out["inform"].cpu().numpy(); obj = out["objective"].cpu().numpy(); xg = x.cpu().numpy()
+    A = p.tables()["A"]
+    for i in range(nb):
+        ref = orc.solve_one(spec, lo[i], up[i], np.ones(spec.nC), orc.default_opts(hessian=hessian, itlim=3000))
+        assert inf[i] in (0, 1) and ref["inform"] in (0, 1)
+        assert abs(obj[i] - ref["objective"]) <= 1e-6 * max(1.0, abs(ref["objective"]))
+        Ax = A @ xg[i]
+        assert (Ax >= lo[i] - 1e-6).all() and (Ax <= up[i] + 1e-6).all()
+    assert (np.diff(obj) < 0).all()          # wider ranges, lower optimal cost
