@@ -566,7 +566,7 @@ static int build_precond(ntg_plan *p)
 		// one dense block per output, kept once per distinct block: s-major (symmetric, so [s][row] == [row][s]),
 		// rows padded with zeros to a multiple of 16
 		const int spad = (nb_first + 15) & ~15;
-		std::vector<double> all(wblocks.size() * (size_t)spad * nb_first, 0.0);
+		std::vector<double> all(wblocks.size() * (size_t)spad * nb_first + 16, 0.0);   // +16: the last row tile reads up to 15 words past a row
 		for (size_t q = 0; q < wblocks.size(); q++) std::copy(wblocks[q].begin(), wblocks[q].end(), all.begin() + q * (size_t)spad * nb_first);
 		double *d_wb = nullptr;
 		if (dev_upload(&d_wb, all.data(), all.size(), p->owned)) return NTG_E_HIP;

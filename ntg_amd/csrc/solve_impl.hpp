@@ -898,69 +898,59 @@ __device__ __attribute__((noinline)) void apply_n0(int n, int w, const double *_
 }
 
 // out = W0 v when W0 is block diagonal by output with equally sized dense blocks, few of them distinct (one basis
-// class, the same constraint pattern at the ends; outputs with the same cost derivative share a block): small dense
-// products  Out(nco x nout_b) = Wb(nco x nco) V(nco x nout_b).  A lane owns one row of the block for a share of
-// the outputs, so every word of Wb it reads from L2 is used for several outputs (the ELL form streams one copy of
-// the block per output).  V is staged in LDS (`stage`, laid out like v) and read
-// as broadcasts; `out` may alias `stage`: it is only written after the last read.
+// class, the same constraint pattern at the ends; outputs with the same cost derivative share a block): the one
+// GEMM-shaped piece of the path,  Out(nco x nout) = sum_b W_b (nco x nco) V_b (nco x nout),  V_b = the columns of the
+// outputs that use block b.  It runs on the matrix cores: v_mfma_f64_16x16x4_f64 tiles, a wave owns row tiles of 16
+// coefficients and sweeps k in steps of 4.  Register layout of the instruction (probed on gfx950): lane l supplies
+// A[i = l%16][k = l/16] and B[k = l/16][j = l%16] and receives D[i = 4r + l/16][j = l%16], r = 0..3.
+//   A = W_b: s-major in HBM/L2 ([s][row], symmetric), so the 16 lanes of a k read 16 consecutive words;
+//   B = V:   staged in LDS laid out like v ([output][coefficient]); column j >= nout or of another block is 0.
+// Rows of W_b beyond nco are zero padding (spad rows, a multiple of 16); `out` may alias `stage`: the result tiles
+// stay in registers until every wave has finished reading.
 typedef const __attribute__((address_space(3))) double *lds_cdp;
 typedef const __attribute__((address_space(3))) int *lds_cip;
-// OPP = outputs per lane (compile time, so that the accumulators are plain registers and the inner loop has no
-// branches); outputs beyond the lane's share are computed on a clamped index and dropped.
-template <int NT, int OPP>
-__device__ __attribute__((noinline)) void apply_n0_block(int nout, int nco, int spad, int nblk, int parts, const double *__restrict__ wb,
-                                                         lds_cip oinfo, lds_cdp stage, double *out)
-{
-	constexpr int U = 16;
-	// nco <= NT (checked by the caller): lane i owns row (i mod nco) of the block for the outputs of part (i / nco)
-	const int opp = (nout + parts - 1) / parts;   // outputs per part (<= OPP)
-	const int i = threadIdx.x, part = min(i / nco, parts - 1), row = i - (i / nco) * nco, o0 = part * opp;
-	const int no = i < parts * nco ? min(opp, nout - o0) : 0;
-	double acc[OPP];
-	int base[OPP], blk[OPP];
-#pragma unroll
-	for (int j = 0; j < OPP; j++) {
-		const int o = min(o0 + j, nout - 1);
-		acc[j] = 0.0; base[j] = o * nco; blk[j] = j < no ? oinfo[o * 10 + 2] : -1;
-	}
-	for (int b = 0; b < nblk; b++) {   // outputs that share block b reuse every word of it
-		const double *wbb = wb + (size_t)b * spad * nco + row;
-		for (int s0 = 0; s0 < spad; s0 += U) {
-			// U independent L2 loads in flight per lane (rows beyond nco are zero padding), then the FMAs
-			double wv[U];
-#pragma unroll
-			for (int u = 0; u < U; u++) wv[u] = wbb[(size_t)(s0 + u) * nco];   // consecutive lanes, consecutive words
-#pragma unroll
-			for (int u = 0; u < U; u++) {
-				const int sidx = min(s0 + u, nco - 1);
-#pragma unroll
-				for (int j = 0; j < OPP; j++) {
-					const double sv = stage[base[j] + sidx];
-					acc[j] = fma(wv[u], blk[j] == b ? sv : 0.0, acc[j]);
-				}
-			}
-		}
-	}
-	lds_sync();   // every read of stage is done: out may be the same buffer
-#pragma unroll
-	for (int j = 0; j < OPP; j++) { if (j < no) out[base[j] + row] = acc[j]; }
-}
-// One out-of-line entry per workgroup size (like apply_n0: it runs once or twice per major and must not add to the
-// register pressure of the main loop): stage v in LDS, pick the outputs-per-lane instance, multiply.
+typedef double ntg_d4 __attribute__((ext_vector_type(4)));
 template <int NT>
-__device__ __attribute__((noinline)) void apply_n0_block_any(int nC, int nout, int nco, int spad, int nblk, const double *wb, lds_cip oinfo,
-                                                             const double *v, double *stage_w, double *out)
+__device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int nco, int spad, int nblk, const double *__restrict__ wb,
+                                                         lds_cip oinfo, const double *v, double *stage_w, double *out)
 {
+	constexpr int NW = NT / 64, TMAX = 4;   // nco <= NT (checked by the caller): at most NT/16 = 4 NW row tiles
 	lds_sync();   // previous readers of stage are done
 	for (int c = threadIdx.x; c < nC; c += NT) stage_w[c] = v[c];   // owner lanes: v may live in HBM
 	lds_sync();
 	lds_cdp stage = (lds_cdp)stage_w;
-	const int parts = min(NT / nco, nout), opp = (nout + parts - 1) / parts;
-	if (opp <= 2) apply_n0_block<NT, 2>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
-	else if (opp <= 4) apply_n0_block<NT, 4>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
-	else if (opp <= 6) apply_n0_block<NT, 6>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
-	else if (opp <= 8) apply_n0_block<NT, 8>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
-	else apply_n0_block<NT, NTG_MAX_OUT>(nout, nco, spad, nblk, parts, wb, oinfo, stage, out);
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, li = lane & 15, lk = lane >> 4;
+	const int ntile = (nco + 15) >> 4;
+	const int myblk = li < nout ? oinfo[li * 10 + 2] : -1;
+	lds_cdp bcol = stage + (li < nout ? li : 0) * nco;
+	ntg_d4 acc[TMAX];
+#pragma unroll
+	for (int t = 0; t < TMAX; t++) acc[t] = ntg_d4{0.0, 0.0, 0.0, 0.0};
+	for (int b = 0; b < nblk; b++) {
+		const double *wbb = wb + (size_t)b * spad * nco + li;
+		const bool mine = myblk == b;
+		for (int k0 = 0; k0 < spad; k0 += 4) {
+			const int k = k0 + lk;
+			const double bv = mine ? bcol[min(k, nco - 1)] : 0.0;   // k >= nco: W's row is zero padding
+			const double *wk = wbb + (size_t)k * nco;
+#pragma unroll
+			for (int t = 0; t < TMAX; t++) {
+				const int tile = wave + t * NW;
+				if (tile < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wk[tile * 16], bv, acc[t], 0, 0, 0);
+			}
+		}
+	}
+	lds_sync();   // every read of stage is done: out may be the same buffer
+	if (li < nout) {
+#pragma unroll
+		for (int t = 0; t < TMAX; t++) {
+			const int tile = wave + t * NW;
+			if (tile < ntile) {
+#pragma unroll
+				for (int r = 0; r < 4; r++) { const int row = tile * 16 + 4 * r + lk; if (row < nco) out[li * nco + row] = acc[t][r]; }
+			}
+		}
+	}
 }
 
 // out = W0 v : identity on null(A) (cold start) or the collocation preconditioner.  `stage` is an LDS buffer of
@@ -977,7 +967,7 @@ __device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, i
 		return;
 	}
 	if (hessian == 1 && T.n0b && T.n0b_n <= NT) {
-		apply_n0_block_any<NT>(D.nC, D.nout, T.n0b_n, T.n0b_sp, T.n0b_nblk, T.n0b, (lds_cip)oinfo, v, stage, out);
+		apply_n0_block<NT>(D.nC, D.nout, T.n0b_n, T.n0b_sp, T.n0b_nblk, T.n0b, (lds_cip)oinfo, v, stage, out);
 		if (BIG) __syncthreads();   // out may live in HBM and was written by row, not by owner lane
 		else lds_sync();
 		return;
