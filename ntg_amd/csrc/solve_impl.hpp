@@ -914,7 +914,7 @@ template <int NT>
 __device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int nco, int spad, int nblk, const double *__restrict__ wb,
                                                          lds_cip oinfo, const double *v, double *stage_w, double *out)
 {
-	constexpr int NW = NT / 64, TMAX = 4;   // nco <= NT (checked by the caller): at most NT/16 = 4 NW row tiles
+	constexpr int NW = NT / 64, TMAX = 4, U = 4;   // nco <= NT (checked by the caller): at most NT/16 = 4 NW row tiles
 	lds_sync();   // previous readers of stage are done
 	for (int c = threadIdx.x; c < nC; c += NT) stage_w[c] = v[c];   // owner lanes: v may live in HBM
 	lds_sync();
@@ -929,15 +929,22 @@ __device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int n
 	for (int b = 0; b < nblk; b++) {
 		const double *wbb = wb + (size_t)b * spad * nco + li;
 		const bool mine = myblk == b;
-		for (int k0 = 0; k0 < spad; k0 += 4) {
-			const int k = k0 + lk;
-			const double bv = mine ? bcol[min(k, nco - 1)] : 0.0;   // k >= nco: W's row is zero padding
-			const double *wk = wbb + (size_t)k * nco;
+		for (int k0 = 0; k0 < spad; k0 += 4 * U) {   // spad is a multiple of 16 = 4 U
+			// U k-steps of loads first (L2 latency overlaps), then their matrix instructions
+			double av[U][TMAX], bv[U];
 #pragma unroll
-			for (int t = 0; t < TMAX; t++) {
-				const int tile = wave + t * NW;
-				if (tile < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(wk[tile * 16], bv, acc[t], 0, 0, 0);
+			for (int u = 0; u < U; u++) {
+				const int k = k0 + 4 * u + lk;
+				bv[u] = mine ? bcol[min(k, nco - 1)] : 0.0;   // k >= nco: W's row is zero padding
+				const double *wk = wbb + (size_t)k * nco;
+#pragma unroll
+				for (int t = 0; t < TMAX; t++) av[u][t] = (wave + t * NW < ntile) ? wk[(wave + t * NW) * 16] : 0.0;
 			}
+#pragma unroll
+			for (int u = 0; u < U; u++)
+#pragma unroll
+				for (int t = 0; t < TMAX; t++)
+					if (wave + t * NW < ntile) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][t], bv[u], acc[t], 0, 0, 0);
 		}
 	}
 	lds_sync();   // every read of stage is done: out may be the same buffer
