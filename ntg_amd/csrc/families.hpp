@@ -6,7 +6,8 @@
 // returns the value and the gradient over the full stacked flag, exactly like the callbacks
 // (cost.c:107-108, constraints.c:146-151).  Every output of a family has maxderiv == Family::DM.
 // Besides the dense callbacks every family offers the trajectory constraints in the two-step form the
-// augmented-Lagrangian evaluation uses: nltc_val (values only) and nltc_vjp (df += J' t), so that a family
+// augmented-Lagrangian evaluation uses: nltc_val (values, plus Family::TAPE doubles it wants to keep) and nltc_vjp
+// (df += J' t, with that tape), so that a family
 // with many constraints never holds its dense [ncon][nz] Jacobian in registers.
 //
 //   NTG_FAM_KINCAR     f = sum_o (z_o'')^2                      examples/kincar.c:105-117
@@ -40,7 +41,7 @@ struct DenseTraj {
 };
 
 template <> struct Family<NTG_FAM_KINCAR> {
-	static constexpr int DM = 3;
+	static constexpr int DM = 3, TAPE = 1;
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int, const double *z, double &f, double *df)
 	{
@@ -56,12 +57,12 @@ template <> struct Family<NTG_FAM_KINCAR> {
 	static __device__ __forceinline__ void nlicf(int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nltcf(int, int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nlfcf(int, const double *, double *, double *) {}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *, double *) {}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *, const double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *, double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *, const double *, double *, const double *) {}
 };
 
 template <> struct Family<NTG_FAM_VANDERPOL> {
-	static constexpr int DM = 3;
+	static constexpr int DM = 3, TAPE = 1;
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int, int, const double *zz, double &f, double *df)
 	{
@@ -77,13 +78,13 @@ template <> struct Family<NTG_FAM_VANDERPOL> {
 	static __device__ __forceinline__ void nlicf(int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nltcf(int, int, const double *, double *, double *) {}
 	static __device__ __forceinline__ void nlfcf(int, const double *, double *, double *) {}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *, double *) {}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *, const double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *, double *, double *) {}
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *, const double *, double *, const double *) {}
 };
 
 // dc is [ncon][nz] row-major (== the reference's dc[constraint][variable])
 template <> struct Family<NTG_FAM_TESTFAM> {
-	static constexpr int DM = 3;
+	static constexpr int DM = 3, TAPE = 1;
 	static constexpr int NNLIC = 1, NNLTC = 2, NNLFC = 1;
 	static __device__ __forceinline__ void icf(int nout, const double *z, double &f, double *df)
 	{
@@ -140,12 +141,12 @@ template <> struct Family<NTG_FAM_TESTFAM> {
 		for (int v = 0; v < nz; v++) dc[v] = 0.0;
 		dc[2] += z[0]; dc[0] += z[2]; dc[3 * L + 1] += 2.0 * z[3 * L + 1];
 	}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int i, const double *z, double *c) { DenseTraj<Family, NZMAX>::val(nout, i, z, c); }
-	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int nz, int i, const double *z, const double *t, double *df) { DenseTraj<Family, NZMAX>::vjp(nout, nz, i, z, t, df); }
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int i, const double *z, double *c, double *) { DenseTraj<Family, NZMAX>::val(nout, i, z, c); }
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int nz, int i, const double *z, const double *t, double *df, const double *) { DenseTraj<Family, NZMAX>::vjp(nout, nz, i, z, t, df); }
 };
 
 template <> struct Family<NTG_FAM_OBSTACLE> {
-	static constexpr int DM = 3;
+	static constexpr int DM = 3, TAPE = 1;
 	static constexpr int NNLIC = 0, NNLTC = 1, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int i, const double *z, double &f, double *df) { Family<NTG_FAM_KINCAR>::ucf(nout, i, z, f, df); }
 	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }
@@ -159,12 +160,12 @@ template <> struct Family<NTG_FAM_OBSTACLE> {
 		for (int v = 0; v < 3 * nout; v++) dc[v] = 0.0;
 		dc[0] = 2.0 * dx; dc[3] = 2.0 * dy;
 	}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int i, const double *z, double *c) { DenseTraj<Family, NZMAX>::val(nout, i, z, c); }
-	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int nz, int i, const double *z, const double *t, double *df) { DenseTraj<Family, NZMAX>::vjp(nout, nz, i, z, t, df); }
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int i, const double *z, double *c, double *) { DenseTraj<Family, NZMAX>::val(nout, i, z, c); }
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int nz, int i, const double *z, const double *t, double *df, const double *) { DenseTraj<Family, NZMAX>::vjp(nout, nz, i, z, t, df); }
 };
 
 template <> struct Family<NTG_FAM_QUADROTOR> {
-	static constexpr int DM = 5;
+	static constexpr int DM = 5, TAPE = 1;
 	static constexpr int NNLIC = 0, NNLTC = 2, NNLFC = 0;
 	static constexpr double G = 9.81;
 	static __device__ __forceinline__ void ucf(int, int, const double *z, double &f, double *df)
@@ -188,13 +189,13 @@ template <> struct Family<NTG_FAM_QUADROTOR> {
 		dc[2] = 2.0 * ax; dc[7] = 2.0 * ay; dc[12] = 2.0 * az;
 		dc[20 + 1] = 2.0 * z[1]; dc[20 + 6] = 2.0 * z[6]; dc[20 + 11] = 2.0 * z[11];
 	}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *z, double *c)
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int, int, const double *z, double *c, double *)
 	{
 		const double ax = z[2], ay = z[7], az = z[12] + G;
 		c[0] = ax * ax + ay * ay + az * az;
 		c[1] = z[1] * z[1] + z[6] * z[6] + z[11] * z[11];
 	}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *z, const double *t, double *df)
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int, int, int, const double *z, const double *t, double *df, const double *)
 	{
 		df[2] += t[0] * (2.0 * z[2]); df[7] += t[0] * (2.0 * z[7]); df[12] += t[0] * (2.0 * (z[12] + G));
 		df[1] += t[1] * (2.0 * z[1]); df[6] += t[1] * (2.0 * z[6]); df[11] += t[1] * (2.0 * z[11]);
@@ -203,7 +204,7 @@ template <> struct Family<NTG_FAM_QUADROTOR> {
 
 template <> struct Family<NTG_FAM_MANIP> {
 	static constexpr int DM = 3;
-	static constexpr int MAXARMS = NTG_MAX_OUT / 3;
+	static constexpr int MAXARMS = NTG_MAX_OUT / 3, TAPE = 3 * (NTG_MAX_OUT / 3);
 	static constexpr int NNLIC = 0, NNLTC = MAXARMS, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int i, const double *z, double &f, double *df) { Family<NTG_FAM_KINCAR>::ucf(nout, i, z, f, df); }
 	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }
@@ -223,23 +224,25 @@ template <> struct Family<NTG_FAM_MANIP> {
 			dc[j * nz + 9 * j + 6] = c3;
 		}
 	}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int, const double *z, double *c)
+	// values, and the cosines of the three link angles of every arm on the tape: the vjp needs nothing else
+	template <int NZMAX> static __device__ __forceinline__ void nltc_val(int nout, int, const double *z, double *c, double *tape)
 	{
 #pragma unroll
 		for (int j = 0; j < MAXARMS; j++) {
 			if (3 * j < nout) {
 				const double a1 = z[9 * j], a2 = a1 + z[9 * j + 3], a3 = a2 + z[9 * j + 6];
-				c[j] = sin(a1) + sin(a2) + sin(a3);
+				double s1, s2, s3;
+				sincos(a1, &s1, &tape[3 * j]); sincos(a2, &s2, &tape[3 * j + 1]); sincos(a3, &s3, &tape[3 * j + 2]);
+				c[j] = s1 + s2 + s3;
 			}
 		}
 	}
-	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int, int, const double *z, const double *t, double *df)
+	template <int NZMAX> static __device__ __forceinline__ void nltc_vjp(int nout, int, int, const double *, const double *t, double *df, const double *tape)
 	{
 #pragma unroll
 		for (int j = 0; j < MAXARMS; j++) {
 			if (3 * j < nout) {
-				const double a1 = z[9 * j], a2 = a1 + z[9 * j + 3], a3 = a2 + z[9 * j + 6];
-				const double c1 = cos(a1), c2 = cos(a2), c3 = cos(a3);
+				const double c1 = tape[3 * j], c2 = tape[3 * j + 1], c3 = tape[3 * j + 2];
 				df[9 * j] += t[j] * (c1 + c2 + c3);
 				df[9 * j + 3] += t[j] * (c2 + c3);
 				df[9 * j + 6] += t[j] * c3;

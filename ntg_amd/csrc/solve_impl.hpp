@@ -490,10 +490,11 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 			for (int v = 0; v < NZ; v++) df[v] *= w;
 			if (HASCON && alon && D.nnltc) {                      // constraints.c:148-155 folded into the same pass
 				double c[NTc], t[NTc];
-				Fam::template nltc_val<NZ>(nout, i, z, c);
+				double tape[Fam::TAPE];
+				Fam::template nltc_val<NZ>(nout, i, z, c, tape);
 #pragma unroll
 				for (int j = 0; j < NTc; j++) t[j] = j < D.nnltc ? al_term(c[j], D.nnlic + j * P + i, b0 + D.nnlic + j) : 0.0;
-				Fam::template nltc_vjp<NZ>(nout, nz, i, z, t, df);   // df += J' t, constraint-major like the dense loop
+				Fam::template nltc_vjp<NZ>(nout, nz, i, z, t, df, tape);   // df += J' t, constraint-major like the dense loop
 			}
 			if (chm_now) {
 				// the weighted-gradient rows are (output, channel of CHM) in flag order: row = o NCH + rank(r)
