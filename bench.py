@@ -184,13 +184,9 @@ def main():
         xC0 = torch.ones((nbC, specC.nC), dtype=torch.float64, device=dev)
         wC = torch.empty(planC.workspace_bytes(nbC, oc), dtype=torch.uint8, device=dev)
 
-        def mpc_run(nres):
+        def mpc_run(nres):   # nres x (solve, shift) inside the library: first step direct, the rest replayed as a hipGraph
             loC1, upC1, xC = loC0.clone(), upC0.clone(), xC0.clone()
-            bad = 0
-            for _ in range(nres):
-                o2 = planC.solve(loC1, upC1, xC, oc, work=wC)
-                planC.mpc_shift(xC, loC1, upC1, 5, 1)
-                bad = bad + (o2["inform"] != 0).sum()
+            _, bad = planC.mpc_run(xC, loC1, upC1, nres, 5, 1, oc, work=wC)
             return bad
         mpc_run(5); torch.cuda.synchronize()
         t1 = time.perf_counter(); bad = mpc_run(100); torch.cuda.synchronize()

@@ -152,6 +152,14 @@ int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x, int ntimes
 int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, int shift_knots, double *d_x,
                         double *d_lower, double *d_upper, void *stream);
 
+/* nsteps receding-horizon steps (solve, then ntg_batch_mpc_shift) without returning to the caller in between; after the
+ * first step the (solve, shift) pair is replayed as a hipGraph.  d_inform [batch] receives the last step's inform,
+ * d_notconv [1] (may be NULL; zero it first) accumulates the number of problems whose re-solve did not end with inform 0.
+ * With stream == NULL the run uses a private stream and returns when it has finished. */
+int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int shift_bp, int shift_knots, double *d_x,
+                      double *d_lower, double *d_upper, const ntg_solve_opts *o, int *d_inform, int *d_notconv,
+                      void *d_work, long long work_bytes, void *stream);
+
 /* ntg_open(): everything ntg() does before it calls npsol_ (ntg.c:114-229), with ntg()'s own
  * argument list minus initialguess, the bounds and the outputs; the problem stays current until
  * ntg_close().  For external SQP/IPOPT drivers (Pending:9) that iterate on their own and only need

@@ -68,6 +68,7 @@ def lib():
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_longlong, C.c_void_p]
         L.ntg_basis_batch.argtypes = [C.c_int] * 6 + [C.c_void_p] * 5
+        L.ntg_batch_mpc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_longlong, C.c_void_p]
         L.ntg_batch_interp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ntg_batch_mpc_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -204,6 +205,21 @@ class Plan:
         """Receding-horizon step in place: re-pin initial bounds to the solution's flag at breakpoint
         shift_bp, shift the coefficients by shift_knots knot intervals."""
         _check(lib().ntg_batch_mpc_shift(self.h, x.shape[0], shift_bp, shift_knots, _ptr(x), _ptr(lower), _ptr(upper), self._stream()))
+
+    def mpc_run(self, x, lower, upper, nsteps: int, shift_bp: int, shift_knots: int, opts: Optional[SolveOpts] = None, work=None):
+        """nsteps x (solve, shift) inside the library (hipGraph replay).  Returns (inform of the last step, #not converged)."""
+        import torch
+        o = opts if opts is not None else default_opts()
+        batch = x.shape[0]
+        need = self.workspace_bytes(batch, o)
+        if work is None:
+            work = torch.empty(need, dtype=torch.uint8, device=x.device)
+        inform = torch.empty(batch, dtype=torch.int32, device=x.device)
+        bad = torch.zeros(1, dtype=torch.int32, device=x.device)
+        torch.cuda.current_stream().synchronize()
+        _check(lib().ntg_batch_mpc_run(self.h, batch, nsteps, shift_bp, shift_knots, _ptr(x), _ptr(lower), _ptr(upper), C.byref(o),
+                                       _ptr(inform), _ptr(bad), _ptr(work), work.numel() * work.element_size(), self._stream()))
+        return inform, bad
 
     def workspace_bytes(self, batch: int, opts: Optional[SolveOpts] = None) -> int:
         return int(lib().ntg_batch_workspace_bytes(self.h, batch, C.byref(opts) if opts is not None else None))

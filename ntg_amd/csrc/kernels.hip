@@ -468,6 +468,20 @@ hipError_t ntg_launch_interp(const NtgDims &D, int batch, int ntimes, const doub
 	return hipGetLastError();
 }
 
+// receding-horizon bookkeeping: how many problems of the last re-solve did not end with inform 0
+__global__ void count_notconv_kernel(int batch, const int *__restrict__ inform, int *__restrict__ count)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	const int bad = (i < batch && inform[i] != 0) ? 1 : 0;
+	const unsigned long long m = __ballot(bad);
+	if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+hipError_t ntg_launch_count_notconv(int batch, const int *inform, int *count, hipStream_t st)
+{
+	hipLaunchKernelGGL(count_notconv_kernel, dim3((batch + 255) / 256), dim3(256), 0, st, batch, inform, count);
+	return hipGetLastError();
+}
+
 hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,
                               const double *lfc, double *aband, int *rbp, hipStream_t st)
 {

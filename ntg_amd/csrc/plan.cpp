@@ -696,6 +696,48 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	return 0;
 }
 
+// A receding-horizon run: nsteps times (solve, shift).  The first step runs directly (it may build the preconditioner);
+// the (solve, count, shift) sequence of the remaining steps is captured once into a hipGraph and replayed, so that a
+// step costs one graph launch instead of three kernel launches from the host loop.
+extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int shift_bp, int shift_knots, double *d_x,
+                                 double *d_lower, double *d_upper, const ntg_solve_opts *o, int *d_inform, int *d_notconv,
+                                 void *d_work, long long work_bytes, void *stream)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0 || nsteps <= 0) return 0;
+	if (!d_x || !d_lower || !d_upper || !d_inform) return fail(NTG_E_BADARG, "null argument");
+	if (shift_bp < 0 || shift_bp >= p->D.P || shift_knots < 0) return fail(NTG_E_BADARG, "shift out of range");
+	HIPCHK(hipSetDevice(p->device));
+	hipStream_t st = (hipStream_t)stream, own = nullptr;
+	if (!st) { HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking)); st = own; }   // the legacy default stream cannot be captured
+	auto step = [&]() -> int {
+		int rc = ntg_batch_solve(p, batch, d_lower, d_upper, d_x, o, nullptr, d_inform, nullptr, nullptr, nullptr, d_work, work_bytes, st);
+		if (rc) return rc;
+		if (d_notconv) { hipError_t e = ntg_launch_count_notconv(batch, d_inform, d_notconv, st); if (e != hipSuccess) return fail(NTG_E_HIP, hipGetErrorString(e)); }
+		return ntg_batch_mpc_shift(p, batch, shift_bp, shift_knots, d_x, d_lower, d_upper, st);
+	};
+	int rc = 0;
+	if (own) rc = hipDeviceSynchronize() == hipSuccess ? 0 : NTG_E_HIP;   // order after work queued on the default stream
+	if (!rc) rc = step();
+	if (!rc && nsteps > 1) {
+		hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+		hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+		if (e == hipSuccess) {
+			rc = step();
+			hipError_t e2 = hipStreamEndCapture(st, &graph);
+			if (!rc && e2 != hipSuccess) rc = fail(NTG_E_HIP, hipGetErrorString(e2));
+			if (!rc && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(NTG_E_HIP, "hipGraphInstantiate failed");
+			for (int s = 1; !rc && s < nsteps; s++) if (hipGraphLaunch(exec, st) != hipSuccess) rc = fail(NTG_E_HIP, "hipGraphLaunch failed");
+			if (exec) (void)hipGraphExecDestroy(exec);
+			if (graph) (void)hipGraphDestroy(graph);
+		} else {
+			for (int s = 1; !rc && s < nsteps; s++) rc = step();   // capture unavailable: plain launches
+		}
+	}
+	if (own) { if (hipStreamSynchronize(own) != hipSuccess && !rc) rc = NTG_E_HIP; (void)hipStreamDestroy(own); }
+	return rc;
+}
+
 extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times, double *d_z,
                                 void *stream)
 {

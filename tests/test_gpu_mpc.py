@@ -80,3 +80,23 @@ def test_mpc_full_config_C_properties():
         p.mpc_shift(x, lo_d, up_d, 5, 1)
     assert ninf == 0
     assert worst_feas <= 1e-8
+
+
+def test_mpc_run_graph_replay_is_the_host_loop():
+    """ntg_batch_mpc_run (first step direct, the rest replayed as a hipGraph) == the same steps issued one by one."""
+    spec = cf.config_B(); p = plan_for("B")
+    nb = 256
+    lo, up = cf.kincar_random_bounds(1, nb)
+    opts = api.default_opts(hessian=1)
+    work = torch.empty(p.workspace_bytes(nb, opts), dtype=torch.uint8, device="cuda:0")
+    lo1, up1 = dev(lo), dev(up)
+    x1 = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    for _ in range(12):
+        p.solve(lo1, up1, x1, opts, work=work)
+        p.mpc_shift(x1, lo1, up1, 5, 1)
+    lo2, up2 = dev(lo), dev(up)
+    x2 = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    inform, bad = p.mpc_run(x2, lo2, up2, 12, 5, 1, opts, work=work)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0 and (inform == 0).all()
+    assert torch.equal(x1, x2) and torch.equal(lo1, lo2) and torch.equal(up1, up2)
