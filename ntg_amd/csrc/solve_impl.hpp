@@ -1172,7 +1172,11 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 
 		// line-search state lives in LDS (17 doubles would otherwise sit in every lane's registers);
 		// each step works on a register copy and lane 0 publishes it back between two barriers
-		LineSearch *lsm = (LineSearch *)(smem_raw + L.ls);
+		// two copies of the line-search state: every lane advances its own register copy, lane 0 stores the result into the
+		// OTHER copy, which is first read after the barriers of the next evaluation -- no barrier for the hand-over
+		LineSearch *lsb = (LineSearch *)(smem_raw + L.ls);
+		int lsi = 0;
+		double ls_a = 0.0;   // current trial step (every lane)
 		double r4[4] = {0, 0, 0, 0};   // gp.d, d.d, x.x, gp.gp of the current iterate
 		bool finished = false;
 		for (;;) {
@@ -1220,15 +1224,15 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					double dd[1] = {0.0};
 					for_vec<NT>(n, [&](int c) { dd[0] += sgpt[c] * (-sd[c]); });
 					block_sum<NT, 1>(dd, S.red);
-					LineSearch lsr = *lsm;
+					LineSearch lsr = lsb[lsi];
 					rc = lsr.step(Fn, dd[0]);
-					lds_sync();
-					if (tid == 0) *lsm = lsr;
-					lds_sync();
+					ls_a = lsr.a;
+					if (tid == 0) lsb[lsi ^ 1] = lsr;
+					lsi ^= 1;
 				}
 				if (rc == 0 || rc == 2) {
 					if (rc == 2) state = ST_FORCE;
-					const double a = lsm->a;
+					const double a = ls_a;
 					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * (-sd[c]); });
 					NTG_STAMP(5);
 					continue;
@@ -1254,7 +1258,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						finished = true; at_x = false;
 					}
 				} else {
-					alpha = lsm->a;
+					alpha = ls_a;
 					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
 					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
 					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
@@ -1330,9 +1334,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (!finished) {
 						const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
 						const double a = amax < 1.0 ? amax : 1.0;
-						lds_sync();
-						if (tid == 0) lsm->init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
-						lds_sync();
+						if (tid == 0) lsb[lsi ^ 1].init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
+						lsi ^= 1; ls_a = a;
 						state = ST_LS;
 						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * (-sd[c]); });
 					}
