@@ -725,13 +725,13 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 // to HBM.  Row order [initial; trajectory constraint-major x breakpoint; final].
 template <int FAM, int NOUT, int K, int NT>
 __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S, const double *sx, int mode,
-                                 double *c_out, double *jband, double *cjac)
+                                 double *c_out, double *jband, double *cjac, double *scratch, int scratch_cap)
 {
 	using Fam = Family<FAM>;
 	constexpr int DM = Fam::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
 	constexpr int NI = Fam::NNLIC > 0 ? Fam::NNLIC : 1, NTc = Fam::NNLTC > 0 ? Fam::NNLTC : 1, NF = Fam::NNLFC > 0 ? Fam::NNLFC : 1;
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz, tid = threadIdx.x;
-	auto emit_row = [&](int row, int bp, const double *dcrow) {
+	auto emit_row = [&](int row, int bp, const double *dcrow, double *jb) {
 		for (int o = 0; o < nout; o++) {
 			const int k = D.order[o], cc = D.cls[o], d = D.d[o];
 			const int col0 = D.iC[o] + S.off[cc * P + bp];
@@ -741,7 +741,7 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 					const int chr = S.chrow[cc * NTG_MAX_ORDER + r];
 					if (chr >= 0) a += dcrow[D.iz[o] + r] * S.rowv[chr + q * P + bp];
 				}
-				if (jband) jband[(size_t)row * D.sumk + D.koff[o] + q] = a;
+				if (jb) jb[(size_t)row * D.sumk + D.koff[o] + q] = a;
 				if (cjac) cjac[(size_t)(col0 + q) * D.ncnln + row] = a;
 			}
 		}
@@ -752,18 +752,74 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 		Fam::nlicf(nout, z, c, dc);
 		for (int j = 0; j < D.nnlic; j++) {
 			if (c_out && mode != 1) c_out[j] = c[j];
-			if (mode != 0) emit_row(j, 0, dc + j * nz);
+			if (mode != 0) emit_row(j, 0, dc + j * nz, jband);
 		}
 	}
+	// Trajectory rows.  The banded Jacobian of one constraint is P consecutive rows of sum(k) entries: a contiguous block
+	// of memory.  With one lane per breakpoint each store instruction would scatter 8-byte words sum(k)*8 bytes apart;
+	// instead the lanes first leave the functor's derivatives dc[j][v] (v in the trajectory-constraint active variables --
+	// a constraint depends on nothing else, ntg.h:57-60) in LDS, by breakpoint, and then walk the block in memory order:
+	// consecutive lanes, consecutive words.  The LDS area is the weighted-gradient rows of the cost pass, which runs after
+	// this; constraints are processed in chunks that fit it.
+	const int ncomp = __popcll(D.tcon_mask);
+	const bool coalesced = Fam::NNLTC > 0 && D.nnltc && jband && mode != 0 && ncomp > 0 && ncomp * P <= scratch_cap;
 	if (Fam::NNLTC > 0 && D.nnltc) {
-		for (int i = tid; i < P; i += NT) {
-			double z[NZ], c[NTc], dc[NTc * NZ];
-			compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
-			Fam::nltcf(nout, i, z, c, dc);
-			for (int j = 0; j < D.nnltc; j++) {
-				const int row = D.nnlic + j * P + i;              // constraints.c:139,153
-				if (c_out && mode != 1) c_out[row] = c[j];
-				if (mode != 0) emit_row(row, i, dc + j * nz);
+		const int chunk = coalesced ? max(1, min(D.nnltc, scratch_cap / (ncomp * P))) : D.nnltc;
+		for (int j0 = 0; j0 < D.nnltc; j0 += chunk) {
+			const int jn = min(chunk, D.nnltc - j0);
+			for (int i = tid; i < P; i += NT) {
+				double z[NZ], c[NTc], tape[Fam::TAPE];
+				compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
+				Fam::template nltc_val<NZ>(nout, i, z, c, tape);
+				for (int j = j0; j < j0 + jn; j++) {
+					const int row = D.nnlic + j * P + i;              // constraints.c:139,153
+					if (c_out && mode != 1) c_out[row] = c[j];
+					if (mode == 0) continue;
+					// row j of the functor's Jacobian = J' e_j: one (sparse, for the large families) vjp instead of a dense
+					// [ncon][nz] array in registers
+					double t[NTc], dcr[NZ];
+#pragma unroll
+					for (int jj = 0; jj < NTc; jj++) t[jj] = jj == j ? 1.0 : 0.0;
+#pragma unroll
+					for (int v = 0; v < NZ; v++) dcr[v] = 0.0;
+					Fam::template nltc_vjp<NZ>(nout, nz, i, z, t, dcr, tape);
+					if (cjac || !coalesced) emit_row(row, i, dcr, coalesced ? nullptr : jband);
+					if (coalesced) {
+						int comp = 0;
+#pragma unroll
+						for (int v = 0; v < NZ; v++)
+							if (v < nz && ((D.tcon_mask >> v) & 1ull)) { scratch[((j - j0) * ncomp + comp) * P + i] = dcr[v]; comp++; }
+					}
+				}
+			}
+			if (coalesced) {
+				lds_sync();
+				// every wave walks its own contiguous share of the block, 64 consecutive words per store instruction;
+				// (constraint, breakpoint, entry) advance by carries instead of divisions
+				constexpr int NW = NT / 64;
+				const int sumk = D.sumk, per = P * sumk, total = jn * per, seg = (total + NW - 1) / NW;
+				const int wv = tid >> 6, f0 = wv * seg + (tid & 63), fend = min(total, (wv + 1) * seg);
+				double *dst = jband + (size_t)(D.nnlic + j0 * P) * sumk;
+				int jc = f0 / per, rem = f0 - jc * per, bp = rem / sumk, e = rem - bp * sumk;
+				for (int f = f0; f < fend; f += 64) {
+					int o = 0;
+					if (NOUT > 0 && K > 0) o = e / K;                 // one order for every output
+					else while (o + 1 < nout && D.koff[o + 1] <= e) o++;
+					const int q = e - (NOUT > 0 && K > 0 ? o * K : D.koff[o]), cc = D.cls[o], d = NOUT > 0 ? DM : D.d[o];
+					const int iz = NOUT > 0 ? DM * o : D.iz[o];
+					double a = 0.0;
+					for (int r = 0; r < d; r++) {
+						const int v = iz + r, chr = S.chrow[cc * NTG_MAX_ORDER + r];
+						if (((D.tcon_mask >> v) & 1ull) && chr >= 0) {
+							const int comp = __popcll(D.tcon_mask & ((1ull << v) - 1ull));
+							a += scratch[(jc * ncomp + comp) * P + bp] * S.rowv[chr + q * P + bp];
+						}
+					}
+					dst[f] = a;
+					e += 64;
+					while (e >= sumk) { e -= sumk; if (++bp == P) { bp = 0; jc++; } }
+				}
+				lds_sync();
 			}
 		}
 	}
@@ -774,7 +830,7 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 		for (int j = 0; j < D.nnlfc; j++) {
 			const int row = D.nnlic + D.nnltc * P + j;
 			if (c_out && mode != 1) c_out[row] = c[j];
-			if (mode != 0) emit_row(row, P - 1, dc + j * nz);
+			if (mode != 0) emit_row(row, P - 1, dc + j * nz, jband);
 		}
 	}
 }
@@ -815,11 +871,13 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 		} else {
 			for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
 		}
+		const int P1 = D.P + 1;
 		if (D.ncnln && (c || jband || cjac)) {   // constraints first: they still need x, the cost pass overwrites it with g
 			lds_sync();
 			eval_constraints<FAM, NOUT, K, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
 			                                jband ? jband + (size_t)b * D.ncnln * D.sumk : nullptr,
-			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr);
+			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr,
+			                                S.dfz, (D.ntav > 0 ? D.ntav : 1) * (P1) + ntg_dfz_tail(D));
 		}
 		double gn2;
 		const double F = eval_cost<FAM, NOUT, K, NT, EPT, (NOUT >= 3), CHM>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr},
