@@ -176,6 +176,23 @@ def main():
                                  "iters_mean": float(oo["iters"].float().mean().item()),
                                  "iters_max": int(oo["iters"].max().item())}
         del wc
+        # ---- BASELINE configs[1]: kincar 2 outputs, order 6, 20 intervals, batch 256 ----
+        specB = cf.config_B(); planB = api.Plan(specB, local)
+        loB, upB = cf.kincar_random_bounds(1, 256)
+        loB = torch.tensor(loB, device=dev); upB = torch.tensor(upB, device=dev)
+        resB = {"workload": specB.name + ", batch 256"}
+        for key, oB in (("fixed_50_majors", api.default_opts(itlim=50, fixed_iters=1, hessian=0)), ("to_convergence", api.default_opts(hessian=1))):
+            wB = torch.empty(planB.workspace_bytes(256, oB), dtype=torch.uint8, device=dev)
+            xB = torch.ones((256, specB.nC), dtype=torch.float64, device=dev)
+            for _ in range(3):
+                xB.fill_(1.0); planB.solve(loB, upB, xB, oB, work=wB)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(20):
+                xB.fill_(1.0); ooB = planB.solve(loB, upB, xB, oB, work=wB)
+            torch.cuda.synchronize(); dtB = (time.perf_counter() - t1) / 20
+            resB[key] = {"value": 256 / dtB, "unit": "trajectories/s", "ms_per_batch": 1e3 * dtB, "iters_mean": float(ooB["iters"].float().mean().item())}
+        res["config_B_batch256"] = resB   # one problem per CU: this size measures the latency of a single solve, not throughput
+        del planB
         # ---- BASELINE config C: receding-horizon MPC, 100 re-solves x batch 1024, kincar 2-output ----
         specC = cf.config_B(); planC = api.Plan(specC, local)
         nbC = 1024
