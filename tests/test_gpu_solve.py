@@ -138,3 +138,37 @@ def test_full_batch_properties_config_M():
     xp = torch.ones_like(x)
     p.solve(lo_d[perm].contiguous(), up_d[perm].contiguous(), xp, api.default_opts(hessian=1))
     assert torch.equal(xp, x[perm])
+
+
+def test_c_abi_error_returns():
+    """Bad arguments come back as negative NTG_E_* codes with a message -- never a crash, never a silent result."""
+    import ctypes as C
+    import copy
+    L = api.lib()
+    spec = cf.config_K0()
+    # plan creation: unknown family, maxderiv that the family does not have, bad spline spec
+    for mutate, what in ((lambda s: setattr(s, "family", 77), "family"),
+                         (lambda s: setattr(s, "maxderiv", [2, 2]), "maxderiv"),
+                         (lambda s: setattr(s, "order", [11, 11]), "order")):
+        s2 = copy.deepcopy(spec); mutate(s2)
+        if what == "maxderiv":
+            s2.lic = np.eye(4); s2.lfc = np.eye(4); s2.tcostav = [(0, 1), (1, 1)]
+        with pytest.raises(api.NtgError):
+            api.Plan(s2, 0)
+    with pytest.raises(api.NtgError):
+        api.Plan(spec, 99)                                         # no such device
+    p = plan_for("K0")
+    lo, up = cf.bounds_K0_shipped()
+    lo_d, up_d = dev(lo[None]), dev(up[None])
+    x = torch.ones((1, spec.nC), dtype=torch.float64, device="cuda:0")
+    o = api.default_opts()
+    small = torch.empty(16, dtype=torch.uint8, device="cuda:0")
+    rc = L.ntg_batch_solve(p.h, 1, lo_d.data_ptr(), up_d.data_ptr(), x.data_ptr(), C.byref(o), None, None, None, None, None,
+                           small.data_ptr(), 16, None)
+    assert rc == -2 and b"workspace" in L.ntg_last_error()         # NTG_E_BADARG
+    rc = L.ntg_batch_solve(p.h, 1, None, up_d.data_ptr(), x.data_ptr(), C.byref(o), None, None, None, None, None, None, 0, None)
+    assert rc == -2
+    assert L.ntg_batch_solve(p.h, 0, None, None, None, None, None, None, None, None, None, None, 0, None) == 0   # empty batch: nothing to do
+    rc = L.ntg_batch_eval(p.h, 1, x.data_ptr(), 5, None, None, None, None, None, None)
+    assert rc == -2 and b"mode" in L.ntg_last_error()
+    assert torch.equal(x, torch.ones_like(x))                      # nothing was touched
