@@ -540,7 +540,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 template <int NOUT, int K, int NT, int DM, int EPT, bool SHARED = false, int CHM = 0>
 __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, double *sg, double *gnorm2, const CoefMap<EPT> &cm,
                                               bool hasI, bool hasF, double psi, double rv2, double *Fpure, double *rv2_out,
-                                              const LinIneq *li = nullptr, bool chm_ok = false)
+                                              const LinIneq *li = nullptr, bool chm_ok = false, double *defer = nullptr)
 {
 	const int P = D.P, nout = NOUT > 0 ? NOUT : D.nout, nz = D.nz;
 	const int tid = threadIdx.x;
@@ -687,6 +687,10 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 			acc[1] += g * g;
 		}
 	}
+	if (defer) {   // the caller folds these four partial sums into a reduction of its own (sqp_kernel: with the line search's slope)
+		defer[0] = acc[0]; defer[1] = acc[1]; defer[2] = acc[2]; defer[3] = acc[3];
+		return 0.0;
+	}
 	block_sum<NT, 4>(acc, S.red);
 	const double I = D.nicf ? S.dfi[nz] : 0.0, Ff = D.nfcf ? S.dff[nz] : 0.0;
 	*gnorm2 = acc[1];
@@ -702,7 +706,7 @@ template <int FAM, int NOUT, int K, int NT, int EPT, bool SHARED = false, int CH
 __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, const double *sx, double *sg, double *gnorm2,
                                             const CoefMap<EPT> &cm, const ALState &al, double *Fpure = nullptr,
                                             double *rv2_out = nullptr, unsigned long long *tk = nullptr, const LinIneq *li = nullptr,
-                                            bool chm_ok = false)
+                                            bool chm_ok = false, double *defer = nullptr)
 {
 	using Fam = Family<FAM>;
 	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
@@ -716,7 +720,8 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	if (tk) { lds_sync(); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[6] += t1 - t0; t0 = t1; }
 	const double F = cost_phase2<NOUT, K, NT, Fam::DM, EPT, SHARED, CHM>(D, S, sg, gnorm2, cm, D.nicf || (alon && D.nnlic), D.nfcf || (alon && D.nnlfc),
 	                                          psi, rv2, Fpure, rv2_out, lin_on ? li : nullptr,
-	                                          chm_ok && (alon ? (D.tcost_mask | D.tcon_mask) : D.tcost_mask) == chm_full_mask(CHM, NOUT > 0 ? NOUT : 1, Fam::DM));
+	                                          chm_ok && (alon ? (D.tcost_mask | D.tcon_mask) : D.tcost_mask) == chm_full_mask(CHM, NOUT > 0 ? NOUT : 1, Fam::DM),
+	                                          defer);
 	if (tk) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tk[7] += t1 - t0; }
 	return F;
 }
@@ -893,13 +898,20 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 // ------------------------------------------------------------------------------------------
 // gp = g - A'(AA')^-1 A g  (projection onto null(A)); S.lam receives the multipliers estimate.
 // A is kept sparse (CSR for A g, CSC for A' lam); (AA')^-1 is a small dense matrix.
+// With dneg != nullptr the pass also accumulates this lane's share of gp . (-dneg) into *slope (the directional
+// derivative the line search needs) and leaves the closing barrier to the reduction that follows.
 template <int NT, bool BIG>
-__device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */)
+__device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const double *sg, double *sgp, double *tmp /* LDS [nclin] */,
+                                        const double *dneg = nullptr, double *slope = nullptr)
 {
 	const int m = D.mE, tid = threadIdx.x;
 	if (BIG) __syncthreads();   // g lives in HBM/L2 and is read across lanes
 	else lds_sync();
-	if (m == 0) { for (int c = tid; c < D.nC; c += NT) sgp[c] = sg[c]; lds_sync(); return; }
+	if (m == 0) {
+		for (int c = tid; c < D.nC; c += NT) { const double gq = sg[c]; sgp[c] = gq; if (dneg) *slope += gq * (-dneg[c]); }
+		if (!dneg) lds_sync();
+		return;
+	}
 	if (D.q_use) {
 		// gp = g - Q g with Q = A'(AA')^-1 A stored as ELL over its non-zero rows: one pass, no
 		// intermediate barrier; the padded entries (value 0, column 0) keep every load unconditional
@@ -911,9 +923,11 @@ __device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const d
 #pragma unroll 4
 				for (int e = 0; e < w; e++) s += S.q_val[t * w + e] * sg[S.q_col[t * w + e]];
 			}
-			sgp[c] = sg[c] - s;
+			const double gq = sg[c] - s;
+			sgp[c] = gq;
+			if (dneg) *slope += gq * (-dneg[c]);
 		});
-		lds_sync();
+		if (!dneg) lds_sync();
 		return;
 	}
 	for (int r = tid; r < m; r += NT) {
@@ -931,9 +945,11 @@ __device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const d
 	for (int c = tid; c < D.nC; c += NT) {
 		double s = 0.0;
 		for (int e = S.csc_ptr[c]; e < S.csc_ptr[c + 1]; e++) s += S.csc_val[e] * S.lam[S.csc_row[e]];
-		sgp[c] = sg[c] - s;
+		const double gq = sg[c] - s;
+		sgp[c] = gq;
+		if (dneg) *slope += gq * (-dneg[c]);
 	}
-	lds_sync();
+	if (!dneg) lds_sync();
 }
 
 // out = W0 v for the collocation preconditioner (ELL, rows streamed from L2).  Kept out of line:
@@ -1239,9 +1255,23 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		bool finished = false;
 		for (;;) {
 			// ================= the one evaluation site =================
-			double gn2n, Fpn, rv2n;
-			const double Fn = eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gn2n, cm, al, &Fpn, &rv2n, sp.stamps ? tk : nullptr, LIN ? &lin : nullptr, CHM != 0);
+			// The evaluation leaves its four sums (quadrature, |g|^2, penalty, violation) as per-lane partials; the
+			// projection pass adds the slope of the line search, and ONE workgroup reduction serves all five.
+			double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, gdummy;
+			(void)eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gdummy, cm, al, nullptr, nullptr, sp.stamps ? tk : nullptr,
+			                                                        LIN ? &lin : nullptr, CHM != 0, part);
 			NTG_STAMP(1);
+			if (state != ST_FINAL && state != ST_REEVAL) {
+				project<NT, BIG>(D, S, sg, sgpt, tmp, sd, &part[4]);
+				NTG_STAMP(2);
+				block_sum<NT, 5>(part, S.red);
+			} else {
+				double p4[4] = {part[0], part[1], part[2], part[3]};
+				block_sum<NT, 4>(p4, S.red);
+				part[0] = p4[0]; part[1] = p4[1]; part[2] = p4[2]; part[3] = p4[3];
+			}
+			const double Fpn = (D.nicf ? S.dfi[D.nz] : 0.0) + part[0] + (D.nfcf ? S.dff[D.nz] : 0.0);   // ntg.c:328
+			const double Fn = Fpn + part[2], gn2n = part[1], rv2n = part[3];
 			if (state == ST_FINAL) {
 				// multipliers estimate lam = (AA')^-1 A g at the final point
 				if (BIG) __syncthreads(); else lds_sync();
@@ -1265,8 +1295,6 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (state == ST_REEVAL) {   // constraint values and multiplier estimates refreshed at x
 				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 			} else {
-			project<NT, BIG>(D, S, sg, sgpt, tmp);
-			NTG_STAMP(2);
 			if (state == ST_INIT) {
 				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
@@ -1279,9 +1307,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			} else {
 				int rc = 1;
 				if (state == ST_LS) {
-					double dd[1] = {0.0};
-					for_vec<NT>(n, [&](int c) { dd[0] += sgpt[c] * (-sd[c]); });
-					block_sum<NT, 1>(dd, S.red);
+					const double dd[1] = {part[4]};   // gp+ . (-d), reduced together with the evaluation's sums
 					LineSearch lsr = lsb[lsi];
 					rc = lsr.step(Fn, dd[0]);
 					ls_a = lsr.a;
