@@ -143,3 +143,25 @@ def test_batch_interp_matches_spline_interp(name):
                                             co.ctypes.data_as(dp), int(spec.ncoef[o]), int(spec.order[o]), int(spec.mult[o]), int(spec.maxderiv[o]))
                 ref[b, ti, iz[o]:iz[o + 1]] = f
     assert rel(z, ref) <= 1e-13
+
+
+def test_full_size_eval_properties_config_M():
+    """BASELINE size (4096 x config M), no oracle run: the kincar cost is a quadratic form, so the evaluation must be
+    homogeneous of degree 2 in f and linear in g; f = g.x / 2 (Euler) ties the two outputs together; the three NPSOL
+    modes (values, gradient, both) give identical numbers."""
+    spec = SPECS["M"](); p = plan_for("M")
+    nb = 4096
+    g0 = torch.Generator(device="cuda:0"); g0.manual_seed(5)
+    x1 = torch.randn((nb, spec.nC), dtype=torch.float64, device="cuda:0", generator=g0)
+    x2 = torch.randn((nb, spec.nC), dtype=torch.float64, device="cuda:0", generator=g0)
+    e1, e2 = p.eval(x1, 2), p.eval(x2, 2)
+    e3 = p.eval((2.0 * x1 - 0.5 * x2).contiguous(), 2)
+    gl = 2.0 * e1["g"] - 0.5 * e2["g"]
+    assert (e3["g"] - gl).abs().max().item() <= 1e-12 * gl.abs().max().item()
+    e4 = p.eval((3.0 * x1).contiguous(), 2)
+    assert torch.allclose(e4["f"], 9.0 * e1["f"], rtol=1e-13, atol=0.0)
+    euler = 0.5 * (e1["g"] * x1).sum(dim=1)
+    assert torch.allclose(e1["f"], euler, rtol=1e-11, atol=0.0)
+    # modes: values only / gradient only give the same numbers as both
+    f0 = p.eval(x1, 0)["f"]; g1 = p.eval(x1, 1)["g"]
+    assert torch.equal(f0, e1["f"]) and torch.equal(g1, e1["g"])
