@@ -35,6 +35,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
                "-I", os.path.join(HERE, "..", "include"), "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
+        cmd += os.environ.get("NTG_AMD_CXXFLAGS", "").split()   # e.g. -DNTG_HIST_G=8 for tuning experiments
         log = open(obj + ".log", "w")
         procs.append((src, obj, subprocess.Popen(cmd, stdout=log, stderr=subprocess.STDOUT), log))
     failed = []
