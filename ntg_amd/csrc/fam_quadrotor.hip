@@ -7,6 +7,8 @@ hipError_t ntg_launch_eval_quadrotor(const NtgDims &D, const NtgTables &T, const
 {
 	if (a.nt == 256 && ntg_all_d(D, 5) && D.nout == 4 && ntg_uniform_order(D, 256, 4) == 8)
 		return launch_eval_one<NTG_FAM_QUADROTOR, 4, 8, 256, 4>(D, T, L, a);
+	if (a.nt == 512 && ntg_all_d(D, 5) && D.nout == 4 && ntg_uniform_order(D, 512, 4) == 8)
+		return launch_eval_one<NTG_FAM_QUADROTOR, 4, 8, 512, 4>(D, T, L, a);   // one workgroup per CU: more waves per workgroup
 	return launch_eval_generic<NTG_FAM_QUADROTOR>(D, T, L, a);
 }
 

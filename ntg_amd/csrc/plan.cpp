@@ -652,8 +652,9 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	if (batch <= 0) return 0;
 	HIPCHK(hipSetDevice(p->device));
 	const NtgDims &D = p->D;
-	const int nt = auto_threads(D);
+	int nt = auto_threads(D);
 	SmemLayout L = ntg_make_layout(D, nt, 0, 1);
+	if (nt == 256 && L.total > 80 * 1024) { nt = 512; L = ntg_make_layout(D, nt, 0, 1); }   // one workgroup per CU anyway: give it more waves
 	if (L.total > 160 * 1024) return fail(NTG_E_UNSUPPORTED, "problem tables exceed 160 KiB of LDS");
 	hipStream_t st = (hipStream_t)stream;
 	if (d_cjac && D.ncnln) HIPCHK(hipMemsetAsync(d_cjac, 0, (size_t)batch * D.ncnln * D.nC * 8, st)); // GcJac starts zeroed (ntg.c:217)
