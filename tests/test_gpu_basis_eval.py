@@ -165,3 +165,24 @@ def test_full_size_eval_properties_config_M():
     # modes: values only / gradient only give the same numbers as both
     f0 = p.eval(x1, 0)["f"]; g1 = p.eval(x1, 1)["g"]
     assert torch.equal(f0, e1["f"]) and torch.equal(g1, e1["g"])
+
+
+@pytest.mark.parametrize("per_interval,ncars", [(3, 1), (7, 1), (3, 3), (7, 3), (4, 3)])
+def test_eval_other_column_widths_vs_oracle(per_interval, ncars):
+    """The column form has compile-time widths 8, 12 and 16 (breakpoints per knot interval 3 / 5 / 7 for order 6); other
+    widths take the general kernel.  All against the oracle."""
+    spec = cf._kincar_spec(ncars, 6, 3, 20, per_interval * 20 + 1, 5.0, f"kincar-{2 * ncars}out-{per_interval}bp")
+    p = api.Plan(spec, 0)
+    rng = np.random.default_rng(31)
+    x = rng.normal(size=(7, spec.nC)) * 3
+    ev = p.eval(dev(x), 2)
+    ref = orc.eval_batch(spec, x, 2)
+    assert rel(ev["f"].cpu().numpy(), ref["f"]) <= 1e-12
+    assert rel(ev["g"].cpu().numpy(), ref["g"]) <= 1e-12
+    # and a solve on the same grid (the solve kernel's column-form gather for this width)
+    lo, up = cf.kincar_random_bounds(ncars, 4)
+    xs = torch.ones((4, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), xs, api.default_opts(hessian=1))
+    refs = orc.solve_batch(spec, lo, up, np.ones((4, spec.nC)), orc.default_opts(hessian=1), nthreads=4)
+    assert (out["inform"] == 0).all()
+    assert np.abs(out["objective"].cpu().numpy() - refs["objective"]).max() <= 1e-9 * np.abs(refs["objective"]).max()
