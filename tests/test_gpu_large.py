@@ -125,3 +125,26 @@ def test_short_quasi_newton_memory_matches_oracle():
     assert (np.abs(obj - ref["objective"]) <= 2e-5 * np.abs(ref["objective"])).all()
     # and the restart really happened: more majors than the memory holds
     assert out["iters"].min().item() > 16
+
+
+@pytest.mark.parametrize("ncars,l,expect_big", [(2, 20, False), (8, 60, True)])
+def test_generic_instances_kincar(ncars, l, expect_big):
+    """Shapes without a tuned instance take the generic kernels (run-time nout / order): 4 outputs, and 16 outputs x 60
+    intervals (nC = 2928), whose vectors no longer fit in LDS -- the generic BIG instance."""
+    import ctypes as C
+    spec = cf._kincar_spec(ncars, 6, 3, l, 5 * l + 1, 5.0, f"kincar-{2 * ncars}out-l{l}")
+    p = api.Plan(spec, 0)
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    api.lib().ntg_debug_layout(p.h, C.byref(api.default_opts(hessian=1)), C.byref(a), C.byref(b), C.byref(c))
+    assert (a.value < 0) == expect_big
+    nb = 3
+    lo, up = cf.kincar_random_bounds(ncars, nb)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=1), want_lambda=True)
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(hessian=1), nthreads=nb)
+    assert (out["inform"] == 0).all() and (ref["inform"] == 0).all()
+    assert np.abs(out["objective"].cpu().numpy() - ref["objective"]).max() <= 1e-9 * np.abs(ref["objective"]).max()
+    assert np.abs(x.cpu().numpy() - ref["x"]).max() <= 1e-6 * np.abs(ref["x"]).max()
+    xr = np.random.default_rng(2).normal(size=(nb, spec.nC))
+    ev = p.eval(dev(xr), 2); er = orc.eval_batch(spec, xr, 2)
+    assert rel(ev["f"].cpu().numpy(), er["f"]) <= 1e-12 and rel(ev["g"].cpu().numpy(), er["g"]) <= 1e-12
