@@ -120,3 +120,31 @@ def test_every_linear_row_a_range(hessian):
         Ax = A @ xg[i]
         assert (Ax >= lo[i] - 1e-6).all() and (Ax <= up[i] + 1e-6).all()
     assert (np.diff(obj) < 0).all()          # wider ranges, lower optimal cost
+
+
+def test_linear_trajectory_inequality_rows():
+    """A linear TRAJECTORY row declared as a range (lateral position y(t) <= a ceiling at every breakpoint): 101 rows of
+    the augmented Lagrangian whose Jacobian rows are rows of A."""
+    spec = cf.config_B()
+    ltc = np.zeros((1, spec.nz)); ltc[0, 3] = 1.0            # y
+    spec.ltc = ltc
+    spec.lin_ineq = [0] * 6 + [1] + [0] * 6                   # lic (6), ltc (1), lfc (6)
+    p = api.Plan(spec, 0)
+    nb = 6
+    lo0, up0 = cf.kincar_random_bounds(1, nb)
+    ymax = np.maximum(lo0[:, 3], lo0[:, 9]) + 0.05           # a ceiling just above both end points
+    lo = np.concatenate([lo0[:, :6], np.full((nb, 1), -cf.INF_BOUND), lo0[:, 6:]], axis=1)
+    up = np.concatenate([up0[:, :6], ymax[:, None], up0[:, 6:]], axis=1)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=1), want_lambda=True)
+    inf = out["inform"].cpu().numpy(); obj = out["objective"].cpu().numpy(); xg = x.cpu().numpy()
+    A = p.tables()["A"]; P = spec.nbps
+    nact = 0
+    for i in range(nb):
+        ref = orc.solve_one(spec, lo[i], up[i], np.ones(spec.nC), orc.default_opts(hessian=1))
+        assert inf[i] in (0, 1) and ref["inform"] in (0, 1)
+        assert abs(obj[i] - ref["objective"]) <= 1e-6 * max(1.0, abs(ref["objective"]))
+        y = (A @ xg[i])[6:6 + P]
+        assert y.max() <= ymax[i] + 1e-6
+        nact += int(y.max() >= ymax[i] - 1e-6)
+    assert nact >= 2
