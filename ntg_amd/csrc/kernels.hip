@@ -371,6 +371,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
 	L.rho = L.c2 = p;   // rho_i, c2_i travel with the pair in HBM
 	L.oinfo = p; p = align16(p + D.nout * 10 * 4);
 	L.tavrow = p; p = align16(p + D.nz * 4);
+	L.tcomp = p; p = align16(p + D.nz * 4);
 	L.ls = p; p = align16(p + 2 * (int)sizeof(LineSearch));   // double buffered (see sqp_kernel)
 	L.tI = p; p = align16(p + (D.nI + 1) * 8);   // multiplier estimates of the linear inequality rows
 	L.q_idx = L.q_col = L.q_val = p;

@@ -84,7 +84,7 @@ __host__ __device__ inline int ntg_dfz_tail(const NtgDims &D) { int w = 16; for 
 // byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
 struct SmemLayout {
 	int rowv, colp, chrow, chcol, off, bps, wts, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
-	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, q_idx, q_col, q_val, ls, tI, total;
+	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, tcomp, q_idx, q_col, q_val, ls, tI, total;
 };
 
 struct SolveParams {

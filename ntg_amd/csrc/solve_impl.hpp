@@ -171,7 +171,7 @@ struct Smem {
 	double *x, *dfz, *fvals, *red, *dfi, *dff, *vecs, *lam, *rho, *c2;
 	// sparse linear-constraint operator: LDS copies when they fit, HBM/L2 otherwise
 	const int *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col; const double *csr_val, *csc_val, *sinv_val;
-	int *oinfo, *tavrow;   // per-output scalars and flag->row map in LDS (no per-lane kernarg gathers)
+	int *oinfo, *tavrow, *tcomp;   // per-output scalars, flag->row map, flag->compact trajectory-constraint index, in LDS
 	short *q_idx; int *q_col; double *q_val;
 	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T)
 	{
@@ -192,7 +192,7 @@ struct Smem {
 			csc_ptr = T.csc_ptr; csc_row = T.csc_row; csc_val = T.csc_val;
 			sinv_ptr = T.sinv_ptr; sinv_col = T.sinv_col; sinv_val = T.sinv_val;
 		}
-		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow);
+		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow); tcomp = (int *)(base + L.tcomp);
 		q_idx = (short *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
 	}
 };
@@ -229,7 +229,10 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 		q[0] = D.order[o]; q[1] = D.mult[o]; q[2] = D.n0_blk[o]; q[3] = D.d[o]; q[4] = D.iC[o]; q[5] = D.iz[o];
 		q[6] = D.cls[o] * NTG_MAX_ORDER; q[7] = D.cls[o] * D.P; q[8] = D.cls_W[D.cls[o]]; q[9] = D.ncoef[o];
 	}
-	for (int v = tid; v < D.nz; v += NT) S.tavrow[v] = D.tav_row[v];
+	for (int v = tid; v < D.nz; v += NT) {
+		S.tavrow[v] = D.tav_row[v];
+		S.tcomp[v] = ((D.tcon_mask >> v) & 1ull) ? __popcll(D.tcon_mask & ((1ull << v) - 1ull)) : -1;   // see eval_constraints
+	}
 	for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;   // the row's extra element stays 0
 	for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[(D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + i] = 0.0;   // overrun of the last columns' reads (times 0)
 	if (D.q_use) {
@@ -814,11 +817,8 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 					const int iz = NOUT > 0 ? DM * o : D.iz[o];
 					double a = 0.0;
 					for (int r = 0; r < d; r++) {
-						const int v = iz + r, chr = S.chrow[cc * NTG_MAX_ORDER + r];
-						if (((D.tcon_mask >> v) & 1ull) && chr >= 0) {
-							const int comp = __popcll(D.tcon_mask & ((1ull << v) - 1ull));
-							a += scratch[(jc * ncomp + comp) * P + bp] * S.rowv[chr + q * P + bp];
-						}
+						const int comp = S.tcomp[iz + r], chr = S.chrow[cc * NTG_MAX_ORDER + r];
+						if (comp >= 0 && chr >= 0) a += scratch[(jc * ncomp + comp) * P + bp] * S.rowv[chr + q * P + bp];
 					}
 					dst[f] = a;
 					e += 64;
