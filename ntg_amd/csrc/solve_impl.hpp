@@ -773,12 +773,17 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 	const bool coalesced = Fam::NNLTC > 0 && D.nnltc && jband && mode != 0 && ncomp > 0 && ncomp * P <= scratch_cap;
 	if (Fam::NNLTC > 0 && D.nnltc) {
 		const int chunk = coalesced ? max(1, min(D.nnltc, scratch_cap / (ncomp * P))) : D.nnltc;
+		// with one breakpoint per lane (P <= NT) the flag, the values and the functor's tape are computed once and kept in
+		// registers across the chunks; otherwise they are recomputed per chunk
+		const bool keep = P <= NT;
+		double z[NZ], c[NTc], tape[Fam::TAPE];
 		for (int j0 = 0; j0 < D.nnltc; j0 += chunk) {
 			const int jn = min(chunk, D.nnltc - j0);
 			for (int i = tid; i < P; i += NT) {
-				double z[NZ], c[NTc], tape[Fam::TAPE];
-				compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
-				Fam::template nltc_val<NZ>(nout, i, z, c, tape);
+				if (!keep || j0 == 0) {
+					compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
+					Fam::template nltc_val<NZ>(nout, i, z, c, tape);
+				}
 				for (int j = j0; j < j0 + jn; j++) {
 					const int row = D.nnlic + j * P + i;              // constraints.c:139,153
 					if (c_out && mode != 1) c_out[row] = c[j];
