@@ -249,6 +249,22 @@ def main():
                         "inform_counts": {str(k): int((infL == k).sum()) for k in np.unique(infL)}, "qn_memory": qnm or 256,
                         "iters_mean": float(ooL["iters"].float().mean().item()), "nfev_mean": float(ooL["nfev"].float().mean().item())}
             del wL, planL
+        # ---- funobj + funcon with banded Jacobian rows (the constraint-Jacobian assembly), configs D and E ----
+        for key, mk, nbJ in (("jacobian_assembly_D", cf.config_D, 4096), ("jacobian_assembly_E", cf.config_E, 2048)):
+            specJ = mk(); planJ = api.Plan(specJ, local)
+            xJ = torch.randn((nbJ, specJ.nC), dtype=torch.float64, device=dev)
+            oJ = planJ.eval(xJ, 2)
+            planJ.eval(xJ, 2, out=oJ); torch.cuda.synchronize()
+            j0, j1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            j0.record()
+            for _ in range(5):
+                planJ.eval(xJ, 2, out=oJ)
+            j1.record(); torch.cuda.synchronize()
+            msJ = j0.elapsed_time(j1) / 5
+            bJ = nbJ * specJ.eval_bytes()
+            res[key] = {"kernel": "eval_kernel", "batch": nbJ, "ms": msJ, "achieved": bJ / (msJ * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": bJ / (msJ * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_eval": specJ.eval_bytes(), "workload": specJ.name}
+            del oJ, planJ, xJ
         # ---- standalone evaluation kernel streamed over a large batch ----
         nb = 1 << 18
         xe = torch.randn((nb, spec.nC), dtype=torch.float64, device=dev)

@@ -171,20 +171,25 @@ class Plan:
         import torch
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-    def eval(self, x, mode: int = 2, want_dense_jac: bool = False):
+    def eval(self, x, mode: int = 2, want_dense_jac: bool = False, out=None):
+        """funobj + funcon for a batch.  `out` (a dict returned by an earlier call with the same shapes) reuses its buffers."""
         import torch
         sp = self.spec
         assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
         batch = x.shape[0]
         dev = x.device
-        f = torch.empty(batch, dtype=torch.float64, device=dev)
-        g = torch.empty((batch, sp.nC), dtype=torch.float64, device=dev)
-        c = jb = cj = None
-        if sp.ncnln:
-            c = torch.zeros((batch, sp.ncnln), dtype=torch.float64, device=dev)
-            jb = torch.zeros((batch, sp.ncnln, sp.sumk), dtype=torch.float64, device=dev)
-            if want_dense_jac:
-                cj = torch.empty((batch, sp.nC, sp.ncnln), dtype=torch.float64, device=dev)
+        if out is not None:
+            f, g, c, jb = out["f"], out["g"], out.get("c"), out.get("jband")
+            cj = None
+        else:
+            f = torch.empty(batch, dtype=torch.float64, device=dev)
+            g = torch.empty((batch, sp.nC), dtype=torch.float64, device=dev)
+            c = jb = cj = None
+            if sp.ncnln:
+                c = torch.zeros((batch, sp.ncnln), dtype=torch.float64, device=dev)
+                jb = torch.zeros((batch, sp.ncnln, sp.sumk), dtype=torch.float64, device=dev)
+                if want_dense_jac:
+                    cj = torch.empty((batch, sp.nC, sp.ncnln), dtype=torch.float64, device=dev)
         _check(lib().ntg_batch_eval(self.h, batch, _ptr(x), mode, _ptr(f), _ptr(g), _ptr(c), _ptr(jb), _ptr(cj), self._stream()))
         out = dict(f=f, g=g)
         if sp.ncnln:
