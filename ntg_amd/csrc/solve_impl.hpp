@@ -807,27 +807,36 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 			}
 			if (coalesced) {
 				lds_sync();
-				// every wave walks its own contiguous share of the block, 64 consecutive words per store instruction;
-				// (constraint, breakpoint, entry) advance by carries instead of divisions
-				constexpr int NW = NT / 64;
-				const int sumk = D.sumk, per = P * sumk, total = jn * per, seg = (total + NW - 1) / NW;
-				const int wv = tid >> 6, f0 = wv * seg + (tid & 63), fend = min(total, (wv + 1) * seg);
+				// a wave takes whole rows (stride NW); its lanes are the entries of the row, 64 at a time: a store
+				// instruction writes 64 consecutive words, and what an entry needs to know about itself -- output, block
+				// column, which derivative channels contribute -- is decoded once per lane, outside the loop over rows
+				constexpr int NW = NT / 64, RMAX = NOUT > 0 ? DM : NTG_MAX_ORDER;
+				const int sumk = D.sumk, nrows = jn * P, wv = tid >> 6, ln = tid & 63;
 				double *dst = jband + (size_t)(D.nnlic + j0 * P) * sumk;
-				int jc = f0 / per, rem = f0 - jc * per, bp = rem / sumk, e = rem - bp * sumk;
-				for (int f = f0; f < fend; f += 64) {
+				for (int e = ln; e < sumk; e += 64) {
 					int o = 0;
 					if (NOUT > 0 && K > 0) o = e / K;                 // one order for every output
 					else while (o + 1 < nout && D.koff[o + 1] <= e) o++;
 					const int q = e - (NOUT > 0 && K > 0 ? o * K : D.koff[o]), cc = D.cls[o], d = NOUT > 0 ? DM : D.d[o];
 					const int iz = NOUT > 0 ? DM * o : D.iz[o];
-					double a = 0.0;
-					for (int r = 0; r < d; r++) {
-						const int comp = S.tcomp[iz + r], chr = S.chrow[cc * NTG_MAX_ORDER + r];
-						if (comp >= 0 && chr >= 0) a += scratch[(jc * ncomp + comp) * P + bp] * S.rowv[chr + q * P + bp];
+					int cof[RMAX], rof[RMAX];                          // scratch / rowv offsets of the contributing channels, -1: none
+#pragma unroll
+					for (int r = 0; r < RMAX; r++) {
+						const int comp = r < d ? S.tcomp[iz + r] : -1, chr = r < d ? S.chrow[cc * NTG_MAX_ORDER + r] : -1;
+						const bool on = comp >= 0 && chr >= 0;
+						cof[r] = on ? comp * P : -1; rof[r] = on ? chr + q * P : 0;
 					}
-					dst[f] = a;
-					e += 64;
-					while (e >= sumk) { e -= sumk; if (++bp == P) { bp = 0; jc++; } }
+					int jc = 0, bp = wv;
+					while (bp >= P) { bp -= P; jc++; }
+					for (int row = wv; row < nrows; row += NW) {
+						double a = 0.0;
+#pragma unroll
+						for (int r = 0; r < RMAX; r++)
+							if (cof[r] >= 0) a += scratch[jc * ncomp * P + cof[r] + bp] * S.rowv[rof[r] + bp];
+						dst[(size_t)row * sumk + e] = a;
+						bp += NW;
+						while (bp >= P) { bp -= P; jc++; }
+					}
 				}
 				lds_sync();
 			}
