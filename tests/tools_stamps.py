@@ -16,7 +16,7 @@ else:
 dev = torch.device("cuda:0")
 plan = api.Plan(spec, 0)
 x = torch.ones((B, spec.nC), dtype=torch.float64, device=dev)
-for mode in ((dict(hessian=1),) if cfg in "DE" else (dict(itlim=50, fixed_iters=1, hessian=0), dict(hessian=1, itlim=50))):
+for mode in ((dict(hessian=1, qn_memory=int(os.environ.get("QNM", "0"))),) if cfg in "DE" else (dict(itlim=50, fixed_iters=1, hessian=0), dict(hessian=1, itlim=50))):
     x.fill_(1.0)
     out = plan.solve(torch.tensor(lo, device=dev), torch.tensor(up, device=dev), x, api.default_opts(**mode), want_lambda=True)
     torch.cuda.synchronize()
