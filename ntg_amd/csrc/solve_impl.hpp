@@ -1078,11 +1078,10 @@ __device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, i
 // t += (sum of the stored rank-2 BFGS terms) v.  Pairs are streamed from HBM/L2 once, G at a
 // time: 2G partial dots per lane, ONE workgroup reduction, then the axpys from the registers
 // that still hold the pair elements.
-template <int NT>
+template <int NT, int EPT = 3, int G = NTG_HIST_G>
 __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, const double *hist, int npairs,
                               const double *v, double *t)
 {
-	constexpr int G = NTG_HIST_G, EPT = 3;
 	const int n = D.nC, tid = threadIdx.x;
 	if (n <= EPT * NT) {
 		double vv[EPT], tt[EPT];
@@ -1363,7 +1362,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					NTG_STAMP(5);
 					apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgpt, st, sxt, S.oinfo);
 					NTG_STAMP(4);
-					apply_history<NT>(D, S, hist, npairs, sgpt, st);
+					// register-resident pairs: 3 coefficients per lane, 6 pairs per round; the 5-coefficient instances (config E)
+					// take 3 pairs per round
+					apply_history<NT, (EPT > 4 ? 5 : 3), (EPT > 4 ? 3 : NTG_HIST_G)>(D, S, hist, npairs, sgpt, st);
 					NTG_STAMP(3);
 					double r6[6] = {0, 0, 0, 0, 0, 0};
 					for_vec<NT>(n, [&](int c) {
