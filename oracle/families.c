@@ -154,6 +154,47 @@ static void manip_nltcf(int *mode, int *nstate, int *i, double *c, double **dc, 
 	}
 }
 
+/* ---- second derivatives of the constraint callbacks above: Hz (nz x nz row-major) += sum_j t_j d2c_j ---- */
+#define HZ(a, b) Hz[(a) * nz + (b)]
+static void tf_nlic_hess(int *i, const double *t, double *Hz, double **zp)
+{ int nz = 3 * fam_nout; (void)i; (void)zp; HZ(0, 0) += 2.0 * t[0]; }
+static void tf_nltc_hess(int *i, const double *t, double *Hz, double **zp)
+{
+	int L = fam_nout - 1, nz = 3 * fam_nout; (void)i;
+	HZ(0, 0) += 2.0 * t[0]; HZ(3 * L, 3 * L) += 2.0 * t[0];
+	HZ(1, 3 * L + 2) += t[1]; HZ(3 * L + 2, 1) += t[1]; HZ(0, 0) += t[1] * cos(zp[0][0]);
+}
+static void tf_nlfc_hess(int *i, const double *t, double *Hz, double **zp)
+{
+	int L = fam_nout - 1, nz = 3 * fam_nout; (void)i; (void)zp;
+	HZ(0, 2) += t[0]; HZ(2, 0) += t[0]; HZ(3 * L + 1, 3 * L + 1) += 2.0 * t[0];
+}
+static void obs_nltc_hess(int *i, const double *t, double *Hz, double **zp)
+{ int nz = 6; (void)i; (void)zp; HZ(0, 0) += 2.0 * t[0]; HZ(3, 3) += 2.0 * t[0]; }
+static void quad_nltc_hess(int *i, const double *t, double *Hz, double **zp)
+{
+	int nz = 20; (void)i; (void)zp;
+	HZ(2, 2) += 2.0 * t[0]; HZ(7, 7) += 2.0 * t[0]; HZ(12, 12) += 2.0 * t[0];
+	HZ(1, 1) += 2.0 * t[1]; HZ(6, 6) += 2.0 * t[1]; HZ(11, 11) += 2.0 * t[1];
+}
+static void manip_nltc_hess(int *i, const double *t, double *Hz, double **zp)
+{
+	int j, narms = fam_nout / 3, nz = 3 * fam_nout; (void)i;
+	for (j = 0; j < narms; j++) {
+		const double qa = zp[3 * j][0], qb = zp[3 * j + 1][0], qc = zp[3 * j + 2][0];
+		const double s1 = sin(qa), s2 = sin(qa + qb), s3 = sin(qa + qb + qc);
+		const int a = 9 * j, b = 9 * j + 3, c = 9 * j + 6;
+		/* c_j = sin a1 + sin a2 + sin a3, a1 = qa, a2 = qa+qb, a3 = qa+qb+qc:  d2c = -(s1 e1e1' + s2 e2e2' + s3 e3e3') */
+		HZ(a, a) -= t[j] * (s1 + s2 + s3); HZ(a, b) -= t[j] * (s2 + s3); HZ(a, c) -= t[j] * s3;
+		HZ(b, a) -= t[j] * (s2 + s3); HZ(b, b) -= t[j] * (s2 + s3); HZ(b, c) -= t[j] * s3;
+		HZ(c, a) -= t[j] * s3; HZ(c, b) -= t[j] * s3; HZ(c, c) -= t[j] * s3;
+	}
+}
+#undef HZ
+orc_nlhess_t orc_family_nlic_hess(int fam) { return fam == 2 ? tf_nlic_hess : NULL; }
+orc_nlhess_t orc_family_nltc_hess(int fam) { return fam == 2 ? tf_nltc_hess : fam == 3 ? obs_nltc_hess : fam == 4 ? quad_nltc_hess : fam == 5 ? manip_nltc_hess : NULL; }
+orc_nlhess_t orc_family_nlfc_hess(int fam) { return fam == 2 ? tf_nlfc_hess : NULL; }
+
 orc_ucf_t orc_family_ucf(int fam) { return (fam == 0 || fam == 3 || fam == 5) ? kincar_ucf : fam == 1 ? vdp_ucf : fam == 2 ? tf_ucf : fam == 4 ? quad_ucf : NULL; }
 orc_icf_t orc_family_icf(int fam) { return fam == 2 ? tf_icf : NULL; }
 orc_icf_t orc_family_fcf(int fam) { return fam == 2 ? tf_fcf : NULL; }
@@ -184,6 +225,7 @@ static orc_problem *make_from_spec(const orc_batch_spec *s, const double *lowerb
 		s->nicf, orc_family_icf(s->family), s->nucf, orc_family_ucf(s->family), s->nfcf, orc_family_fcf(s->family),
 		s->nicostav, (orc_AV *)s->icostav, s->ntcostav, (orc_AV *)s->tcostav, s->nfcostav, (orc_AV *)s->fcostav);
 	free(lic); free(ltc); free(lfc);
+	p->nlic_hess = orc_family_nlic_hess(s->family); p->nltc_hess = orc_family_nltc_hess(s->family); p->nlfc_hess = orc_family_nlfc_hess(s->family);
 	return p;
 }
 static int spec_nb(const orc_batch_spec *s) { return s->nlic + s->nltc + s->nlfc + s->nnlic + s->nnltc + s->nnlfc; }

@@ -59,6 +59,9 @@ typedef void (*orc_icf_t)(int *, int *, double *, double *, double **);
 typedef void (*orc_ucf_t)(int *, int *, int *, double *, double *, double **);
 typedef void (*orc_nlic_t)(int *, int *, double *, double **, double **);
 typedef void (*orc_nltc_t)(int *, int *, int *, double *, double **, double **);
+/* second derivatives of the nonlinear constraints (no reference counterpart: NPSOL never asks for them; used by the
+ * structured Newton mode of oracle/sqp.c only): Hz (nz x nz, row-major) += sum_j t[j] d2 c_j / dz dz at one breakpoint */
+typedef void (*orc_nlhess_t)(int *i, const double *t, double *Hz, double **zp);
 
 /* one NTG problem = everything ntg() stashes in its globals (ntg.c:17-41,119-152) */
 typedef struct {
@@ -74,6 +77,7 @@ typedef struct {
 	double *A;    /* nclin x nC column-major, ld = max(nclin,1)  (ntg.c:162-206) */
 	double *cJac; /* ncnln x nC column-major, persists (ntg.c:210-220) */
 	double *bl, *bu; /* nC+nclin+ncnln (ntg.c:222-229) */
+	orc_nlhess_t nlic_hess, nltc_hess, nlfc_hess; /* optional (NULL: Gauss-Newton terms only), see orc_nlhess_t */
 } orc_problem;
 
 orc_problem *orc_problem_make(
@@ -106,7 +110,9 @@ typedef struct {
 	double steplimit;    /* NPSOL "step limit", default 2.0 */
 	double ls_mu, ls_eta;/* sufficient decrease / curvature (line search tolerance), 1e-4 / 0.9 */
 	int ls_maxfev;       /* 20 */
-	int hessian;         /* 0: identity cold start (NPSOL), 1: collocation preconditioner */
+	int hessian;         /* 0: identity cold start (NPSOL), 1: collocation preconditioner, 2: structured Newton step for
+	                      * problems with nonlinear rows (banded H0 + mu J'J + curvature, refreshed every major);
+	                      * 2 behaves like 1 where it does not apply */
 	int fixed_iters;     /* 1: run exactly itlim majors, no convergence exit */
 	int verbose;
 	int qn_memory;       /* BFGS updates kept before W restarts from W0 (the device's pair memory); <= 0: 256 */
@@ -136,6 +142,9 @@ orc_icf_t orc_family_fcf(int fam);
 orc_nlic_t orc_family_nlicf(int fam);
 orc_nltc_t orc_family_nltcf(int fam);
 orc_nlic_t orc_family_nlfcf(int fam);
+orc_nlhess_t orc_family_nlic_hess(int fam);
+orc_nlhess_t orc_family_nltc_hess(int fam);
+orc_nlhess_t orc_family_nlfc_hess(int fam);
 void orc_family_set_nout(int nout); /* thread-local nout for generic families */
 
 /* batched CPU driver used by tests and bench.py's cpu_baseline leg */

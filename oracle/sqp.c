@@ -294,6 +294,265 @@ static int build_colloc_W0(const orc_problem *p, const double *AE, int m, double
 	return rc;
 }
 
+
+#ifndef NWT_SIGMA_SCALE
+#define NWT_SIGMA_SCALE 1e4   /* sigma = this x max diag(cost model) / max diag(A_E'A_E): large enough that K_s is positive
+                               * definite whenever K is on null(A_E) in practice; the step does not depend on it */
+#endif
+#ifndef NWT_KAPPA
+#define NWT_KAPPA 0.25
+#endif
+#ifndef NWT_BOTH
+#define NWT_BOTH 0
+#endif
+#ifndef NWT_MU0
+#define NWT_MU0 10.0      /* first penalty parameter of the structured Newton mode */
+#endif
+#ifndef NWT_MUFAC
+#define NWT_MUFAC 10.0    /* its growth factor */
+#endif
+
+/* ---------------- structured Newton mode (opts.hessian = 2) ----------------
+ * For problems with nonlinear rows the inner iteration takes W = Z (Z' K Z)^-1 Z' with
+ *   K = sum_i M_i' B_i M_i,   B_i = 2 w_i diag(cost active variables)                (cost model, constant)
+ *                                 + mu sum_{j active at i} a_j a_j'                  (Gauss-Newton term of the penalty)
+ *                                 + sum_j t_j d2c_j/dz2                              (constraint curvature, when K stays PD)
+ * refreshed at every major iteration (a semismooth Newton step on the augmented Lagrangian).  M_i = the collocation
+ * rows of breakpoint i, a_j = dc_j/dz, t = the multiplier estimates of the last evaluation.  With one spline spec for
+ * every output and the coefficients interleaved by output (p = cl nout + o) K is banded, half bandwidth k nout - 1.
+ * The equality rows A_E are handled exactly: K_s = K + sigma A_E'A_E = L L' (band Cholesky), border W = L^-1 A_E',
+ * S = W'W, and  W_K v = L^-T (I - W S^-1 W') L^-1 v  -- the same operator for every sigma > 0. */
+typedef struct {
+	orc_problem *p;
+	int n, nout, k, nco, hb, ld, m, P, nz;
+	double sigma;
+	double *K0, *Kb;   /* band lower, column j at [j*ld .. j*ld+hb]: entry (j+s, j) at [j*ld+s]; interleaved order */
+	double *AEp;       /* [m][n] equality rows, interleaved order */
+	double *Wt;        /* [m][n] rows of (L^-1 A_E')' */
+	double *S;         /* chol(W'W), m x m */
+	double *wk, *rm, *Bz, *dcbuf, **dc, **zp;
+	int nfact, nfail, curv;
+} nwt_t;
+
+static int nwt_ip(const nwt_t *w, int c) { const int o = c / w->nco, cl = c - o * w->nco; return cl * w->nout + o; }
+
+/* K (band) += M_i' B M_i for the symmetric z-space matrix B (nz x nz, zeros skipped) */
+static void nwt_add_bp(nwt_t *w, double *Kb, int bp, const double *B)
+{
+	const orc_colloc *cc = w->p->cc;
+	int nz = w->nz, v, v2, o, r, o2, r2, q, q2;
+	for (o = 0; o < w->nout; o++) for (r = 0; r < cc->maxderiv[o]; r++) {
+		v = cc->iz[o] + r;
+		for (o2 = 0; o2 < w->nout; o2++) for (r2 = 0; r2 < cc->maxderiv[o2]; r2++) {
+			const double b = B[v * nz + cc->iz[o2] + r2];
+			if (b == 0.0) continue;
+			v2 = cc->iz[o2] + r2; (void)v2;
+			for (q = 0; q < w->k; q++) {
+				const int pr = (cc->off[o][bp] + q) * w->nout + o;
+				const double bq = b * cc->blk[o][((size_t)bp * w->k + q) * cc->maxderiv[o] + r];
+				for (q2 = 0; q2 < w->k; q2++) {
+					const int pc = (cc->off[o2][bp] + q2) * w->nout + o2;
+					if (pr >= pc) Kb[(size_t)pc * w->ld + (pr - pc)] += bq * cc->blk[o2][((size_t)bp * w->k + q2) * cc->maxderiv[o2] + r2];
+				}
+			}
+		}
+	}
+}
+
+static int nwt_applicable(const orc_problem *p, int nI)
+{
+	const orc_colloc *cc = p->cc;
+	int o;
+	if (p->ncnln <= 0 || nI > 0) return 0;
+	for (o = 1; o < cc->nout; o++) {
+		if (cc->order[o] != cc->order[0] || cc->mult[o] != cc->mult[0] || cc->ninterv[o] != cc->ninterv[0] || cc->maxderiv[o] != cc->maxderiv[0]) return 0;
+		if (memcmp(cc->off[o], cc->off[0], cc->nbps * sizeof(int))) return 0;
+		if (memcmp(cc->blk[o], cc->blk[0], (size_t)cc->nbps * cc->order[0] * cc->maxderiv[0] * sizeof(double))) return 0;
+	}
+	return 1;
+}
+
+static nwt_t *nwt_make(orc_problem *p, const double *AE, int m)
+{
+	const orc_colloc *cc = p->cc;
+	nwt_t *w = calloc(1, sizeof(*w));
+	int i, j, c, a, P = cc->nbps;
+	double dmaxK = 0.0, dmaxA = 0.0;
+	w->p = p; w->n = cc->nC; w->nout = cc->nout; w->k = cc->order[0]; w->nco = cc->ncoef[0]; w->m = m; w->P = P; w->nz = cc->nz;
+	w->hb = w->k * w->nout - 1; w->ld = w->hb + 1;
+	w->K0 = calloc((size_t)w->n * w->ld, sizeof(double)); w->Kb = malloc((size_t)w->n * w->ld * sizeof(double));
+	w->AEp = calloc((size_t)(m + 1) * w->n, sizeof(double)); w->Wt = malloc((size_t)(m + 1) * w->n * sizeof(double));
+	w->S = malloc((size_t)(m + 1) * (m + 1) * sizeof(double));
+	w->wk = malloc(w->n * sizeof(double)); w->rm = malloc((m + 1) * sizeof(double));
+	w->Bz = malloc((size_t)w->nz * w->nz * sizeof(double));
+	{
+		int ncmax = p->nnlic > p->nnltc ? p->nnlic : p->nnltc; if (p->nnlfc > ncmax) ncmax = p->nnlfc; if (ncmax < 1) ncmax = 1;
+		w->dcbuf = malloc((size_t)ncmax * w->nz * sizeof(double)); w->dc = malloc(ncmax * sizeof(double *));
+		for (i = 0; i < ncmax; i++) w->dc[i] = w->dcbuf + (size_t)i * w->nz;
+	}
+	w->zp = malloc(w->nout * sizeof(double *));
+	/* cost model: 2 w_i on the trajectory-cost active variables, 2 on the initial / final ones */
+	for (i = 0; i < P; i++) {
+		double wt = 0.0;
+		if (i > 0) wt += (cc->bps[i] - cc->bps[i - 1]) / 2;
+		if (i < P - 1) wt += (cc->bps[i + 1] - cc->bps[i]) / 2;
+		memset(w->Bz, 0, (size_t)w->nz * w->nz * sizeof(double));
+		if (p->nucf) for (a = 0; a < p->ntcostav; a++) { const int v = cc->iz[p->tcostav[a].output] + p->tcostav[a].deriv; w->Bz[v * w->nz + v] += 2.0 * wt; }
+		if (i == 0 && p->nicf) for (a = 0; a < p->nicostav; a++) { const int v = cc->iz[p->icostav[a].output] + p->icostav[a].deriv; w->Bz[v * w->nz + v] += 2.0; }
+		if (i == P - 1 && p->nfcf) for (a = 0; a < p->nfcostav; a++) { const int v = cc->iz[p->fcostav[a].output] + p->fcostav[a].deriv; w->Bz[v * w->nz + v] += 2.0; }
+		nwt_add_bp(w, w->K0, i, w->Bz);
+	}
+	for (i = 0; i < m; i++) for (c = 0; c < w->n; c++) w->AEp[(size_t)i * w->n + nwt_ip(w, c)] = M_(AE, m, i, c);
+	for (j = 0; j < w->n; j++) {
+		double s = 0.0;
+		for (i = 0; i < m; i++) s += w->AEp[(size_t)i * w->n + j] * w->AEp[(size_t)i * w->n + j];
+		if (s > dmaxA) dmaxA = s;
+		if (w->K0[(size_t)j * w->ld] > dmaxK) dmaxK = w->K0[(size_t)j * w->ld];
+	}
+	w->sigma = (m > 0 && dmaxA > 0.0) ? NWT_SIGMA_SCALE * dmaxK / dmaxA : 0.0;
+	/* sigma A_E'A_E: a row's support spans more than the band only if it couples breakpoints (never for lic/ltc/lfc rows) */
+	for (i = 0; i < m; i++) {
+		const double *ar = w->AEp + (size_t)i * w->n;
+		for (j = 0; j < w->n; j++) {
+			int r2;
+			if (ar[j] == 0.0) continue;
+			for (r2 = j; r2 < w->n && r2 <= j + w->hb; r2++) if (ar[r2] != 0.0) w->K0[(size_t)j * w->ld + (r2 - j)] += w->sigma * ar[j] * ar[r2];
+		}
+	}
+	return w;
+}
+static void nwt_free(nwt_t *w)
+{
+	if (!w) return;
+	free(w->K0); free(w->Kb); free(w->AEp); free(w->Wt); free(w->S); free(w->wk); free(w->rm); free(w->Bz); free(w->dcbuf); free(w->dc); free(w->zp); free(w);
+}
+
+/* band Cholesky K_s = L L' with the border W = L^-1 A_E' carried along (left-looking, column by column).
+ * strict: a non-positive pivot is a failure (return 1); otherwise it is replaced by a tiny positive number. */
+static int nwt_factor(nwt_t *w, int strict)
+{
+	int n = w->n, hb = w->hb, ld = w->ld, m = w->m, j, kk, i, r;
+	double *Kb = w->Kb;
+	for (r = 0; r < m; r++) memcpy(w->Wt + (size_t)r * n, w->AEp + (size_t)r * n, n * sizeof(double));
+	for (j = 0; j < n; j++) {
+		double *cj = Kb + (size_t)j * ld, d, orig = cj[0];
+		const int k0 = j - hb > 0 ? j - hb : 0, imax = (n - 1 - j) < hb ? (n - 1 - j) : hb;
+		for (kk = k0; kk < j; kk++) {
+			const double *ck = Kb + (size_t)kk * ld;
+			const double ljk = ck[j - kk];
+			const int smax = hb - (j - kk);   /* rows j..kk+hb of column kk */
+			if (ljk == 0.0) continue;
+			for (i = 0; i <= smax && i <= imax; i++) cj[i] -= ck[j - kk + i] * ljk;
+			for (r = 0; r < m; r++) w->Wt[(size_t)r * n + j] -= w->Wt[(size_t)r * n + kk] * ljk;
+		}
+		d = cj[0];
+		if (!(d > 0.0)) {
+			if (strict) return 1;
+			d = 1e-14 * fabs(orig) + 1e-300;
+		}
+		d = sqrt(d); cj[0] = d;
+		for (i = 1; i <= imax; i++) cj[i] /= d;
+		for (r = 0; r < m; r++) w->Wt[(size_t)r * n + j] /= d;
+	}
+	for (i = 0; i < m; i++) for (j = 0; j <= i; j++) {
+		const double sv = dot_(w->Wt + (size_t)i * n, w->Wt + (size_t)j * n, n);
+		M_(w->S, m, i, j) = sv; M_(w->S, m, j, i) = sv;
+	}
+	if (m > 0 && chol_(w->S, m)) return strict ? 1 : 2;
+	return 0;
+}
+
+/* out = W_K v  (natural coefficient order in and out) */
+static void nwt_apply(nwt_t *w, const double *v, double *out)
+{
+	int n = w->n, hb = w->hb, ld = w->ld, m = w->m, j, i, r;
+	double *y = w->wk;
+	const double *Kb = w->Kb;
+	for (j = 0; j < n; j++) y[nwt_ip(w, j)] = v[j];
+	for (j = 0; j < n; j++) {   /* L y = v */
+		const double *cj = Kb + (size_t)j * ld;
+		const int imax = (n - 1 - j) < hb ? (n - 1 - j) : hb;
+		y[j] /= cj[0];
+		for (i = 1; i <= imax; i++) y[j + i] -= cj[i] * y[j];
+	}
+	if (m > 0) {
+		for (r = 0; r < m; r++) w->rm[r] = dot_(w->Wt + (size_t)r * n, y, n);
+		chol_solve_(w->S, m, w->rm);
+		for (r = 0; r < m; r++) { const double lr = w->rm[r]; const double *wr = w->Wt + (size_t)r * n; for (j = 0; j < n; j++) y[j] -= wr[j] * lr; }
+	}
+	for (j = n - 1; j >= 0; j--) {   /* L' z = y */
+		const double *cj = Kb + (size_t)j * ld;
+		const int imax = (n - 1 - j) < hb ? (n - 1 - j) : hb;
+		double sv = y[j];
+		for (i = 1; i <= imax; i++) sv -= cj[i] * y[j + i];
+		y[j] = sv / cj[0];
+	}
+	for (j = 0; j < n; j++) out[j] = y[nwt_ip(w, j)];
+}
+
+/* rebuild K at x from the multiplier estimates t of the evaluation at x (all zero while mu == 0) and factor it:
+ * first with the constraint curvature; if that is not positive definite, with the Gauss-Newton terms alone */
+static void nwt_refresh(nwt_t *w, const double *x, double mu, const double *t, int allow_curv)
+{
+	orc_problem *p = w->p;
+	const orc_colloc *cc = p->cc;
+	int nz = w->nz, P = w->P, attempt, i, j, v, v2, md = 1, ns = 0, o;
+	double cdum[64];
+	if (mu > 0.0) {
+		if (p->nnlic) orc_updateZ(p->Z, cc, x, p->icav, p->nicav, ORC_AVINITIAL);
+		if (p->nnltc) orc_updateZ(p->Z, cc, x, p->tcav, p->ntcav, ORC_AVTRAJECTORY);
+		if (p->nnlfc) orc_updateZ(p->Z, cc, x, p->fcav, p->nfcav, ORC_AVFINAL);
+	}
+	for (attempt = (allow_curv && mu > 0.0) ? 0 : 1; attempt < 2; attempt++) {
+		const int curv = attempt == 0;
+		memcpy(w->Kb, w->K0, (size_t)w->n * w->ld * sizeof(double));
+		if (mu > 0.0) {
+			for (i = 0; i < P; i++) {
+				int any = 0;
+				memset(w->Bz, 0, (size_t)nz * nz * sizeof(double));
+				for (o = 0; o < w->nout; o++) w->zp[o] = p->Z + cc->iZ[o] + (size_t)i * cc->maxderiv[o];
+				if (p->nnltc) {
+					double tt[64];
+					md = 1; p->nltcf(&md, &ns, &i, cdum, w->dc, w->zp);
+					for (j = 0; j < p->nnltc; j++) {
+						const double tj = t[p->nnlic + j * P + i];
+						tt[j] = tj;
+						if (tj == 0.0) continue;
+						any = 1;
+						for (v = 0; v < nz; v++) { if (w->dc[j][v] == 0.0) continue; for (v2 = 0; v2 < nz; v2++) w->Bz[v * nz + v2] += mu * w->dc[j][v] * w->dc[j][v2]; }
+					}
+					if (curv && any && p->nltc_hess) p->nltc_hess(&i, tt, w->Bz, w->zp);
+				}
+				if (i == 0 && p->nnlic) {
+					md = 1; p->nlicf(&md, &ns, cdum, w->dc, w->zp);
+					for (j = 0; j < p->nnlic; j++) {
+						const double tj = t[j];
+						if (tj == 0.0) continue;
+						any = 1;
+						for (v = 0; v < nz; v++) { if (w->dc[j][v] == 0.0) continue; for (v2 = 0; v2 < nz; v2++) w->Bz[v * nz + v2] += mu * w->dc[j][v] * w->dc[j][v2]; }
+					}
+					if (curv && p->nlic_hess) p->nlic_hess(&i, t, w->Bz, w->zp);
+				}
+				if (i == P - 1 && p->nnlfc) {
+					const double *tf = t + p->nnlic + p->nnltc * P;
+					md = 1; p->nlfcf(&md, &ns, cdum, w->dc, w->zp);
+					for (j = 0; j < p->nnlfc; j++) {
+						if (tf[j] == 0.0) continue;
+						any = 1;
+						for (v = 0; v < nz; v++) { if (w->dc[j][v] == 0.0) continue; for (v2 = 0; v2 < nz; v2++) w->Bz[v * nz + v2] += mu * w->dc[j][v] * w->dc[j][v2]; }
+					}
+					if (curv && p->nlfc_hess) p->nlfc_hess(&i, tf, w->Bz, w->zp);
+				}
+				if (any) nwt_add_bp(w, w->Kb, i, w->Bz);
+			}
+		}
+		w->nfact++;
+		w->curv = curv;
+		if (!nwt_factor(w, curv)) return;
+		w->nfail++;
+	}
+}
+
 /* ---------------- the solver ---------------- */
 typedef struct {
 	const double *A; int n, m;   /* A: the EQUALITY rows, m x n column-major */
@@ -343,7 +602,10 @@ static double al_eval(al_t *a, const double *x, double *g, double *rv_out, doubl
 			cj = 0.0; for (i = 0; i < n; i++) cj += M_(p->A, m, r, i) * x[i];
 			a->c[j] = cj;
 		}
-		{
+		if (!(a->mu > 0.0)) {   /* phase 0 of the structured Newton mode: the objective alone; rv = plain violation */
+			const double pj = cj < bl ? bl : (cj > bu ? bu : cj), rj = (cj - pj) / (1.0 + fabs(cj));
+			a->tnew[j] = 0.0; rv2 += rj * rj;
+		} else {
 			const double v = cj + a->lam[j] / a->mu;
 			const double pj = v < bl ? bl : (v > bu ? bu : v);
 			/* distance to the clamped shifted value: |c - b| for an active row, min(slack, lam/mu) for a feasible one --
@@ -355,7 +617,7 @@ static double al_eval(al_t *a, const double *x, double *g, double *rv_out, doubl
 		}
 	}
 	F += pen;
-	if (nc > 0)
+	if (nc > 0 && a->mu > 0.0)
 		for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < nc; j++) sum += M_(p->cJac, nc, j, i) * a->tnew[j]; g[i] += sum; }
 	for (j = 0; j < nI; j++) { const int r = a->irow[j]; for (i = 0; i < n; i++) g[i] += M_(p->A, m, r, i) * a->tnew[nc + j]; }
 	if (rv_out) *rv_out = sqrt(rv2);
@@ -373,7 +635,9 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	double r = o->opttol > 0 ? o->opttol : pow(DBL_EPSILON, 0.8), sr = sqrt(r), ftol = 1e-8;
 	double *W, *W0 = NULL, *g, *gp, *gn, *gpn, *d, *pdir, *xt, *s, *y, *u, *t, *lam;
 	double F = 0, Fn = 0, alpha = 0, pnorm = 0, gnf = 0, gnfn = 0, rv = 0, rvn = 0, rv_prev = HUGE_VAL;
-	int weak = 0;
+	int weak = 0, newton = 0, hess = o->hessian, outer0 = 0;
+	nwt_t *nw = NULL;
+	double *t_x = NULL;   /* multiplier estimates of the evaluation at the current iterate x */
 	proj_t pj;
 	ls_t ls;
 	al_t al;
@@ -383,11 +647,14 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	 * in the augmented Lagrangian */
 	for (i = 0; i < mall; i++) { if (p->bl[n + i] == p->bu[n + i]) erow[m++] = i; else irow[nI++] = i; }
 	nal = nc + nI;
+	newton = (o->hessian == 2) && nwt_applicable(p, nI);
+	if (o->hessian == 2 && !newton) hess = 1;
 	if (nal > 0 && o->fixed_iters) { res->inform = 9; free(erow); free(irow); return; }
 	AE = malloc((size_t)(m + 1) * n * sizeof(double)); bE = malloc((m + 1) * sizeof(double));
 	for (i = 0; i < m; i++) { bE[i] = p->bl[n + erow[i]]; for (j = 0; j < n; j++) M_(AE, m, i, j) = M_(p->A, mall, erow[i], j); }
 
-	W = malloc((size_t)n * n * sizeof(double));
+	W = newton ? NULL : malloc((size_t)n * n * sizeof(double));
+	t_x = calloc(nal + 1, sizeof(double));
 	g = malloc(n * sizeof(double)); gp = malloc(n * sizeof(double)); gn = malloc(n * sizeof(double));
 	gpn = malloc(n * sizeof(double)); d = malloc(n * sizeof(double)); pdir = malloc(n * sizeof(double));
 	xt = malloc(n * sizeof(double)); s = malloc(n * sizeof(double)); y = malloc(n * sizeof(double));
@@ -407,30 +674,37 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 		chol_solve_(pj.S, m, pj.tmpm);
 		for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(AE, m, i, j) * pj.tmpm[i]; x[j] += sum; }
 	}
-	if (o->hessian == 1) {
+	if (hess == 1) {
 		W0 = malloc((size_t)n * n * sizeof(double));
 		if (build_colloc_W0(p, AE, m, W0)) { free(W0); W0 = NULL; }
 	}
+	if (newton) { nw = nwt_make(p, AE, m); al.mu = 0.0; outer0 = -1; }
+/* out = W v, and the restart of W (from W0 / the identity, or -- structured Newton mode -- a Gauss-Newton refactorisation at x) */
+#define APPLY_W(v, out) do { if (nw) nwt_apply(nw, (v), (out)); else { int i_, j_; for (i_ = 0; i_ < n; i_++) { double sum_ = 0.0; for (j_ = 0; j_ < n; j_++) sum_ += M_(W, n, i_, j_) * (v)[j_]; (out)[i_] = sum_; } } } while (0)
+#define RESET_W() do { nupd = 0; if (nw) nwt_refresh(nw, x, al.mu, t_x, 0); else if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double)); \
+	else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; } } while (0)
 
 	/* outer loop: one pass when there are no nonlinear constraints; otherwise the multiplier /
 	 * penalty iteration of the augmented Lagrangian (at most 30 passes) */
-	for (outer = 0; outer < (nal > 0 ? 30 : 1); outer++) {
+	for (outer = outer0; outer < (nal > 0 ? 30 : 1); outer++) {
 		/* inner tolerance: NPSOL's for the last passes, looser while the constraints are far off */
 		const double sri = nal > 0 ? fmax(sr, fmin(1e-3, 0.1 * rv_prev)) : sr;
 		int inner_inform = 4, stop = 0, at_x = 1, nupd = 0;
 		weak = 0;
-		if (outer > 0 && m > 0) {
+		if (outer != outer0 && m > 0) {
 			/* steps stay in null(A) only to rounding; hundreds of majors per pass can drift: re-apply
 			 * x += A'(AA')^-1 (b - A x) before every further pass */
 			for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(AE, m, i, j) * x[j]; pj.tmpm[i] = bE[i] - sum; }
 			chol_solve_(pj.S, m, pj.tmpm);
 			for (j = 0; j < n; j++) { double sum = 0.0; for (i = 0; i < m; i++) sum += M_(AE, m, i, j) * pj.tmpm[i]; x[j] += sum; }
 		}
-		if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
-		else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
 		F = al_eval(&al, x, g, &rv, &gnf);
+		memcpy(t_x, al.tnew, nal * sizeof(double));
+		if (nw) nwt_refresh(nw, x, al.mu, t_x, 1);
+		else if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
+		else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
 		project(&pj, g, gp, lam);
-		for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
+		APPLY_W(gp, d);
 
 		for (;;) {
 			double dphi0, xnorm, amax, a1, sy, yu, rho, cc2, tolg;
@@ -450,10 +724,10 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			if (pnorm == 0.0 || !(dphi0 < 0.0)) {
 				/* already stationary in null(A) (or W lost definiteness numerically: restart once) */
 				if (pnorm != 0.0) {
-					nupd = 0;
-					if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
-					else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
-					for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; pdir[i] = -sum; }
+					RESET_W();
+					APPLY_W(gp, d);
+					if (nal > 0 && m > 0) { project(&pj, d, xt, NULL); memcpy(d, xt, n * sizeof(double)); }
+					for (i = 0; i < n; i++) pdir[i] = -d[i];
 					dphi0 = dot_(gp, pdir, n); pnorm = nrm2_(pdir, n);
 				}
 				if (pnorm == 0.0 || !(dphi0 < 0.0)) { inner_inform = (nrm2_(gp, n) <= tolg) ? 0 : 6; break; }
@@ -481,11 +755,9 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			if (rc != 1) {
 				/* line search failed: if the quasi-Newton matrix carries updates, drop them and retry from
 				 * the same point with W0 (a poor W is the usual cause); fail only if W0 itself fails */
-				if (nupd > 0 && nrm2_(gp, n) > tolg) {
-					nupd = 0;
-					if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
-					else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
-					for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
+				if ((nupd > 0 || (nw && nw->curv)) && nrm2_(gp, n) > tolg) {
+					RESET_W();
+					APPLY_W(gp, d);
 					continue;
 				}
 				/* no further decrease obtainable along a descent direction: converged if the projected gradient
@@ -499,18 +771,24 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			alpha = ls.a;
 			for (i = 0; i < n; i++) { s[i] = alpha * pdir[i]; y[i] = gpn[i] - gp[i]; }
 			memcpy(x, xt, n * sizeof(double));
+			memcpy(t_x, al.tnew, nal * sizeof(double));
+			if (nw) {
+				/* structured Newton mode: a fresh factorisation at the new iterate replaces the quasi-Newton update */
+				nwt_refresh(nw, x, al.mu, t_x, 1);
+				APPLY_W(gpn, t);
+				sy = 0.0;
+			} else {
 			if (nupd == (o->qn_memory > 0 ? o->qn_memory : 256)) {
 				/* memory full (the device keeps the updates as pairs): restart the approximation from W0 */
-				nupd = 0;
-				if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double));
-				else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; }
-				for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gp[j]; d[i] = sum; }
+				RESET_W();
+				APPLY_W(gp, d);
 			}
 			/* t = W gp+,  u = W y = t - d */
-			for (i = 0; i < n; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(W, n, i, j) * gpn[j]; t[i] = sum; }
+			APPLY_W(gpn, t);
 			for (i = 0; i < n; i++) u[i] = t[i] - d[i];
 			sy = dot_(s, y, n);
-			if (sy > 1e-12 * nrm2_(s, n) * nrm2_(y, n)) {
+			}
+			if (!nw && sy > 1e-12 * nrm2_(s, n) * nrm2_(y, n)) {
 				double a1s, a2u;
 				yu = dot_(y, u, n); rho = 1.0 / sy; cc2 = rho * (1.0 + rho * yu);
 				for (j = 0; j < n; j++) for (i = 0; i < n; i++)
@@ -532,14 +810,22 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			    nrm2_(gp, n) <= sri * (1.0 + fmax(1.0 + fabs(F), gnf))) { inner_inform = 0; break; }
 		}
 		if (nal == 0) { inform = (inner_inform == 0 && weak) ? 1 : inner_inform; break; }
+		if (outer < 0) {
+			/* phase 0 of the structured Newton mode (the objective alone, from the caller's start) is done: switch the
+			 * augmented Lagrangian on */
+			if (stop) { inform = 4; break; }
+			al.mu = NWT_MU0;
+			continue;
+		}
 		/* ---- multiplier / penalty update from the constraint values AT x: if the inner solve ended on a
 		 *      rejected line-search trial, the last evaluation was elsewhere -> evaluate once more at x ---- */
 		if (!at_x) { F = al_eval(&al, x, g, &rv, &gnf); at_x = 1; }
 		if (inner_inform == 6) { inform = 6; break; }
 		if (rv <= ftol && sri <= sr && inner_inform == 0) { memcpy(al.lam, al.tnew, nal * sizeof(double)); inform = weak ? 1 : 0; break; }
 		if (stop) { inform = 4; break; }
-		if (rv <= 0.25 * rv_prev) { memcpy(al.lam, al.tnew, nal * sizeof(double)); rv_prev = rv; }
-		else al.mu *= 10.0;
+		if (rv <= NWT_KAPPA * rv_prev) { memcpy(al.lam, al.tnew, nal * sizeof(double)); rv_prev = rv; }
+		else if (nw && NWT_BOTH) { memcpy(al.lam, al.tnew, nal * sizeof(double)); if (rv < rv_prev) rv_prev = rv; al.mu *= NWT_MUFAC; }
+		else al.mu *= (nw ? NWT_MUFAC : 10.0);
 		if (outer == 29) inform = 3;   /* nonlinear constraints not satisfied to tolerance */
 	}
 	if (nal > 0 && m > 0 && inform != 9) {
@@ -579,8 +865,9 @@ done:
 	if (R && inform != 9) {
 		/* R'R = (W + A'(AA')^-1 A)^-1 when W0 is rank-deficient; W itself otherwise */
 		double *Hf = malloc((size_t)n * n * sizeof(double)), *col = malloc(n * sizeof(double));
-		memcpy(Hf, W, (size_t)n * n * sizeof(double));
-		if (W0 && m > 0) {
+		if (nw) { for (j = 0; j < n; j++) { memset(col, 0, n * sizeof(double)); col[j] = 1.0; nwt_apply(nw, col, &M_(Hf, n, 0, j)); } }
+		else memcpy(Hf, W, (size_t)n * n * sizeof(double));
+		if ((W0 || nw) && m > 0) {
 			double *X = malloc((size_t)m * n * sizeof(double));
 			for (j = 0; j < n; j++) { for (i = 0; i < m; i++) M_(X, m, i, j) = M_(AE, m, i, j); chol_solve_(pj.S, m, &M_(X, m, 0, j)); }
 			for (j = 0; j < n; j++) for (i = 0; i < n; i++) { double sum = 0.0; int k; for (k = 0; k < m; k++) sum += M_(AE, m, k, i) * M_(X, m, k, j); M_(Hf, n, i, j) += sum; }
@@ -597,6 +884,10 @@ done:
 		}
 		free(Hf); free(col);
 	}
+	if (o->verbose && nw) fprintf(stderr, "  newton: %d factorisations, %d not positive definite with curvature\n", nw->nfact, nw->nfail);
+	nwt_free(nw); free(t_x);
+#undef APPLY_W
+#undef RESET_W
 	free(W); free(W0); free(g); free(gp); free(gn); free(gpn); free(d); free(pdir); free(xt);
 	free(s); free(y); free(u); free(t); free(lam); free(pj.S); free(pj.tmpm);
 	free(al.lam); free(al.tnew); free(al.c); free(erow); free(irow); free(AE); free(bE);
