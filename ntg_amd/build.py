@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libntg_amd.so")
 SOURCES = ["kernels.hip", "fam_kincar.hip", "fam_kincar_chm.hip", "fam_vanderpol.hip", "fam_testfam.hip", "fam_obstacle.hip", "fam_quadrotor.hip",
            "fam_manip.hip", "plan.cpp", "ntg_host.cpp"]
-HEADERS = ["ntg_dev.hpp", "solve_impl.hpp", "eval_fast.hpp", "families.hpp", "linesearch.hpp", "plan.hpp", "../../include/ntg_amd.h", "../../include/ntg.h"]
+HEADERS = ["ntg_dev.hpp", "solve_impl.hpp", "newton.hpp", "eval_fast.hpp", "families.hpp", "linesearch.hpp", "plan.hpp", "../../include/ntg_amd.h", "../../include/ntg.h"]
 
 
 def _stale() -> bool:

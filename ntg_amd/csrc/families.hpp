@@ -42,6 +42,8 @@ struct DenseTraj {
 
 template <> struct Family<NTG_FAM_KINCAR> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
+	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int, const double *z, double &f, double *df)
 	{
@@ -63,6 +65,8 @@ template <> struct Family<NTG_FAM_KINCAR> {
 
 template <> struct Family<NTG_FAM_VANDERPOL> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
+	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int, int, const double *zz, double &f, double *df)
 	{
@@ -85,6 +89,8 @@ template <> struct Family<NTG_FAM_VANDERPOL> {
 // dc is [ncon][nz] row-major (== the reference's dc[constraint][variable])
 template <> struct Family<NTG_FAM_TESTFAM> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
+	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
 	static constexpr int NNLIC = 1, NNLTC = 2, NNLFC = 1;
 	static __device__ __forceinline__ void icf(int nout, const double *z, double &f, double *df)
 	{
@@ -147,6 +153,13 @@ template <> struct Family<NTG_FAM_TESTFAM> {
 
 template <> struct Family<NTG_FAM_OBSTACLE> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr int COUPLE = 2, CG = 2;   // one group (x, y); constraint flag entries x, y
+	// B (CG x CG) = mu a a' [row active] + t d2c/dz2 [curv]: the second-order model of the row's augmented-Lagrangian term
+	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *z, const double *t, double mu, bool curv, double *B)
+	{
+		const double dx = z[0] - 20.0, dy = z[3] - 0.5, a0 = 2.0 * dx, a1 = 2.0 * dy, m = t[0] != 0.0 ? mu : 0.0, h = curv ? 2.0 * t[0] : 0.0;
+		B[0] = m * a0 * a0 + h; B[1] = m * a0 * a1; B[2] = m * a1 * a0; B[3] = m * a1 * a1 + h;
+	}
 	static constexpr int NNLIC = 0, NNLTC = 1, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int i, const double *z, double &f, double *df) { Family<NTG_FAM_KINCAR>::ucf(nout, i, z, f, df); }
 	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }
@@ -166,6 +179,21 @@ template <> struct Family<NTG_FAM_OBSTACLE> {
 
 template <> struct Family<NTG_FAM_QUADROTOR> {
 	static constexpr int DM = 5, TAPE = 1;
+	static constexpr int COUPLE = 4, CG = 6;   // one group; constraint flag entries in flag order: x', x'', y', y'', z', z''
+	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *z, const double *t, double mu, bool curv, double *B)
+	{
+		const double a0[6] = {0.0, 2.0 * z[2], 0.0, 2.0 * z[7], 0.0, 2.0 * (z[12] + G)};   // thrust^2
+		const double a1[6] = {2.0 * z[1], 0.0, 2.0 * z[6], 0.0, 2.0 * z[11], 0.0};          // speed^2
+		const double m0 = t[0] != 0.0 ? mu : 0.0, m1 = t[1] != 0.0 ? mu : 0.0;
+#pragma unroll
+		for (int i = 0; i < 6; i++)
+#pragma unroll
+			for (int j = 0; j < 6; j++) B[6 * i + j] = m0 * a0[i] * a0[j] + m1 * a1[i] * a1[j];
+		if (curv) {
+			B[7] += 2.0 * t[0]; B[21] += 2.0 * t[0]; B[35] += 2.0 * t[0];
+			B[0] += 2.0 * t[1]; B[14] += 2.0 * t[1]; B[28] += 2.0 * t[1];
+		}
+	}
 	static constexpr int NNLIC = 0, NNLTC = 2, NNLFC = 0;
 	static constexpr double G = 9.81;
 	static __device__ __forceinline__ void ucf(int, int, const double *z, double &f, double *df)
@@ -205,6 +233,20 @@ template <> struct Family<NTG_FAM_QUADROTOR> {
 template <> struct Family<NTG_FAM_MANIP> {
 	static constexpr int DM = 3;
 	static constexpr int MAXARMS = NTG_MAX_OUT / 3, TAPE = 3 * (NTG_MAX_OUT / 3);
+	static constexpr int COUPLE = 3, CG = 3;   // one group per arm; constraint flag entries qa, qb, qc
+	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int g, const double *z, const double *t, double mu, bool curv, double *B)
+	{
+		const double a1 = z[9 * g], a2 = a1 + z[9 * g + 3], a3 = a2 + z[9 * g + 6];
+		double s1, s2, s3, c1, c2, c3;
+		sincos(a1, &s1, &c1); sincos(a2, &s2, &c2); sincos(a3, &s3, &c3);
+		const double a[3] = {c1 + c2 + c3, c2 + c3, c3}, m = t[g] != 0.0 ? mu : 0.0, tt = curv ? t[g] : 0.0;
+		// d2c = -(s1 e1 e1' + s2 e2 e2' + s3 e3 e3'),  e1 = (1,0,0), e2 = (1,1,0), e3 = (1,1,1)
+		const double h[9] = {s1 + s2 + s3, s2 + s3, s3, s2 + s3, s2 + s3, s3, s3, s3, s3};
+#pragma unroll
+		for (int i = 0; i < 3; i++)
+#pragma unroll
+			for (int j = 0; j < 3; j++) B[3 * i + j] = m * a[i] * a[j] - tt * h[3 * i + j];
+	}
 	static constexpr int NNLIC = 0, NNLTC = MAXARMS, NNLFC = 0;
 	static __device__ __forceinline__ void ucf(int nout, int i, const double *z, double &f, double *df) { Family<NTG_FAM_KINCAR>::ucf(nout, i, z, f, df); }
 	static __device__ __forceinline__ void icf(int, const double *, double &f, double *) { f = 0.0; }

@@ -17,6 +17,7 @@
 // 64-lane wavefront shuffles + one LDS hop across the waves of the workgroup.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <algorithm>
 #include "solve_impl.hpp"
 
 
@@ -361,7 +362,12 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
 	L.wts = p; p = align16(p + D.P * 8);
 	L.x = p; if (with_x) p = align16(p + npad * 8);
 	// [row][P+1] + a zero tail: the column form reads W consecutive entries from a column's first breakpoint
-	L.dfz = p; p = align16(p + ((D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + ntg_dfz_tail(D)) * 8);
+	{
+		// the structured Newton mode borrows this area between evaluations: solve vectors and factorisation panels of every group
+		int dfz_bytes = ((D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + ntg_dfz_tail(D)) * 8;
+		if (D.nwt_on) dfz_bytes = std::max(dfz_bytes, D.nwt_ngrp * ((16 * ((D.nwt_ng + 15) / 16) + 48) + 48 * 17) * 8);
+		L.dfz = p; L.nwt_y = p; p = align16(p + dfz_bytes);
+	}
 	L.fvals = p; p = align16(p + D.P * 8);
 	L.red = p; p = align16(p + 16 * (nthreads / 64 + 1) * 8);
 	L.dfi = p; p = align16(p + (D.nz + 1) * 8);

@@ -42,6 +42,9 @@ struct NtgDims {
 	int n0_blk[NTG_MAX_OUT];            // which dense preconditioner block an output uses (NtgTables::n0b)
 	int ch_row0[NTG_MAX_ORDER], ch_col0[NTG_MAX_ORDER];   // host copy of class 0's channel offsets (NtgTables::chrow/chcol)
 	int tav_rmask;                      // union over outputs of the derivative indices with a cost AV
+	// structured Newton mode (newton.hpp): coupling groups of nwt_go outputs, nwt_ng free coefficients each (interleaved by
+	// output), half bandwidth nwt_hb, nwt_cg constraint flag entries per group; nwt_on = 0: the plan does not qualify
+	int nwt_on, nwt_ngrp, nwt_go, nwt_ng, nwt_hb, nwt_cg;
 };
 
 struct NtgTables {
@@ -71,6 +74,9 @@ struct NtgTables {
 	// = 1 for slots declared as inequalities; inequality rows as CSR (by row) and CSC (by coefficient)
 	const int *erow, *rowmap, *linflag, *irow;
 	const int *icsr_ptr, *icsr_col, *icsc_ptr, *icsc_row; const double *icsr_val, *icsc_val;
+	// structured Newton mode: nwt_map[g][p] = coefficient of free entry p of group g; nwt_pos[c] = g * nwt_ng + p, or -1 for a
+	// pinned coefficient; nwt_k0 = cost-model band [g][p][hb+1]; nwt_lo/hi[cl] = breakpoints [lo, hi) in whose block cl lies
+	const int *nwt_map, *nwt_pos; const double *nwt_k0; const short *nwt_lo, *nwt_hi;
 	const short *q_idx;    // [nC] row of coefficient c in the compact Q, or -1
 	const int *q_col;      // [q_nt][q_w]
 	const double *q_val;   // [q_nt][q_w], zero padded
@@ -85,6 +91,7 @@ __host__ __device__ inline int ntg_dfz_tail(const NtgDims &D) { int w = 16; for 
 struct SmemLayout {
 	int rowv, colp, chrow, chcol, off, bps, wts, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
 	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, tcomp, q_idx, q_col, q_val, ls, tI, total;
+	int nwt_y;   // structured Newton mode: byte offset (inside the dfz area, which is idle between evaluations) of the solve vectors; panels follow
 };
 
 struct SolveParams {
@@ -96,6 +103,6 @@ struct SolveParams {
 // launcher arguments (host side)
 struct EvalArgs { int nt, grid, ncu, batch, mode; const double *x; double *f, *g, *c, *jb, *cj; hipStream_t st; };
 struct SqpArgs {
-	int nt, big, batch; const double *lo, *up; double *x, *obj; int *inf, *it, *nf; double *cl, *hist, *alw, *vecw; hipStream_t st;
+	int nt, big, batch; const double *lo, *up; double *x, *obj; int *inf, *it, *nf; double *cl, *hist, *alw, *vecw, *nwtw; hipStream_t st;
 };
 

@@ -15,6 +15,7 @@
 #include "ntg_dev.hpp"
 #include "plan.hpp"
 
+static int build_newton_tables(ntg_plan *p);
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #define HIPCHK(x)                                                                                 \
@@ -388,7 +389,94 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	p->tcostav.assign(s->tcostav, s->tcostav + s->ntcostav);
 	p->icostav.assign(s->icostav, s->icostav + s->nicostav);
 	p->fcostav.assign(s->fcostav, s->fcostav + s->nfcostav);
+	if (build_newton_tables(p)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 	*out = p;
+	return 0;
+}
+
+// ---- structured Newton mode (newton.hpp): does the plan qualify, and its batch-shared tables ----
+// Qualifies when: the family offers the per-group second-order blocks (Family::COUPLE / CG of families.hpp, mirrored here), one
+// spline spec for every output, only trajectory nonlinear rows on exactly the flag entries the family's block covers, no
+// linear inequality rows, and equality rows that pin a square invertible block of coefficients (the usual initial / final
+// conditions): then null(A_E) = {pinned coefficients = 0} and the reduced Hessian is a principal submatrix of the band.
+static int build_newton_tables(ntg_plan *p)
+{
+	NtgDims &D = p->D;
+	D.nwt_on = 0;
+	int go = 0, cg = 0;
+	u64 gmask = 0;   // constraint flag entries of group 0, relative to the group's first flag entry
+	const int dm = D.d[0];
+	switch (D.family) {
+	case NTG_FAM_OBSTACLE: go = 2; cg = 2; gmask = (1ull << 0) | (1ull << 3); break;
+	case NTG_FAM_QUADROTOR: go = 4; cg = 6; gmask = (1ull << 1) | (1ull << 2) | (1ull << 6) | (1ull << 7) | (1ull << 11) | (1ull << 12); break;
+	case NTG_FAM_MANIP: go = 3; cg = 3; gmask = (1ull << 0) | (1ull << 3) | (1ull << 6); break;
+	default: return 0;
+	}
+	if (!D.uniform || D.nI > 0 || D.nnlic || D.nnlfc || D.nnltc <= 0 || D.nout % go || !p->lin_ok) return 0;
+	const int ngrp = D.nout / go, k = D.order[0], nco = D.ncoef[0], n = D.nC, P = D.P, hb = k * go - 1, m = D.mE;
+	if (hb > 32 || ngrp > 8) return 0;
+	u64 want = 0;
+	for (int g = 0; g < ngrp; g++) want |= gmask << (dm * go * g);
+	if (D.tcon_mask != want) return 0;
+	// pinned coefficients = the columns the equality rows touch; they must form a square system
+	std::vector<char> pinned(n, 0);
+	int npin = 0;
+	// (entries at rounding level do not count: the last breakpoint of a cumulative-add linspace (ntg.c:385-388) may lie an ulp
+	// past the last knot, where the spline is extrapolated and the other basis functions are ~1e-16 instead of 0; the solve
+	// re-projects x and every direction onto A x = b anyway)
+	for (int i = 0; i < m; i++) {
+		double big = 0.0;
+		for (int c = 0; c < n; c++) big = std::max(big, std::fabs(p->h_AE[(size_t)i * n + c]));
+		for (int c = 0; c < n; c++) if (std::fabs(p->h_AE[(size_t)i * n + c]) > 1e-10 * big && !pinned[c]) { pinned[c] = 1; npin++; }
+	}
+	if (npin != m) return 0;
+	std::vector<int> map, pos(n, -1);
+	int ng = -1;
+	for (int g = 0; g < ngrp; g++) {
+		int cnt = 0;
+		for (int cl = 0; cl < nco; cl++) for (int o = g * go; o < (g + 1) * go; o++) {
+			const int c = D.iC[o] + cl;
+			if (pinned[c]) continue;
+			pos[c] = g * 1000000 + cnt; map.push_back(c); cnt++;
+		}
+		if (ng < 0) ng = cnt; else if (cnt != ng) return 0;
+	}
+	if (ng < 1) return 0;
+	for (int c = 0; c < n; c++) if (pos[c] >= 0) pos[c] = (pos[c] / 1000000) * ng + pos[c] % 1000000;
+	// breakpoint range of every local coefficient, from the block offsets (consecutive: checked when the column form was built)
+	std::vector<short> lo(nco, (short)P), hi(nco, 0);
+	const int *off = p->h_off.data();
+	for (int i = 0; i < P; i++) for (int q = 0; q < k; q++) { const int cl = off[i] + q; lo[cl] = (short)std::min<int>(lo[cl], i); hi[cl] = (short)std::max<int>(hi[cl], i + 1); }
+	// cost model: 2 w_i on the trajectory-cost variables, 2 on the initial / final ones (diagonal in the flag: same output only)
+	const int ld = hb + 1;
+	std::vector<double> k0((size_t)ngrp * ng * ld, 0.0);
+	const double *blk = p->h_blk.data();
+	auto add = [&](const std::vector<ntg_av> &av, int bp, double w) {
+		for (const ntg_av &a : av) {
+			const int o = a.output, r = a.deriv, g = o / go;
+			for (int q1 = 0; q1 < k; q1++) for (int q2 = 0; q2 < k; q2++) {
+				const int c1 = D.iC[o] + off[bp] + q1, c2 = D.iC[o] + off[bp] + q2;
+				if (pos[c1] < 0 || pos[c2] < 0) continue;
+				const int p1 = pos[c1] - g * ng, p2 = pos[c2] - g * ng;
+				if (p1 < p2) continue;
+				k0[((size_t)g * ng + p1) * ld + (p2 - p1 + hb)] += w * blk[((size_t)bp * k + q1) * dm + r] * blk[((size_t)bp * k + q2) * dm + r];
+			}
+		}
+	};
+	for (int i = 0; i < P; i++) {
+		double w = 0.0;
+		if (i > 0) w += (p->h_bps[i] - p->h_bps[i - 1]) / 2;
+		if (i < P - 1) w += (p->h_bps[i + 1] - p->h_bps[i]) / 2;
+		if (D.nucf) add(p->tcostav, i, 2.0 * w);
+	}
+	if (D.nicf) add(p->icostav, 0, 2.0);
+	if (D.nfcf) add(p->fcostav, P - 1, 2.0);
+	int *d_map = nullptr, *d_pos = nullptr; double *d_k0 = nullptr; short *d_lo = nullptr, *d_hi = nullptr;
+	if (dev_upload(&d_map, map.data(), map.size(), p->owned) || dev_upload(&d_pos, pos.data(), pos.size(), p->owned) ||
+	    dev_upload(&d_k0, k0.data(), k0.size(), p->owned) || dev_upload(&d_lo, lo.data(), lo.size(), p->owned) ||
+	    dev_upload(&d_hi, hi.data(), hi.size(), p->owned)) return NTG_E_HIP;
+	p->T.nwt_map = d_map; p->T.nwt_pos = d_pos; p->T.nwt_k0 = d_k0; p->T.nwt_lo = d_lo; p->T.nwt_hi = d_hi;
+	D.nwt_on = 1; D.nwt_ngrp = ngrp; D.nwt_go = go; D.nwt_ng = ng; D.nwt_hb = hb; D.nwt_cg = cg;
 	return 0;
 }
 
@@ -597,6 +685,7 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	sp->memcap = std::min(sp->itlim, o->qn_memory > 0 ? o->qn_memory : 256);
 	sp->ls_maxfev = o->ls_maxfev > 0 ? o->ls_maxfev : 20;
 	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters;
+	if (sp->hessian == 2 && !D.nwt_on) sp->hessian = 1;   // the structured Newton mode does not apply: collocation preconditioner
 	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
 	sp->sr = std::sqrt(r);
@@ -618,8 +707,18 @@ static int solve_layout(const NtgDims &D, int nt, SmemLayout *L, int *big)
 	*L = ntg_make_layout(D, nt, 1, 0);
 	return L->total <= 160 * 1024 ? 0 : -1;
 }
-static size_t hist_doubles(const NtgDims &D, int batch, const SolveParams &sp) { return (size_t)batch * sp.memcap * (2 * D.nC + 2); }
+static size_t hist_doubles(const NtgDims &D, int batch, const SolveParams &sp)
+{
+	if (sp.hessian == 2) return 0;   // the structured Newton mode keeps no quasi-Newton pairs
+	return (size_t)batch * sp.memcap * (2 * D.nC + 2);
+}
 static size_t al_doubles(const NtgDims &D, int batch) { return (size_t)batch * 2 * (D.ncnln + D.nI); }
+// structured Newton mode: band matrix / factor of every group + the per-breakpoint blocks, per problem
+static size_t nwt_doubles(const NtgDims &D, int batch, const SolveParams &sp)
+{
+	if (sp.hessian != 2 || !D.nwt_on) return 0;
+	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg);
+}
 
 extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, const ntg_solve_opts *o)
 {
@@ -629,7 +728,7 @@ extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, con
 	SmemLayout L; int big;
 	solve_layout(p->D, nt, &L, &big);
 	const size_t npad = (size_t)((p->D.nC + 1) & ~1);
-	return (long long)((hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0)) * 8 + 256);
+	return (long long)((hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0) + nwt_doubles(p->D, batch, sp)) * 8 + 256);
 }
 
 extern "C" int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
@@ -691,8 +790,9 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	if (solve_layout(p->D, nt, &L, &big)) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
 	double *alw = (double *)d_work + hist_doubles(p->D, batch, sp);   // [batch][2][ncnln] multipliers, estimates
 	double *vecw = alw + al_doubles(p->D, batch);                     // [batch][5][npad] x, gp, gp+, d, g (BIG only)
+	double *nwtw = vecw + (big ? (size_t)batch * 5 * ((p->D.nC + 1) & ~1) : 0);   // structured Newton mode: bands and blocks
 	SqpArgs sa{nt, big, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev, d_clambda, (double *)d_work, alw,
-	           big ? vecw : nullptr, (hipStream_t)stream};
+	           big ? vecw : nullptr, sp.hessian == 2 ? nwtw : nullptr, (hipStream_t)stream};
 	HIPCHK(ntg_launch_sqp(p->D, p->T, L, sp, sa));
 	return 0;
 }

@@ -162,6 +162,8 @@ __device__ __forceinline__ void for_vec(int n, F f)
 	}
 }
 
+#include "newton.hpp"
+
 // ------------------------------------------------------------------------------------------
 // LDS carve-up shared by eval_kernel and sqp_kernel
 // ------------------------------------------------------------------------------------------
@@ -1163,13 +1165,16 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 // (read across lanes by Z = M C at every evaluation) stays in LDS; x, gp, gp+, d and g live in a per-problem HBM/L2
 // workspace `vec_all`.  They are touched element-wise by their owner lane, except in the projection, the feasibility
 // step and the preconditioner, which read a handful of entries across lanes behind a full barrier.
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS, int CHM>
+// NWT: the structured Newton mode (ntg_solve_opts.hessian = 2, newton.hpp): W is the inverse of the banded second-order
+// model of the augmented Lagrangian, refactored at every major iteration; no quasi-Newton pairs.  The solve starts with
+// a pass on the objective alone (mu = 0, "phase 0") before the augmented-Lagrangian passes.
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS, int CHM, bool NWT = false>
 __global__ void __launch_bounds__(NT, NTG_SQP_WAVES)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
            double *__restrict__ objective, int *__restrict__ inform_out, int *__restrict__ iters_out,
            int *__restrict__ nfev_out, double *__restrict__ clambda, double *__restrict__ hist_all,
-           double *__restrict__ al_all, double *__restrict__ vec_all)
+           double *__restrict__ al_all, double *__restrict__ vec_all, double *__restrict__ nwt_all)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	Smem S(smem_raw, L, D, T);
@@ -1197,13 +1202,78 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	const int nI = LIN ? D.nI : 0, nal = ncn + nI;
 	// augmented-Lagrangian state (nonlinear rows, then linear inequality rows): multipliers and their estimates live in HBM
 	double *al_lam = al_all + (size_t)b * 2 * (ncn + D.nI), *al_t = al_lam + ncn + D.nI;
-	ALState al{((HASCON && ncn > 0) || nI > 0) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
-	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};
-	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
-	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history / rest
+	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history (structured Newton mode: model assembly) / W0 (Newton: factor + solve) / rest
 	unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define NTG_STAMP(slot) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot] += now_ - tlast; tlast = now_; } } while (0)
 	if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
+	const bool alprob = (HASCON && ncn > 0) || nI > 0;   // rows handled by the augmented-Lagrangian loop
+	ALState al{(alprob && !NWT) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
+	// structured Newton mode: band matrix / factor and the per-breakpoint blocks of this problem (HBM), flags
+	using FamN = Family<FAM>;
+	constexpr int NWT_CG2 = FamN::CG * FamN::CG;
+	double *nwt_K = NWT ? nwt_all + (size_t)b * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (size_t)D.nwt_ngrp * D.P * NWT_CG2) : nullptr;
+	double *nwt_B = NWT ? nwt_K + (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) : nullptr;
+	bool nwt_curv = false;        // the current factor includes the constraint curvature
+	bool phase0 = NWT && alprob;  // the pass on the objective alone is still running
+	int *nwt_flag = (int *)(smem_raw + L.red) + 2 * 16 * (NT / 64 + 1) - 2;   // last word pair of the reduction scratch: "not positive definite"
+	// K = model at the trial point buffer `xs` (must be the iterate x; needs the multiplier estimates al_t of the evaluation
+	// at x), factored; then out = W v.  allow_curv = false: Gauss-Newton terms only.
+	auto nwt_refresh = [&](const double *xs, bool allow_curv) {
+		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, P2 = D.P;
+		const int wave = tid >> 6;
+		double *panel = (double *)(smem_raw + L.nwt_y) + (size_t)ngp * (16 * ((ng + 15) >> 4) + 48);
+		for (int attempt = (allow_curv && al.mu > 0.0) ? 0 : 1; attempt < 2; attempt++) {
+			const bool curv = attempt == 0;
+			if (al.mu > 0.0) {
+				constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ, NTc = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
+				lds_sync();
+				for (int i = tid; i < P2; i += NT) {
+					double z[NZ], t[NTc];
+					compute_z<NOUT, K, DM>(D, S, xs, i, D.tcon_mask, z);
+#pragma unroll
+					for (int j = 0; j < NTc; j++) t[j] = j < D.nnltc ? al_t[D.nnlic + j * P2 + i] : 0.0;
+					for (int g = 0; g < ngp; g++) {
+						double Bk[NWT_CG2];
+						FamN::template nltc_block<NZ>(NOUT > 0 ? NOUT : D.nout, g, z, t, al.mu, curv, Bk);
+#pragma unroll
+						for (int e = 0; e < NWT_CG2; e++) nwt_B[((size_t)g * P2 + i) * NWT_CG2 + e] = Bk[e];
+					}
+				}
+				__syncthreads();
+			}
+			nwt_assemble<NT>(D, T, S.rowv, S.chrow, S.off, S.tcomp, al.mu > 0.0 ? nwt_B : nullptr, nwt_K);
+			if (tid == 0) nwt_flag[0] = 0;
+			__syncthreads();
+			NTG_STAMP(3);
+			if (wave < ngp) {
+				const int f = nwt_factor_wave(nwt_K + (size_t)wave * ng * (hb + 1), ng, hb, panel + (size_t)wave * 48 * NWT_PSTRIDE, curv ? 1 : 0);
+				if (f && (tid & 63) == 0) nwt_flag[0] = 1;
+			}
+			__syncthreads();
+			nwt_curv = curv;
+			if (nwt_flag[0] == 0) break;
+		}
+	};
+	auto nwt_apply = [&](const double *v, double *out) {
+		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ylen = 16 * ((ng + 15) >> 4) + 48;
+		const int wave = tid >> 6;
+		double *yv = (double *)(smem_raw + L.nwt_y);
+		if (BIG) __syncthreads(); else lds_sync();
+		for (int i = tid; i < ngp * ylen; i += NT) {
+			const int g = i / ylen, pp = i - g * ylen;
+			yv[i] = pp < ng ? v[T.nwt_map[g * ng + pp]] : 0.0;
+		}
+		lds_sync();
+		if (wave < ngp) nwt_solve_wave(nwt_K + (size_t)wave * ng * (hb + 1), ng, hb, yv + (size_t)wave * ylen);
+		lds_sync();
+		for (int c = tid; c < n; c += NT) {
+			const int pos = T.nwt_pos[c];
+			out[c] = pos >= 0 ? yv[(pos / ng) * ylen + (pos % ng)] : 0.0;
+		}
+		if (BIG) __syncthreads(); else lds_sync();
+	};
+	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};
+	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
 	// ---- scope check (uniform): linear rows are equalities unless the plan declared them inequalities ----
 	{
 		double bad[1] = {0.0};
@@ -1250,8 +1320,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		};
 		make_feasible();
 		for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
-		if (al.mu > 0.0) {
-			for (int j = tid; j < nal; j += NT) al_lam[j] = 0.0;
+		if (alprob) {
+			for (int j = tid; j < nal; j += NT) { al_lam[j] = 0.0; if (NWT) al_t[j] = 0.0; }
 			sri = fmax(sp.sr, 1e-3);
 			__syncthreads();   // multipliers cross lanes through HBM: full barrier
 		}
@@ -1311,7 +1381,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (state == ST_INIT) {
 				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
-				apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+				if (NWT) { nwt_refresh(sxt, true); nwt_apply(sgp, sd); }
+				else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
 				for_vec<NT>(n, [&](int c) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; });
 				block_sum<NT, 4>(r4, S.red);
@@ -1336,10 +1407,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				}
 				if (rc != 1) {
 					const double tolg = sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
-					if (npairs > 0 && sqrt(r4[3]) > tolg) {
+					if ((npairs > 0 || (NWT && nwt_curv)) && sqrt(r4[3]) > tolg) {
 						// line search failed with a non-trivial W: drop the pairs and retry from the same point with W0
+						// (structured Newton mode: with the Gauss-Newton factor at x; sxt is rebuilt from x first)
 						npairs = 0;
-						apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+						if (NWT) { lds_sync(); for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; }); nwt_refresh(sxt, false); nwt_apply(sgp, sd); }
+						else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 						double r2[2] = {0, 0};
 						for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 						block_sum<NT, 2>(r2, S.red);
@@ -1358,9 +1431,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					alpha = ls_a;
 					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
 					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
-					if (npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
+					if (!NWT && npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
 					NTG_STAMP(5);
-					apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgpt, st, sxt, S.oinfo);
+					if (NWT) { nwt_refresh(sxt, true); nwt_apply(sgpt, st); }   // sxt still holds the accepted point; st (= sxt) is written last
+					else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgpt, st, sxt, S.oinfo);
 					NTG_STAMP(4);
 					// register-resident pairs: 3 coefficients per lane, 6 pairs per round; the 5-coefficient instances (config E)
 					// take 3 pairs per round
@@ -1372,7 +1446,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						r6[0] += s * y; r6[1] += y * u; r6[2] += s * gpn; r6[3] += u * gpn; r6[4] += s * s; r6[5] += y * y;
 					});
 					block_sum<NT, 6>(r6, S.red);
-					const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
+					const bool upd = !NWT && r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
 					const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
 					r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
 					for_vec<NT>(n, [&](int c) {
@@ -1420,7 +1494,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (pnorm == 0.0 || !(dphi0 < 0.0)) {
 						if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
 							npairs = 0;
-							apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+							if (NWT) { lds_sync(); for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; }); nwt_refresh(sxt, false); nwt_apply(sgp, sd); }
+							else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
 							double r2[2] = {0, 0};
 							for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 							block_sum<NT, 2>(r2, S.red);
@@ -1441,6 +1516,16 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				}
 			}
 			NTG_STAMP(5);
+			if (finished && phase0) {
+				// the pass on the objective alone is over: switch the augmented Lagrangian on (multipliers 0) and start its first pass
+				phase0 = false;
+				if (inner_inform == 4) { inform = 4; break; }
+				al.mu = 10.0;
+				npairs = 0; finished = false; inner_inform = 4; state = ST_INIT; weak = false; at_x = true;
+				lds_sync();
+				for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+				continue;
+			}
 			if (finished) {
 				if (al.mu > 0.0) {
 					// ---- multiplier / penalty update of the augmented Lagrangian ----
@@ -1464,6 +1549,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					}
 					// on exit the multipliers stay as they are: x is stationary for the augmented Lagrangian of the CURRENT
 					// multipliers, whose estimates t (al_t) are the ones consistent with it and the ones reported
+					// the estimates al_t were stored by other lanes / waves during the last evaluation (row -> lane of its
+					// breakpoint); only LDS barriers followed on some paths: drain the stores before any lane reads them
+					__syncthreads();
 					if (take && !done_al) for (int j = tid; j < nal; j += NT) al_lam[j] = al_t[j];
 					__syncthreads();   // multipliers cross lanes through HBM: full barrier
 					if (!done_al) {
@@ -1531,13 +1619,14 @@ static hipError_t launch_eval_one(const NtgDims &D, const NtgTables &T, const Sm
 	hipLaunchKernelGGL(kfn, dim3(a.grid), dim3(NT), L.total, a.st, D, T, L, a.batch, a.mode, a.x, a.f, a.g, a.c, a.jb, a.cj);
 	return hipGetLastError();
 }
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true, int CHM = 0>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true, int CHM = 0, bool NWT = false>
 static hipError_t launch_sqp_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
-	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS, CHM>;
+	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS, CHM, NWT>;
+	if (NWT && (!D.nwt_on || !a.nwtw || D.nwt_cg != Family<FAM>::CG || D.nwt_go != Family<FAM>::COUPLE || D.nwt_ngrp * 64 > NT)) return hipErrorInvalidValue;
 	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
 	hipLaunchKernelGGL(kfn, dim3(a.batch), dim3(NT), L.total, a.st, D, T, L, sp, a.batch, a.lo, a.up, a.x, a.obj, a.inf, a.it, a.nf,
-	                   a.cl, a.hist, a.alw, a.vecw);
+	                   a.cl, a.hist, a.alw, a.vecw, a.nwtw);
 	return hipGetLastError();
 }
 // the small-problem instances: 128 or 256 lanes, all vectors in LDS
@@ -1578,9 +1667,26 @@ static hipError_t launch_eval_generic(const NtgDims &D, const NtgTables &T, cons
 	if (a.nt == 512) return launch_eval_one<FAM, 0, 0, 512, 4>(D, T, L, a);
 	return hipErrorInvalidValue;
 }
+// structured Newton mode, generic instances (families that offer it: Family::COUPLE > 0)
+template <int FAM>
+static hipError_t launch_sqp_newton_generic(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
+{
+	if constexpr (Family<FAM>::COUPLE > 0) {
+		if (a.big) {
+			if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, true, true, 0, true>(D, T, L, sp, a);
+			if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, true, true, 0, true>(D, T, L, sp, a);
+			return hipErrorInvalidValue;
+		}
+		if (a.nt == 128) return launch_sqp_one<FAM, 0, 0, 128, 4, false, true, 0, true>(D, T, L, sp, a);
+		if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, false, true, 0, true>(D, T, L, sp, a);
+		if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, false, true, 0, true>(D, T, L, sp, a);
+	}
+	return hipErrorInvalidValue;
+}
 template <int FAM>
 static hipError_t launch_sqp_generic(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
+	if (sp.hessian == 2) return launch_sqp_newton_generic<FAM>(D, T, L, sp, a);
 	if (a.big) {
 		if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, true>(D, T, L, sp, a);
 		if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, true>(D, T, L, sp, a);

@@ -1,0 +1,46 @@
+"""Diagnostic (not a test): structured Newton mode (hessian = 2) of sqp_kernel against the oracle.
+python tests/tools_newton.py [O|D2|E2|D|E] [batch] [nref]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import numpy as np, torch
+import orc
+from ntg_amd import api, configs as cf
+
+which = sys.argv[1] if len(sys.argv) > 1 else "O"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+nref = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+if which == "O": spec = cf.config_O(); lo, up = cf.obstacle_bounds(B)
+if which == "D2": spec = cf.config_D(ninterv=10); lo, up = cf.quadrotor_bounds(B)
+if which == "E2": spec = cf.config_E(ninterv=20, narms=2); lo, up = cf.manipulator_bounds(B, narms=2)
+if which == "D": spec = cf.config_D(); lo, up = cf.quadrotor_bounds(B)
+if which == "E": spec = cf.config_E(); lo, up = cf.manipulator_bounds(B)
+dev = torch.device("cuda:0")
+plan = api.Plan(spec, 0)
+for hess in (2, 1):
+    x = torch.ones((B, spec.nC), dtype=torch.float64, device=dev)
+    lo_t, up_t = torch.tensor(lo, device=dev), torch.tensor(up, device=dev)
+    opts = api.default_opts(hessian=hess)
+    out = plan.solve(lo_t, up_t, x, opts)   # warm-up (plan tables, code load)
+    torch.cuda.synchronize()
+    x.fill_(1.0)
+    t0 = time.time()
+    out = plan.solve(lo_t, up_t, x, opts)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    inf = out["inform"].cpu().numpy(); it = out["iters"].cpu().numpy(); nf = out["nfev"].cpu().numpy()
+    print(f"{which} hessian={hess} batch {B}: {dt*1e3:.2f} ms -> {B/dt:.0f} traj/s; inform {np.bincount(inf)} majors mean {it.mean():.1f} max {it.max()} nfev mean {nf.mean():.1f}", flush=True)
+    if os.environ.get("NTG_AMD_STAMPS") == "1":
+        x.fill_(1.0)
+        o2 = plan.solve(lo_t, up_t, x, opts, want_lambda=True)
+        torch.cuda.synchronize()
+        tk = o2["clambda"][:, :8].cpu().numpy()
+        names = ["setup", "eval", "project", "hist/assemble", "w0/factor+solve", "rest", "ev.phase1", "ev.phase2"]
+        tot = tk[:, :6].sum(axis=1).mean()
+        print("  cycles/problem %.0f (%.1f us at 100 MHz clock)" % (tot, tot / 100.0), {n: "%.1f%%" % (100 * tk[:, i].mean() / tot) for i, n in enumerate(names)})
+    if hess == 2 and nref > 0:
+        r = orc.solve_batch(spec, lo[:nref], up[:nref], np.ones((nref, spec.nC)), orc.default_opts(hessian=2), nthreads=8)
+        obj = out["objective"].cpu().numpy()[:nref]
+        print("  oracle inform", r["inform"], "iters", r["iters"], "gpu iters", it[:nref])
+        print("  rel obj diff", np.abs(obj - r["objective"]) / np.abs(r["objective"]))
+        print("  max |x - x_orc|", np.abs(x.cpu().numpy()[:nref] - r["x"]).max(axis=1))
