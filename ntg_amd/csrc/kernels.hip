@@ -365,7 +365,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
 	{
 		// the structured Newton mode borrows this area between evaluations: solve vectors and factorisation panels of every group
 		int dfz_bytes = ((D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + ntg_dfz_tail(D)) * 8;
-		if (D.nwt_on) dfz_bytes = std::max(dfz_bytes, D.nwt_ngrp * ((16 * ((D.nwt_ng + 15) / 16) + 48) + 48 * 17) * 8);
+		if (D.nwt_on) dfz_bytes = std::max(dfz_bytes, std::max(D.nwt_ngrp * ((16 * ((D.nwt_ng + 15) / 16) + 48) + 48 * 17) * 8, (nthreads / 64) * 216 * 8));
 		L.dfz = p; L.nwt_y = p; p = align16(p + dfz_bytes);
 	}
 	L.fvals = p; p = align16(p + D.P * 8);

@@ -22,6 +22,26 @@
 #include "ntg_dev.hpp"
 
 #define NWT_PSTRIDE 17   // LDS row stride (doubles) of the 48 x 16 panel
+// The factorisation and the assembly are inlined into the solve kernel; only the triangular solves are kept out of line.
+// (With all three out of line the tuned quadrotor instance faulted on the GPU -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION
+// on a flat access -- although every index checked out; inlined, the same code runs clean.  Treated as a code-generation
+// hazard of calls under this register pressure)
+#define NWT_FN __device__ __forceinline__
+#ifdef NWT_CHECK   // debugging aid: report an out-of-range band index instead of touching memory
+#define NWT_IDX(i, lim, tag) (((long long)(i) >= 0 && (long long)(i) < (long long)(lim)) ? (size_t)(i) : (printf("NWT index %s: %lld of %lld (blk %d thr %d)\n", tag, (long long)(i), (long long)(lim), (int)blockIdx.x, (int)threadIdx.x), (size_t)0))
+#else
+#define NWT_IDX(i, lim, tag) ((size_t)(i))
+#endif
+
+// Lanes of ONE wave exchange data through LDS without a workgroup barrier (the LDS queue of a wave is processed in order).
+// The compiler has to be told: without a fence it may forward a lane's own store to its later load of the same address
+// and never see what the other lanes wrote.
+__device__ __forceinline__ void nwt_wave_sync()
+{
+	// compiler: no memory access moves across, nothing is forwarded; hardware: LDS operations done (the loads from HBM
+	// that are in flight for the next block are NOT waited for, unlike with a fence)
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
 __device__ __forceinline__ double nwt_readlane(double v, int lane)
 {
@@ -46,69 +66,106 @@ __device__ __forceinline__ nwt_d4 nwt_load_tile(const double *__restrict__ Kc, i
 	return t;
 }
 
-// Band Cholesky K = L L' of one group by ONE wavefront, in place.  panel: LDS scratch of 48 * NWT_PSTRIDE doubles owned by
-// this wave.  strict: a non-positive pivot is reported (return value 1, factor unusable); otherwise it is replaced by a tiny
-// positive number (the Gauss-Newton matrix is positive definite up to rounding).
-__device__ __attribute__((noinline)) int nwt_factor_wave(double *__restrict__ Kc, int ng, int hb, double *panel, int strict)
+// element (row, col) of the band for the accumulator-layout tile loads: no branches (the address is clamped, the value selected)
+__device__ __forceinline__ double nwt_band_get2(const double *__restrict__ Kc, int ng, int hb, int row, int col)
 {
-	const int lane = threadIdx.x & 63, ld = hb + 1, nbr = (ng + 15) >> 4;
-	const int prow = lane < 48 ? lane : 47;   // lanes 48..63 shadow row 47 (their results are never stored)
+	const bool inb = row < ng && col <= row && col >= 0 && row - col <= hb;
+	const double v = Kc[NWT_IDX(inb ? (long long)row * (hb + 1) + (col - row + hb) : 0, (long long)ng * (hb + 1), "tile")];
+	return inb ? v : ((row >= ng && row == col) ? 1.0 : 0.0);
+}
+__device__ __forceinline__ nwt_d4 nwt_load_tile2(const double *__restrict__ Kc, int ng, int hb, int I, int J, int lane)
+{
+	nwt_d4 t;
+#pragma unroll
+	for (int r = 0; r < 4; r++) t[r] = nwt_band_get2(Kc, ng, hb, 16 * I + 4 * r + (lane >> 4), 16 * J + (lane & 15));
+	return t;
+}
+
+// Band Cholesky K = L L' of one group by ONE wavefront, in place; the diagonal of the factor is stored INVERTED (1 / L_jj:
+// the triangular solves multiply).  panel: LDS scratch of 48 * NWT_PSTRIDE doubles owned by this wave.  Returns the number of
+// non-positive pivots: with strict the factor is then unusable; otherwise each was replaced by a tiny positive number
+// (the Gauss-Newton matrix is positive definite up to rounding).
+// The six window tiles stay in the accumulator layout of the matrix instruction throughout (lane l, register r <->
+// element (4 r + l/16, l%16)).  Pivot j of the 48 x 16 panel: the 12 entries of column j go to LDS (the four lanes that
+// hold them), every lane reads back the pivot, the multipliers of its rows and the multiplier of its column, and
+// applies the rank-1 update  T = keep T + c m  per element:  keep = 0, m = 1/l_jj on column j itself (scaling: those lanes
+// hold c), keep = 1, m = -l_kj / l_jj^2 on the columns k > j, m = 0 on the finished columns.
+NWT_FN int nwt_factor_wave(double *__restrict__ Kc, int ng, int hb, double *panel, int strict)
+{
+	const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
+	double *colbuf = panel, *xbuf = panel + 64;   // 48 doubles; 2 tiles of 16 x NWT_PSTRIDE
 	int fail = 0;
-	nwt_d4 T00 = nwt_load_tile(Kc, ng, hb, 0, 0, lane), T10 = nwt_load_tile(Kc, ng, hb, 1, 0, lane), T11 = nwt_load_tile(Kc, ng, hb, 1, 1, lane);
-	nwt_d4 T20 = nwt_load_tile(Kc, ng, hb, 2, 0, lane), T21 = nwt_load_tile(Kc, ng, hb, 2, 1, lane), T22 = nwt_load_tile(Kc, ng, hb, 2, 2, lane);
+	nwt_d4 T00 = nwt_load_tile2(Kc, ng, hb, 0, 0, lane), T10 = nwt_load_tile2(Kc, ng, hb, 1, 0, lane), T11 = nwt_load_tile2(Kc, ng, hb, 1, 1, lane);
+	nwt_d4 T20 = nwt_load_tile2(Kc, ng, hb, 2, 0, lane), T21 = nwt_load_tile2(Kc, ng, hb, 2, 1, lane), T22 = nwt_load_tile2(Kc, ng, hb, 2, 2, lane);
 	for (int J = 0; J < nbr; J++) {
 		// next block row of the window: in flight during the panel factorisation
-		const nwt_d4 N0 = nwt_load_tile(Kc, ng, hb, J + 3, J + 1, lane), N1 = nwt_load_tile(Kc, ng, hb, J + 3, J + 2, lane), N2 = nwt_load_tile(Kc, ng, hb, J + 3, J + 3, lane);
-		// accumulator layout -> one lane per panel row, through LDS
-#pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const int rr = 4 * r + (lane >> 4), cc = lane & 15;
-			panel[rr * NWT_PSTRIDE + cc] = T00[r];
-			panel[(16 + rr) * NWT_PSTRIDE + cc] = T10[r];
-			panel[(32 + rr) * NWT_PSTRIDE + cc] = T20[r];
-		}
-		double a[16];
-#pragma unroll
-		for (int c = 0; c < 16; c++) a[c] = panel[prow * NWT_PSTRIDE + c];
-		// column Cholesky of the 48 x 16 panel: lanes 0..15 hold the rows of the diagonal tile
+		const nwt_d4 N0 = nwt_load_tile2(Kc, ng, hb, J + 3, J + 1, lane), N1 = nwt_load_tile2(Kc, ng, hb, J + 3, J + 2, lane), N2 = nwt_load_tile2(Kc, ng, hb, J + 3, J + 3, lane);
+		double dinv = 0.0;   // 1 / l_jj of this lane's column (kept by the lanes of the diagonal element)
 #pragma unroll
 		for (int j = 0; j < 16; j++) {
-			double piv = nwt_readlane(a[j], j);
+			if (li == j) {   // column j: rows 4 r + lk of the three tiles
+#pragma unroll
+				for (int r = 0; r < 4; r++) { colbuf[4 * lk + r] = T00[r]; colbuf[16 + 4 * lk + r] = T10[r]; colbuf[32 + 4 * lk + r] = T20[r]; }
+			}
+			nwt_wave_sync();
+			double piv = colbuf[(j & 3) * 4 + (j >> 2)];
+			double c0[4], c1[4], c2[4];
+#pragma unroll
+			for (int r = 0; r < 4; r++) { c0[r] = colbuf[4 * lk + r]; c1[r] = colbuf[16 + 4 * lk + r]; c2[r] = colbuf[32 + 4 * lk + r]; }
+			const double lkj = colbuf[(li & 3) * 4 + (li >> 2)];   // raw entry (row li, column j) of the diagonal tile
 			if (!(piv > 0.0)) {
-				if (strict) fail = 1;
+				fail++;
 				piv = strict ? 1.0 : 1e-30;
 			}
-			const double rinv = 1.0 / sqrt(piv);
-			if (lane >= j) a[j] = lane == j ? piv * rinv : a[j] * rinv;
-#pragma unroll
-			for (int k = j + 1; k < 16; k++) {
-				const double lkj = nwt_readlane(a[j], k);
-				if (lane >= k) a[k] -= a[j] * lkj;
+#ifdef NWT_EXACT_SQRT
+			const double y = 1.0 / sqrt(piv);
+#else
+			// 1/sqrt(piv): hardware estimate, then two coupled Goldschmidt steps with fused residuals (g -> sqrt, h -> 1/(2 sqrt))
+			double y;
+			{
+				const double y0 = __builtin_amdgcn_rsq(piv);
+				double g = piv * y0, h = 0.5 * y0, rr = fma(-h, g, 0.5);
+				g = fma(g, rr, g); h = fma(h, rr, h);
+				rr = fma(-h, g, 0.5);
+				g = fma(g, rr, g); h = fma(h, rr, h);
+				rr = fma(-h, g, 0.5);
+				h = fma(h, rr, h);
+				y = 2.0 * h;
 			}
-		}
-		// the finished block column of L: rows to HBM (band entries only) ...
-		if (lane < 48) {
-			const int row = 16 * J + lane;
-			if (row < ng) {
+#endif
+			// column j itself is scaled (T = c y: these lanes hold c), the columns k > j get T -= c l_kj / l_jj, the finished
+			// columns stay: one multiply and one fused multiply-add per element, each result rounded once
+			const double keep = li == j ? 0.0 : 1.0;
+			const double m = li == j ? y : (li > j ? -(lkj * y) * y : 0.0);
+			if (li == j) dinv = y;
 #pragma unroll
-				for (int c = 0; c < 16; c++) {
-					const int col = 16 * J + c;
-					if (col <= row && row - col <= hb) Kc[(size_t)row * ld + (col - row + hb)] = a[c];
-				}
-			}
+			for (int r = 0; r < 4; r++) { T00[r] = fma(c0[r], m, T00[r] * keep); T10[r] = fma(c1[r], m, T10[r] * keep); T20[r] = fma(c2[r], m, T20[r] * keep); }
+			nwt_wave_sync();   // the column is consumed before the next one overwrites it
 		}
-		// ... and the two sub-diagonal tiles X1, X2 back to LDS for the operand layout of the matrix instruction:
+		// the finished block column of L to HBM (band entries only; the diagonal inverted)
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int rr = 4 * r + lk, col = 16 * J + li;
+			const int row0 = 16 * J + rr, row1 = row0 + 16, row2 = row0 + 32;
+			if (row0 < ng && col <= row0 && row0 - col <= hb) Kc[NWT_IDX((long long)row0 * ld + (col - row0 + hb), (long long)ng * ld, "st0")] = rr == li ? dinv : T00[r];
+			if (row1 < ng && row1 - col <= hb) Kc[NWT_IDX((long long)row1 * ld + (col - row1 + hb), (long long)ng * ld, "st1")] = T10[r];
+			if (row2 < ng && row2 - col <= hb) Kc[NWT_IDX((long long)row2 * ld + (col - row2 + hb), (long long)ng * ld, "st2")] = T20[r];
+		}
+		// the two sub-diagonal tiles X1, X2 through LDS into the operand layout of the matrix instruction:
 		// lane l supplies X[l%16][4 s + l/16] both as A[i][k] and as B[k][j] = X'[k][j]
-		if (lane >= 16 && lane < 48) {
 #pragma unroll
-			for (int c = 0; c < 16; c++) panel[lane * NWT_PSTRIDE + c] = a[c];
+		for (int r = 0; r < 4; r++) {
+			xbuf[(4 * r + lk) * NWT_PSTRIDE + li] = T10[r];
+			xbuf[(16 + 4 * r + lk) * NWT_PSTRIDE + li] = T20[r];
 		}
+		nwt_wave_sync();
 		double x1[4], x2[4];
 #pragma unroll
 		for (int s = 0; s < 4; s++) {
-			x1[s] = panel[(16 + (lane & 15)) * NWT_PSTRIDE + 4 * s + (lane >> 4)];
-			x2[s] = panel[(32 + (lane & 15)) * NWT_PSTRIDE + 4 * s + (lane >> 4)];
+			x1[s] = xbuf[li * NWT_PSTRIDE + 4 * s + lk];
+			x2[s] = xbuf[(16 + li) * NWT_PSTRIDE + 4 * s + lk];
 		}
+		nwt_wave_sync();
 #pragma unroll
 		for (int s = 0; s < 4; s++) {
 			T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s], x1[s], T11, 0, 0, 0);
@@ -132,12 +189,12 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(const double *__restric
 #pragma unroll
 			for (int u = 0; u < 8; u++) {   // entries left of the diagonal block: columns R - hb + e < 16 J  <=>  e < hb - q
 				const int e = part + 4 * u, col = R - hb + e;
-				o[u] = (R < ng && e < hb - q && col >= 0) ? Lc[(size_t)R * ld + e] : 0.0;
+				o[u] = (R < ng && e < hb - q && col >= 0) ? Lc[NWT_IDX((long long)R * ld + e, (long long)ng * ld, "fo")] : 0.0;
 			}
 #pragma unroll
 			for (int c = 0; c < 16; c++) {   // row R of the diagonal block (every part loads it: the values are lane-uniform per q)
 				const int e = hb - (q - c);
-				lr[c] = (R < ng && c <= q && e >= 0) ? Lc[(size_t)R * ld + e] : (c == q ? 1.0 : 0.0);
+				lr[c] = (R < ng && c <= q && e >= 0) ? Lc[NWT_IDX((long long)R * ld + e, (long long)ng * ld, "fd")] : (c == q ? 1.0 : 0.0);
 			}
 		};
 		load(0, off, lrow);
@@ -147,17 +204,18 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(const double *__restric
 			const int R = 16 * J + q;
 			double acc = 0.0;
 #pragma unroll
-			for (int u = 0; u < 8; u++) { const int col = R - hb + part + 4 * u; acc += off[u] * y[col >= 0 ? col : 0]; }
+			for (int u = 0; u < 8; u++) { const int col = R - hb + part + 4 * u; acc += off[u] * y[NWT_IDX(col >= 0 ? col : 0, 16 * nbr + 48, "y1")]; }
 			acc += lane_xchg<16>(acc);
 			acc += lane_xchg<32>(acc);
-			double r = y[R] - acc;
+			double r = y[NWT_IDX(R, 16 * nbr + 48, "y2")] - acc;
 #pragma unroll
 			for (int j = 0; j < 16; j++) {
-				if (q == j) r = r / lrow[j];
+				if (q == j) r = r * lrow[j];   // the diagonal is stored inverted
 				const double yj = nwt_readlane(r, j);
 				if (q > j) r -= lrow[j] * yj;
 			}
 			if (part == 0) y[R] = r;
+			nwt_wave_sync();
 			if (J + 1 < nbr) {
 #pragma unroll
 				for (int u = 0; u < 8; u++) off[u] = offn[u];
@@ -174,12 +232,12 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(const double *__restric
 #pragma unroll
 			for (int u = 0; u < 8; u++) {   // rows below the diagonal block: j = 16 J + 16 + part + 4 u,  j - i <= hb
 				const int j = 16 * J + 16 + part + 4 * u;
-				o[u] = (j < ng && j - i <= hb) ? Lc[(size_t)j * ld + (i - j + hb)] : 0.0;
+				o[u] = (j < ng && j - i <= hb) ? Lc[NWT_IDX((long long)j * ld + (i - j + hb), (long long)ng * ld, "bo")] : 0.0;
 			}
 #pragma unroll
 			for (int c = 0; c < 16; c++) {   // column q of the diagonal block: L[16 J + c][16 J + q], c >= q
 				const int j = 16 * J + c, e = hb - (c - q);
-				lc[c] = (j < ng && c >= q && e >= 0) ? Lc[(size_t)j * ld + e] : (c == q ? 1.0 : 0.0);
+				lc[c] = (j < ng && c >= q && e >= 0) ? Lc[NWT_IDX((long long)j * ld + e, (long long)ng * ld, "bd")] : (c == q ? 1.0 : 0.0);
 			}
 		};
 		load(nbr - 1, off, lcol);
@@ -189,17 +247,18 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(const double *__restric
 			const int i = 16 * J + q;
 			double acc = 0.0;
 #pragma unroll
-			for (int u = 0; u < 8; u++) acc += off[u] * y[16 * J + 16 + part + 4 * u];
+			for (int u = 0; u < 8; u++) acc += off[u] * y[NWT_IDX(16 * J + 16 + part + 4 * u, 16 * nbr + 48, "y3")];
 			acc += lane_xchg<16>(acc);
 			acc += lane_xchg<32>(acc);
-			double r = y[i] - acc;
+			double r = y[NWT_IDX(i, 16 * nbr + 48, "y4")] - acc;
 #pragma unroll
 			for (int j = 15; j >= 0; j--) {
-				if (q == j) r = r / lcol[j];
+				if (q == j) r = r * lcol[j];   // the diagonal is stored inverted
 				const double zj = nwt_readlane(r, j);
 				if (q < j) r -= lcol[j] * zj;
 			}
 			if (part == 0) y[i] = r;
+			nwt_wave_sync();
 			if (J > 0) {
 #pragma unroll
 				for (int u = 0; u < 8; u++) off[u] = offn[u];
@@ -210,53 +269,99 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(const double *__restric
 	}
 }
 
-// K (compact band, every group) = cost model + sum over the breakpoints of M_i' B_i M_i; every lane takes band entries.
-// Bz: [ngrp][P][cg*cg] of this problem, or nullptr (cost model alone: phase 0, mu == 0).
+// K (compact band, every group) = cost model + sum over the breakpoints of M_i' B_i M_i, on the matrix cores.
+// The breakpoints of one knot interval share their block of k Go coefficients, so their contribution is one small dense
+// product  S (kg x kg) = Mst' V,  Mst = the collocation rows of the interval's breakpoints stacked (cnt cg x kg),
+// V = blockdiag(B_i) Mst:  v_mfma_f64_16x16x4_f64 tiles, operands formed on the fly from the channel tables in LDS and
+// the blocks B_i.  A wave takes whole (group, interval) items; intervals of one colour share no coefficient, so the
+// read-modify-write of the band needs no atomics and the sum is deterministic.  Per item there is ONE round trip to
+// HBM/L2: the interval's blocks (one coalesced load, staged in LDS) and the band entries the result is added to are
+// requested together, before the products.
+// Bz: [ngrp][P][cg*cg] of this problem, or nullptr (cost model alone: phase 0, mu == 0).  wbuf: LDS, 216 doubles per wave.
 template <int NT>
-__device__ __attribute__((noinline)) void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *rowv, const int *chrow, const int *offt,
-                                                       const int *tcomp, const double *__restrict__ Bz, double *__restrict__ Kc)
+NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *rowv, const int *chrow, const int *offt,
+                                                       const double *__restrict__ Bz, double *__restrict__ Kc, double *wbuf_all)
 {
-	const int ng = D.nwt_ng, hb = D.nwt_hb, ld = hb + 1, go = D.nwt_go, cg = D.nwt_cg, nco = D.ncoef[0], P = D.P, dm = D.d[0];
-	const int per = ng * ld, total = D.nwt_ngrp * per;
-	for (int e0 = threadIdx.x; e0 < total; e0 += NT) {
-		const int g = e0 / per, rem = e0 - g * per, p = rem / ld, e = rem - p * ld, p2 = p - hb + e;
-		double acc = 0.0;
-		if (p2 >= 0) {
-			acc = T.nwt_k0[e0];
-			if (Bz) {
-				const int c1 = T.nwt_map[g * ng + p], c2 = T.nwt_map[g * ng + p2];
-				const int o1 = c1 / nco, cl1 = c1 - o1 * nco, o2 = c2 / nco, cl2 = c2 - o2 * nco;
-				const int lo = max((int)T.nwt_lo[cl1], (int)T.nwt_lo[cl2]), hi = min((int)T.nwt_hi[cl1], (int)T.nwt_hi[cl2]);
-				const double *Bg = Bz + (size_t)g * P * cg * cg;
-				// the (derivative of output 1, derivative of output 2) pairs that carry a constraint flag entry: at most 4 are
-				// taken per sweep over the breakpoints (quadrotor: velocity / acceleration of both outputs; one otherwise)
-				int nc = 0, r1n = 0, r2n = 0;
-				while (r1n < dm) {
-					int ro1[4], ro2[4], bi[4];
-					nc = 0;
-					for (; r1n < dm && nc < 4; r1n++, r2n = 0) {
-						const int a1 = tcomp[dm * o1 + r1n];
-						if (a1 < 0) continue;
-						for (; r2n < dm && nc < 4; r2n++) {
-							const int a2 = tcomp[dm * o2 + r2n];
-							if (a2 < 0) continue;
-							ro1[nc] = chrow[r1n] + cl1 * P; ro2[nc] = chrow[r2n] + cl2 * P; bi[nc] = (a1 - g * cg) * cg + (a2 - g * cg);
-							nc++;
-						}
-						if (r2n < dm) break;   // the sweep is full: resume at (r1n, r2n)
-					}
-#pragma unroll 4
-					for (int i = lo; i < hi; i++) {
-						const int sh = i - offt[i] * P;   // rowv[ch + (cl - off_i) P + i]
-						const double *Bi = Bg + (size_t)i * cg * cg;
+	constexpr int NW = NT / 64;
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+	const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ld = hb + 1, go = D.nwt_go, cg = D.nwt_cg, P = D.P;
+	const int kg = D.order[0] * go, cover = D.nwt_cover, nint = D.nwt_nint, total = ngp * ng * ld, clo = D.nwt_clo, chi = D.nwt_chi;
+	const u64 upack = D.nwt_upack;
+	for (int e = tid; e < total; e += NT) Kc[e] = T.nwt_k0[e];
+	__syncthreads();
+	if (!Bz) return;
+	double *wbuf = wbuf_all + wave * 216;
+	// the two local columns (block-coefficient index a = q go + o) this lane stands for in the operand tiles
+	const int a0 = li, a1 = 16 + li;
+	const int qa0 = a0 / go, oa0 = a0 - qa0 * go, qa1 = a1 / go, oa1 = a1 - qa1 * go;
+	const bool va0 = a0 < kg, va1 = a1 < kg;
+	// ... and the rows of its four accumulator registers
+	int qr0[4], or0[4], qr1[4], or1[4];
 #pragma unroll
-						for (int u = 0; u < 4; u++)
-							if (u < nc) acc += rowv[ro1[u] + sh] * Bi[bi[u]] * rowv[ro2[u] + sh];
-					}
-				}
+	for (int r = 0; r < 4; r++) { const int ar0 = 4 * r + lk, ar1 = 16 + ar0; qr0[r] = ar0 / go; or0[r] = ar0 - qr0[r] * go; qr1[r] = ar1 / go; or1[r] = ar1 - qr1[r] * go; }
+	for (int color = 0; color < cover; color++) {
+		const int ntc = (nint - color + cover - 1) / cover;   // intervals of this colour
+		for (int w = wave; w < ngp * ntc; w += NW) {
+			const int g = w / ntc, t = color + (w - g * ntc) * cover;
+			const int bp0 = D.nwt_igb[t], cnt = D.nwt_igb[t + 1] - bp0, of = offt[bp0];
+			const int kdim = cnt * cg, ksteps = (kdim + 3) >> 2, nb = cnt * cg * cg;
+			// requests: the interval's blocks ...
+			const double *Bsrc = Bz + ((size_t)g * P + bp0) * cg * cg;
+			double bl[4];
+#pragma unroll
+			for (int u = 0; u < 4; u++) bl[u] = lane + 64 * u < nb ? Bsrc[lane + 64 * u] : 0.0;
+			// ... and the band entries of the lower triangle of S: local index a -> free index p = (of + a/go - clo) go + a%go
+			double *Kg = Kc + (size_t)g * ng * ld;
+			const int cb0 = of + qa0, cb1 = of + qa1;
+			const bool fb0 = va0 && cb0 >= clo && cb0 < chi, fb1 = va1 && cb1 >= clo && cb1 < chi;
+			const int pb0 = (cb0 - clo) * go + oa0, pb1 = (cb1 - clo) * go + oa1;
+			int idx[12]; double kv[12];
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int cr0 = of + qr0[r], cr1 = of + qr1[r];
+				const bool fr0 = 4 * r + lk < kg && cr0 >= clo && cr0 < chi, fr1 = 16 + 4 * r + lk < kg && cr1 >= clo && cr1 < chi;
+				const int pr0 = (cr0 - clo) * go + or0[r], pr1 = (cr1 - clo) * go + or1[r];
+				idx[3 * r] = (fr0 && fb0 && pr0 >= pb0) ? pr0 * ld + (pb0 - pr0 + hb) : -1;
+				idx[3 * r + 1] = (fr1 && fb0) ? pr1 * ld + (pb0 - pr1 + hb) : -1;
+				idx[3 * r + 2] = (fr1 && fb1 && pr1 >= pb1) ? pr1 * ld + (pb1 - pr1 + hb) : -1;
 			}
+#pragma unroll
+			for (int e = 0; e < 12; e++) kv[e] = Kg[NWT_IDX(idx[e] >= 0 ? idx[e] : 0, (long long)ng * ld, "asm")];
+#pragma unroll
+			for (int u = 0; u < 4; u++) if (lane + 64 * u < 216) wbuf[lane + 64 * u] = bl[u];
+			nwt_wave_sync();
+			nwt_d4 S00 = {0.0, 0.0, 0.0, 0.0}, S10 = {0.0, 0.0, 0.0, 0.0}, S11 = {0.0, 0.0, 0.0, 0.0};
+			for (int s = 0; s < ksteps; s++) {
+				const int kk = 4 * s + lk;
+				const bool kvd = kk < kdim;
+				const int bi = kvd ? kk / cg : 0, u = kvd ? kk - bi * cg : 0, bp = bp0 + bi;
+				const int ou = (int)((upack >> (8 * u + 4)) & 15u), ru = (int)((upack >> (8 * u)) & 15u);
+				const double *rvu = rowv + NWT_IDX(chrow[ru] + bp, D.row_total, "rvu");
+				// A[a][kk] = Mst[kk][a]: the basis value of derivative ru at the breakpoint, if column a belongs to output ou
+				const double A0 = (kvd && va0 && oa0 == ou) ? rvu[qa0 * P] : 0.0;
+				const double A1 = (kvd && va1 && oa1 == ou) ? rvu[qa1 * P] : 0.0;
+				// B[kk][b] = V[kk][b] = sum_v B_i[u][v] Mst_i[v][b]
+				double B0 = 0.0, B1 = 0.0;
+				const double *Bi = wbuf + NWT_IDX((bi * cg + u) * cg, 216, "wbuf");
+				for (int v = 0; v < cg; v++) {
+					const int ov = (int)((upack >> (8 * v + 4)) & 15u), rv2 = (int)((upack >> (8 * v)) & 15u);
+					const double bb = kvd ? Bi[v] : 0.0;
+					const double *rvv = rowv + NWT_IDX(chrow[rv2] + bp, D.row_total, "rvv");
+					if (va0 && ov == oa0) B0 += bb * rvv[qa0 * P];
+					if (va1 && ov == oa1) B1 += bb * rvv[qa1 * P];
+				}
+				S00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, B0, S00, 0, 0, 0);
+				S10 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, B0, S10, 0, 0, 0);
+				S11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, B1, S11, 0, 0, 0);
+			}
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				if (idx[3 * r] >= 0) Kg[idx[3 * r]] = kv[3 * r] + S00[r];
+				if (idx[3 * r + 1] >= 0) Kg[idx[3 * r + 1]] = kv[3 * r + 1] + S10[r];
+				if (idx[3 * r + 2] >= 0) Kg[idx[3 * r + 2]] = kv[3 * r + 2] + S11[r];
+			}
+			nwt_wave_sync();   // the staged blocks are consumed before the next item overwrites them
 		}
-		Kc[e0] = acc;
+		__syncthreads();
 	}
-	(void)go;
 }

@@ -45,6 +45,13 @@ struct NtgDims {
 	// structured Newton mode (newton.hpp): coupling groups of nwt_go outputs, nwt_ng free coefficients each (interleaved by
 	// output), half bandwidth nwt_hb, nwt_cg constraint flag entries per group; nwt_on = 0: the plan does not qualify
 	int nwt_on, nwt_ngrp, nwt_go, nwt_ng, nwt_hb, nwt_cg;
+	// breakpoint groups (consecutive breakpoints with the same block offset = one knot interval), how many consecutive
+	// groups overlap a coefficient (colours of the assembly), and the constraint flag entries of a group packed one byte
+	// each: (output within the group) << 4 | derivative
+	int nwt_nint, nwt_cover;
+	u64 nwt_upack;
+	int nwt_clo, nwt_chi;               // the free local coefficients of every output: [clo, chi); free index p = (cl - clo) go + o
+	unsigned short nwt_igb[66];         // first breakpoint of every group, nwt_igb[nint] = P
 };
 
 struct NtgTables {

@@ -471,6 +471,31 @@ static int build_newton_tables(ntg_plan *p)
 	}
 	if (D.nicf) add(p->icostav, 0, 2.0);
 	if (D.nfcf) add(p->fcostav, P - 1, 2.0);
+	// breakpoint groups and colours; constraint flag entries of a group
+	std::vector<int> ig;
+	for (int i = 0; i < P;) { int j = i; while (j < P && off[j] == off[i]) j++; ig.push_back(i); ig.push_back(j - i); i = j; }
+	const int nint = (int)ig.size() / 2;
+	int cover = 1;
+	for (int cl = 0; cl < nco; cl++) { int cnt = 0; for (int t = 0; t < nint; t++) { const int of = off[ig[2 * t]]; if (cl >= of && cl < of + k) cnt++; } cover = std::max(cover, cnt); }
+	for (int t = 0; t + cover < nint; t++) if (off[ig[2 * (t + cover)]] < off[ig[2 * t]] + k) return 0;   // same-colour groups must not share coefficients
+	u64 upack = 0;
+	{
+		int u = 0;
+		for (int o = 0; o < go; o++) for (int r = 0; r < dm; r++) if ((gmask >> (dm * o + r)) & 1ull) { upack |= (u64)((o << 4) | r) << (8 * u); u++; }
+		if (u != cg || cg > 8) return 0;
+	}
+	if (nint > 64) return 0;
+	for (int t = 0; t < nint; t++) { D.nwt_igb[t] = (unsigned short)ig[2 * t]; if (ig[2 * t + 1] > 6) return 0; }   // at most 6 breakpoints per knot interval
+	D.nwt_igb[nint] = (unsigned short)P;
+	D.nwt_nint = nint; D.nwt_cover = cover; D.nwt_upack = upack;
+	// the free coefficients must be the same contiguous range [clo, chi) of every output (pinned ends)
+	{
+		int clo = -1, chi = -1;
+		for (int cl = 0; cl < nco; cl++) if (!pinned[D.iC[0] + cl]) { if (clo < 0) clo = cl; chi = cl + 1; }
+		if (clo < 0) return 0;
+		for (int o = 0; o < D.nout; o++) for (int cl = 0; cl < nco; cl++) if ((bool)pinned[D.iC[o] + cl] != !(cl >= clo && cl < chi)) return 0;
+		D.nwt_clo = clo; D.nwt_chi = chi;
+	}
 	int *d_map = nullptr, *d_pos = nullptr; double *d_k0 = nullptr; short *d_lo = nullptr, *d_hi = nullptr;
 	if (dev_upload(&d_map, map.data(), map.size(), p->owned) || dev_upload(&d_pos, pos.data(), pos.size(), p->owned) ||
 	    dev_upload(&d_k0, k0.data(), k0.size(), p->owned) || dev_upload(&d_lo, lo.data(), lo.size(), p->owned) ||

@@ -1214,6 +1214,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	double *nwt_K = NWT ? nwt_all + (size_t)b * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (size_t)D.nwt_ngrp * D.P * NWT_CG2) : nullptr;
 	double *nwt_B = NWT ? nwt_K + (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) : nullptr;
 	bool nwt_curv = false;        // the current factor includes the constraint curvature
+	int nwt_bad = 0;              // diagnostic: non-positive pivots replaced in Gauss-Newton factorisations (wave 0's count)
 	bool phase0 = NWT && alprob;  // the pass on the objective alone is still running
 	int *nwt_flag = (int *)(smem_raw + L.red) + 2 * 16 * (NT / 64 + 1) - 2;   // last word pair of the reduction scratch: "not positive definite"
 	// K = model at the trial point buffer `xs` (must be the iterate x; needs the multiplier estimates al_t of the evaluation
@@ -1241,15 +1242,17 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				}
 				__syncthreads();
 			}
-			nwt_assemble<NT>(D, T, S.rowv, S.chrow, S.off, S.tcomp, al.mu > 0.0 ? nwt_B : nullptr, nwt_K);
+			if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[6] += now_ - tlast; tlast = now_; }
 			if (tid == 0) nwt_flag[0] = 0;
-			__syncthreads();
+			nwt_assemble<NT>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y));   // ends with a full barrier
 			NTG_STAMP(3);
 			if (wave < ngp) {
 				const int f = nwt_factor_wave(nwt_K + (size_t)wave * ng * (hb + 1), ng, hb, panel + (size_t)wave * 48 * NWT_PSTRIDE, curv ? 1 : 0);
-				if (f && (tid & 63) == 0) nwt_flag[0] = 1;
+				if (f && curv && (tid & 63) == 0) nwt_flag[0] = 1;
+				if (f && !curv) nwt_bad += f;
 			}
 			__syncthreads();
+			if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[7] += now_ - tlast; tlast = now_; }
 			nwt_curv = curv;
 			if (nwt_flag[0] == 0) break;
 		}
@@ -1271,6 +1274,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			out[c] = pos >= 0 ? yv[(pos / ng) * ylen + (pos % ng)] : 0.0;
 		}
 		if (BIG) __syncthreads(); else lds_sync();
+		// the area borrowed from the weighted-gradient rows goes back with its zero padding restored (stage_tables)
+		for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;
+		for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[(D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + i] = 0.0;
+		lds_sync();
 	};
 	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};
 	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
@@ -1341,7 +1348,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			// The evaluation leaves its four sums (quadrature, |g|^2, penalty, violation) as per-lane partials; the
 			// projection pass adds the slope of the line search, and ONE workgroup reduction serves all five.
 			double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, gdummy;
-			(void)eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gdummy, cm, al, nullptr, nullptr, sp.stamps ? tk : nullptr,
+			(void)eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gdummy, cm, al, nullptr, nullptr, (sp.stamps && !NWT) ? tk : nullptr,
 			                                                        LIN ? &lin : nullptr, CHM != 0, part);
 			NTG_STAMP(1);
 			if (state != ST_FINAL && state != ST_REEVAL) {
@@ -1596,7 +1603,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		if (sp.stamps == 1 && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
 		if (sp.stamps == 2 && tid == 0) {   // diagnostic: state of the augmented-Lagrangian loop at exit
 			double *o = clambda + (size_t)b * ntot;
-			o[0] = sqrt(rv2); o[1] = al.mu; o[2] = outer; o[3] = sri; o[4] = rvprev; o[5] = inner_inform; o[6] = mfres; o[7] = F;
+			o[0] = sqrt(rv2); o[1] = al.mu; o[2] = outer; o[3] = sri; o[4] = rvprev; o[5] = inner_inform; o[6] = NWT ? (double)nwt_bad : mfres; o[7] = F;
 		}
 	}
 #undef NTG_STAMP

@@ -1,0 +1,67 @@
+// nwt_unit.hip -- GPU unit check of the band Cholesky / triangular solves of ntg_amd/csrc/newton.hpp against a host band
+// Cholesky (test infrastructure: built and run by tests/test_gpu_newton.py on the GPU box).
+//   usage: nwt_unit <ng> <hb>    prints "max rel err factor-solve: X" and exits 0 when X < 1e-9
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include "../../ntg_amd/csrc/solve_impl.hpp"
+
+__global__ void unit_kernel(double *K, int ng, int hb, double *yio, int *fail)
+{
+	extern __shared__ double sm[];
+	double *y = sm, *panel = sm + 16 * ((ng + 15) / 16) + 48;
+	const int ylen = 16 * ((ng + 15) / 16) + 48;
+	for (int i = threadIdx.x; i < ylen; i += 64) y[i] = i < ng ? yio[i] : 0.0;
+	__syncthreads();
+	const int f = nwt_factor_wave(K, ng, hb, panel, 1);
+	__syncthreads();
+	nwt_solve_wave(K, ng, hb, y);
+	__syncthreads();
+	for (int i = threadIdx.x; i < ng; i += 64) yio[i] = y[i];
+	if (threadIdx.x == 0) *fail = f;
+}
+
+int main(int argc, char **argv)
+{
+	const int ng = argc > 1 ? atoi(argv[1]) : 100, hb = argc > 2 ? atoi(argv[2]) : 17, ld = hb + 1;
+	const double spread = argc > 3 ? atof(argv[3]) : 0.0;   // decades of symmetric diagonal scaling D K D (ill conditioning)
+	std::vector<double> K((size_t)ng * ld, 0.0), rhs(ng), x(ng);
+	srand(7);
+	auto rnd = [] { return rand() / (double)RAND_MAX - 0.5; };
+	// SPD band: random symmetric band + dominant diagonal
+	for (int i = 0; i < ng; i++) for (int e = 0; e <= hb; e++) { const int j = i - hb + e; if (j < 0) continue; K[(size_t)i * ld + e] = (j == i) ? 2.0 * (hb + 1) + rnd() : rnd(); }
+	{
+		std::vector<double> sc(ng);
+		for (int i = 0; i < ng; i++) sc[i] = pow(10.0, spread * rnd());
+		for (int i = 0; i < ng; i++) for (int e = 0; e <= hb; e++) { const int j = i - hb + e; if (j >= 0) K[(size_t)i * ld + e] *= sc[i] * sc[j]; }
+	}
+	for (int i = 0; i < ng; i++) rhs[i] = rnd();
+	// host reference: dense Cholesky solve
+	std::vector<double> A((size_t)ng * ng, 0.0);
+	for (int i = 0; i < ng; i++) for (int e = 0; e <= hb; e++) { const int j = i - hb + e; if (j < 0) continue; A[(size_t)i * ng + j] = K[(size_t)i * ld + e]; A[(size_t)j * ng + i] = K[(size_t)i * ld + e]; }
+	std::vector<double> L(A);
+	for (int j = 0; j < ng; j++) {
+		double d = L[(size_t)j * ng + j];
+		for (int k = 0; k < j; k++) d -= L[(size_t)j * ng + k] * L[(size_t)j * ng + k];
+		d = sqrt(d); L[(size_t)j * ng + j] = d;
+		for (int i = j + 1; i < ng; i++) { double s = L[(size_t)i * ng + j]; for (int k = 0; k < j; k++) s -= L[(size_t)i * ng + k] * L[(size_t)j * ng + k]; L[(size_t)i * ng + j] = s / d; }
+	}
+	x = rhs;
+	for (int i = 0; i < ng; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[(size_t)i * ng + k] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
+	for (int i = ng - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < ng; k++) s -= L[(size_t)k * ng + i] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
+	double *dK, *dy; int *df;
+	hipMalloc(&dK, K.size() * 8); hipMalloc(&dy, ng * 8); hipMalloc(&df, 4);
+	hipMemcpy(dK, K.data(), K.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dy, rhs.data(), ng * 8, hipMemcpyHostToDevice);
+	const size_t lds = (size_t)(16 * ((ng + 15) / 16) + 48 + 48 * NWT_PSTRIDE) * 8;
+	hipLaunchKernelGGL(unit_kernel, dim3(1), dim3(64), lds, 0, dK, ng, hb, dy, df);
+	std::vector<double> y(ng), Lg(K.size()); int fail = -1;
+	if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
+	hipMemcpy(y.data(), dy, ng * 8, hipMemcpyDeviceToHost); hipMemcpy(&fail, df, 4, hipMemcpyDeviceToHost); hipMemcpy(Lg.data(), dK, K.size() * 8, hipMemcpyDeviceToHost);
+	double errL = 0.0, err = 0.0, nx = 0.0;
+	for (int i = 0; i < ng; i++) for (int e = 0; e <= hb; e++) { const int j = i - hb + e; if (j < 0) continue; const double ref = (i == j) ? 1.0 / L[(size_t)i * ng + i] : L[(size_t)i * ng + j]; errL = fmax(errL, fabs(Lg[(size_t)i * ld + e] - ref) / fabs(ref)); }
+	for (int i = 0; i < ng; i++) { err = fmax(err, fabs(y[i] - x[i])); nx = fmax(nx, fabs(x[i])); }
+	printf("ng %d hb %d fail %d: max rel err factor %.3e, max rel err factor-solve: %.3e\n", ng, hb, fail, errL, err / nx);
+	return (fail == 0 && err / nx < 1e-9 && errL < 1e-9) ? 0 : 1;
+}

@@ -36,8 +36,16 @@ for hess in (2, 1):
         torch.cuda.synchronize()
         tk = o2["clambda"][:, :8].cpu().numpy()
         names = ["setup", "eval", "project", "hist/assemble", "w0/factor+solve", "rest", "ev.phase1", "ev.phase2"]
-        tot = tk[:, :6].sum(axis=1).mean()
+        if hess == 2: names = ["setup", "eval", "project", "assemble", "solve", "rest", "Bpass", "factor"]
+        tot = tk[:, :6].sum(axis=1).mean() + (tk[:, 6:8].sum(axis=1).mean() if hess == 2 else 0.0)
         print("  cycles/problem %.0f (%.1f us at 100 MHz clock)" % (tot, tot / 100.0), {n: "%.1f%%" % (100 * tk[:, i].mean() / tot) for i, n in enumerate(names)})
+    if os.environ.get("NTG_AMD_STAMPS") == "2" and hess == 2:
+        x.fill_(1.0)
+        o2 = plan.solve(lo_t, up_t, x, opts, want_lambda=True)
+        torch.cuda.synchronize()
+        dd = o2["clambda"][:, :8].cpu().numpy()
+        print("  diag [rv, mu, outer, sri, rvprev, inner_inform, bad pivots, F]:")
+        for row in dd[:12]: print("   ", " ".join("%.3g" % v for v in row))
     if hess == 2 and nref > 0:
         r = orc.solve_batch(spec, lo[:nref], up[:nref], np.ones((nref, spec.nC)), orc.default_opts(hessian=2), nthreads=8)
         obj = out["objective"].cpu().numpy()[:nref]
