@@ -202,6 +202,44 @@ orc_nlic_t orc_family_nlicf(int fam) { return fam == 2 ? tf_nlicf : NULL; }
 orc_nltc_t orc_family_nltcf(int fam) { return fam == 2 ? tf_nltcf : fam == 3 ? obs_nltcf : fam == 4 ? quad_nltcf : fam == 5 ? manip_nltcf : NULL; }
 orc_nlic_t orc_family_nlfcf(int fam) { return fam == 2 ? tf_nlfcf : NULL; }
 
+/* test hook: the constraint Hessian callbacks against central differences of the Jacobian callbacks at one flag z
+ * (zflat: nout x maxderiv, row-major), multipliers t; returns max |Hz - FD| / max(1, |Hz|) over the three kinds */
+double orc_family_check_hess(int fam, int nout, int maxderiv, const double *zflat, const double *t)
+{
+	const int nz = nout * maxderiv;
+	double *z = malloc(nz * sizeof(double)), *Hz = calloc((size_t)nz * nz, sizeof(double)), *dcp = malloc(16 * nz * sizeof(double)), *dcm = malloc(16 * nz * sizeof(double));
+	double **zp = malloc(nout * sizeof(double *)), *rowp[16], *rowm[16], cdum[16], worst = 0.0, scale = 1.0;
+	int kind, o, v, w, j, i0 = 0, md = 1, ns = 0;
+	orc_family_set_nout(nout);
+	for (o = 0; o < nout; o++) zp[o] = z + o * maxderiv;
+	for (j = 0; j < 16; j++) { rowp[j] = dcp + (size_t)j * nz; rowm[j] = dcm + (size_t)j * nz; }
+	for (kind = 0; kind < 3; kind++) {
+		orc_nlhess_t hf = kind == 0 ? orc_family_nlic_hess(fam) : kind == 1 ? orc_family_nltc_hess(fam) : orc_family_nlfc_hess(fam);
+		orc_nlic_t cf = kind == 0 ? orc_family_nlicf(fam) : kind == 2 ? orc_family_nlfcf(fam) : NULL;
+		orc_nltc_t tf = kind == 1 ? orc_family_nltcf(fam) : NULL;
+		const int ncon = kind == 1 ? (fam == 2 ? 2 : fam == 3 ? 1 : fam == 4 ? 2 : fam == 5 ? nout / 3 : 0) : (fam == 2 ? 1 : 0);
+		if (!hf || ncon == 0) continue;
+		memcpy(z, zflat, nz * sizeof(double));
+		memset(Hz, 0, (size_t)nz * nz * sizeof(double));
+		hf(&i0, t, Hz, zp);
+		for (v = 0; v < nz * nz; v++) if (fabs(Hz[v]) > scale) scale = fabs(Hz[v]);
+		for (w = 0; w < nz; w++) {
+			const double h = 1e-5 * (1.0 + fabs(zflat[w]));
+			memcpy(z, zflat, nz * sizeof(double)); z[w] = zflat[w] + h;
+			md = 1; if (tf) tf(&md, &ns, &i0, cdum, rowp, zp); else cf(&md, &ns, cdum, rowp, zp);
+			z[w] = zflat[w] - h;
+			md = 1; if (tf) tf(&md, &ns, &i0, cdum, rowm, zp); else cf(&md, &ns, cdum, rowm, zp);
+			for (v = 0; v < nz; v++) {
+				double fd = 0.0;
+				for (j = 0; j < ncon; j++) fd += t[j] * (rowp[j][v] - rowm[j][v]) / (2.0 * h);
+				if (fabs(fd - Hz[v * nz + w]) > worst) worst = fabs(fd - Hz[v * nz + w]);
+			}
+		}
+	}
+	free(z); free(Hz); free(dcp); free(dcm); free(zp);
+	return worst / scale;
+}
+
 /* ---------------- batched CPU driver ---------------- */
 static double **rows_view(const double *flat, int nrows, int ncols)
 {
@@ -226,6 +264,10 @@ static orc_problem *make_from_spec(const orc_batch_spec *s, const double *lowerb
 		s->nicostav, (orc_AV *)s->icostav, s->ntcostav, (orc_AV *)s->tcostav, s->nfcostav, (orc_AV *)s->fcostav);
 	free(lic); free(ltc); free(lfc);
 	p->nlic_hess = orc_family_nlic_hess(s->family); p->nltc_hess = orc_family_nltc_hess(s->family); p->nlfc_hess = orc_family_nlfc_hess(s->family);
+	/* the same table as build_newton_tables() of the product (ntg_amd/csrc/plan.cpp) */
+	if (s->family == ORC_FAM_OBSTACLE) { p->couple = 2; p->group_mask = (1ull << 0) | (1ull << 3); }
+	else if (s->family == ORC_FAM_QUADROTOR) { p->couple = 4; p->group_mask = (1ull << 1) | (1ull << 2) | (1ull << 6) | (1ull << 7) | (1ull << 11) | (1ull << 12); }
+	else if (s->family == ORC_FAM_MANIP) { p->couple = 3; p->group_mask = (1ull << 0) | (1ull << 3) | (1ull << 6); }
 	return p;
 }
 static int spec_nb(const orc_batch_spec *s) { return s->nlic + s->nltc + s->nlfc + s->nnlic + s->nnltc + s->nnlfc; }

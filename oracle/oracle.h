@@ -78,6 +78,9 @@ typedef struct {
 	double *cJac; /* ncnln x nC column-major, persists (ntg.c:210-220) */
 	double *bl, *bu; /* nC+nclin+ncnln (ntg.c:222-229) */
 	orc_nlhess_t nlic_hess, nltc_hess, nlfc_hess; /* optional (NULL: Gauss-Newton terms only), see orc_nlhess_t */
+	/* structured Newton mode (opts.hessian = 2): outputs per coupling group of the family and the constraint flag entries of
+	 * group 0 as a bit mask (bit maxderiv*o + r); couple = 0: the family does not offer the mode (host callbacks never do) */
+	int couple; unsigned long long group_mask;
 } orc_problem;
 
 orc_problem *orc_problem_make(

@@ -359,15 +359,54 @@ static void nwt_add_bp(nwt_t *w, double *Kb, int bp, const double *B)
 	}
 }
 
-static int nwt_applicable(const orc_problem *p, int nI)
+/* The mode applies to the same problems as on the device (build_newton_tables() in ntg_amd/csrc/plan.cpp states the rule):
+ * a family with per-group second-order blocks, one spline spec for every output, trajectory nonlinear rows only, on exactly
+ * the family's flag entries, no linear inequality rows, equality rows that pin a square block of coefficients -- the same
+ * range of every output -- and a band of half width k couple - 1 <= 32.  (The arithmetic below is more general -- any
+ * equality rows, through a bordered factorisation -- so that the two implementations check each other.) */
+static int nwt_applicable(const orc_problem *p, int nI, const double *AE, int m)
 {
 	const orc_colloc *cc = p->cc;
-	int o;
-	if (p->ncnln <= 0 || nI > 0) return 0;
+	int o, a, i, c, n = cc->nC, go = p->couple, ngrp, dm, nco, k, P = cc->nbps, npin = 0, clo = -1, chi = -1, nint = 0, cover = 1, cl;
+	unsigned long long want = 0, have = 0;
+	char *pinned;
+	if (p->ncnln <= 0 || nI > 0 || go <= 0 || p->nnlic || p->nnlfc || p->nnltc <= 0 || cc->nout % go) return 0;
 	for (o = 1; o < cc->nout; o++) {
 		if (cc->order[o] != cc->order[0] || cc->mult[o] != cc->mult[0] || cc->ninterv[o] != cc->ninterv[0] || cc->maxderiv[o] != cc->maxderiv[0]) return 0;
 		if (memcmp(cc->off[o], cc->off[0], cc->nbps * sizeof(int))) return 0;
 		if (memcmp(cc->blk[o], cc->blk[0], (size_t)cc->nbps * cc->order[0] * cc->maxderiv[0] * sizeof(double))) return 0;
+	}
+	ngrp = cc->nout / go; dm = cc->maxderiv[0]; nco = cc->ncoef[0]; k = cc->order[0];
+	if (k * go - 1 > 32 || ngrp > 8) return 0;
+	for (a = 0; a < ngrp; a++) want |= p->group_mask << (dm * go * a);
+	for (a = 0; a < p->ntcav; a++) have |= 1ull << (cc->iz[p->tcav[a].output] + p->tcav[a].deriv);
+	if (want != have) return 0;
+	/* pinned coefficients: the columns the equality rows touch (entries at rounding level do not count) */
+	pinned = calloc(n, 1);
+	for (i = 0; i < m; i++) {
+		double big = 0.0;
+		for (c = 0; c < n; c++) if (fabs(M_(AE, m, i, c)) > big) big = fabs(M_(AE, m, i, c));
+		for (c = 0; c < n; c++) if (fabs(M_(AE, m, i, c)) > 1e-10 * big && !pinned[c]) { pinned[c] = 1; npin++; }
+	}
+	for (cl = 0; cl < nco; cl++) if (!pinned[cc->iC[0] + cl]) { if (clo < 0) clo = cl; chi = cl + 1; }
+	i = (npin == m && clo >= 0);
+	for (o = 0; o < cc->nout && i; o++) for (cl = 0; cl < nco; cl++) if ((pinned[cc->iC[o] + cl] != 0) != !(cl >= clo && cl < chi)) { i = 0; break; }
+	free(pinned);
+	if (!i) return 0;
+	/* breakpoint groups: at most 64 of at most 6 breakpoints; groups of one colour share no coefficient */
+	for (i = 0; i < P;) { int j = i; while (j < P && cc->off[0][j] == cc->off[0][i]) j++; if (j - i > 6) return 0; nint++; i = j; }
+	if (nint > 64) return 0;
+	for (cl = 0; cl < nco; cl++) {
+		int cnt = 0, prev = -1;
+		for (i = 0; i < P; i++) { const int of = cc->off[0][i]; if (of != prev && cl >= of && cl < of + k) cnt++; prev = of; }
+		if (cnt > cover) cover = cnt;
+	}
+	{
+		int *offs = malloc(nint * sizeof(int)), t = 0, prev = -1, ok = 1;
+		for (i = 0; i < P; i++) if (cc->off[0][i] != prev) { offs[t++] = cc->off[0][i]; prev = cc->off[0][i]; }
+		for (t = 0; t + cover < nint; t++) if (offs[t + cover] < offs[t] + k) ok = 0;
+		free(offs);
+		if (!ok) return 0;
 	}
 	return 1;
 }
@@ -647,11 +686,11 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	 * in the augmented Lagrangian */
 	for (i = 0; i < mall; i++) { if (p->bl[n + i] == p->bu[n + i]) erow[m++] = i; else irow[nI++] = i; }
 	nal = nc + nI;
-	newton = (o->hessian == 2) && nwt_applicable(p, nI);
-	if (o->hessian == 2 && !newton) hess = 1;
 	if (nal > 0 && o->fixed_iters) { res->inform = 9; free(erow); free(irow); return; }
 	AE = malloc((size_t)(m + 1) * n * sizeof(double)); bE = malloc((m + 1) * sizeof(double));
 	for (i = 0; i < m; i++) { bE[i] = p->bl[n + erow[i]]; for (j = 0; j < n; j++) M_(AE, m, i, j) = M_(p->A, mall, erow[i], j); }
+	newton = (o->hessian == 2) && nwt_applicable(p, nI, AE, m);
+	if (o->hessian == 2 && !newton) hess = 1;
 
 	W = newton ? NULL : malloc((size_t)n * n * sizeof(double));
 	t_x = calloc(nal + 1, sizeof(double));
