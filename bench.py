@@ -32,6 +32,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def orc_off(spec):
+    """block offset of every breakpoint of output 0 (colloc.c:104-111): (interval index) * (order - mult)"""
+    import numpy as np
+    kn = np.asarray(spec.knots[0]); l = len(kn) - 1
+    left = np.clip(np.searchsorted(kn, np.asarray(spec.bps), side="right"), 1, l)
+    return (left - 1) * (spec.order[0] - spec.mult[0])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -40,7 +48,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
     ap.add_argument("--config", default="M", choices=["M", "B"])
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--cpu-sample", type=int, default=512)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="problems of the CPU baseline sample (0: 4 per host thread)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch problems per GPU (default); strong: --batch problems in all, split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -63,7 +73,10 @@ def main():
     spec = cf.config_M() if args.config == "M" else cf.config_B()
     ncars = spec.nout // 2
     B = args.batch
-    # weak scaling: every rank owns its own B problems, drawn from one global stream
+    if args.scaling == "strong":
+        assert args.batch % world == 0, "--scaling strong needs a batch divisible by the number of GPUs"
+        B = args.batch // world
+    # every rank owns its own slice of B problems of one global stream (weak: B = --batch per GPU; strong: --batch in all)
     lo_all, up_all = cf.kincar_random_bounds(ncars, B * world)
     lo = torch.tensor(lo_all[rank * B:(rank + 1) * B], device=dev)
     up = torch.tensor(up_all[rank * B:(rank + 1) * B], device=dev)
@@ -120,11 +133,13 @@ def main():
     value = world * B * args.steps / dt
 
     res = {
-        "metric": "trajectories/sec (batched SQP, 50 major iterations, kincar 6-output order-6/20-interval)",
+        "metric": "trajectories/sec (batched SQP, kincar 6-output order-6/20-interval; value = the fixed-work mode of BASELINE's "
+                  "target: exactly 50 SQP major iterations per problem from an identity cold start; the to-convergence mode is under to_convergence)",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{spec.name}: {B} problems/GPU x {args.iters} SQP majors (identity cold start, fixed work)",
+                   "value_mode": "fixed_50_majors",
                    "batch_per_gpu": B, "nout": spec.nout, "order": spec.order[0], "ninterv": spec.kninterv[0],
                    "nbps": spec.nbps, "nC": spec.nC, "nclin": spec.nclin, "sqp_iters": args.iters,
                    "parallelism": f"problems sharded over {world} GPU(s), final all_gather only"},
@@ -231,24 +246,58 @@ def main():
                                        "inform_counts": {str(k): int((infO == k).sum()) for k in np.unique(infO)},
                                        "iters_mean": float(ooO["iters"].float().mean().item()), "iters_max": int(ooO["iters"].max().item())}
         del wO
-        # ---- BASELINE configs D and E at their full sizes, to convergence (per-GPU share of the 8-GPU batch) ----
+        # ---- BASELINE configs D and E at their full sizes, to convergence (per-GPU share of the 8-GPU batch): the structured
+        #      Newton mode (hessian = 2) and, beside it, the quasi-Newton mode of round 1 ----
+        MFMA_PEAK_TF = 78.6   # fp64 matrix peak of one MI355X (MI355X_MICROARCH.md)
         for key, mk, bnds, nbL, qnm in (("config_D", cf.config_D, cf.quadrotor_bounds, 512, 48), ("config_E", cf.config_E, cf.manipulator_bounds, 1024, 0)):
             specL = mk(); planL = api.Plan(specL, local)
-            loL, upL = bnds(nbL)
-            loL = torch.tensor(loL, device=dev); upL = torch.tensor(upL, device=dev)
-            oL = api.default_opts(hessian=1, qn_memory=qnm)   # D: a 48-pair memory converges in fewer majors than 256 here
-            wL = torch.empty(planL.workspace_bytes(nbL, oL), dtype=torch.uint8, device=dev)
-            for rep in range(2):   # first pass builds the preconditioner and warms the instruction cache
-                xL = torch.ones((nbL, specL.nC), dtype=torch.float64, device=dev)
-                torch.cuda.synchronize(); t1 = time.perf_counter()
-                ooL = planL.solve(loL, upL, xL, oL, work=wL)
-                torch.cuda.synchronize(); dtl = time.perf_counter() - t1
-            infL = ooL["inform"].cpu().numpy()
-            res[key] = {"value": nbL / dtl, "unit": "trajectories/s", "ms_per_batch": 1e3 * dtl, "batch": nbL,
-                        "workload": "%s: nC %d, %d breakpoints, %d nonlinear trajectory rows per problem" % (specL.name, specL.nC, specL.nbps, specL.ncnln),
-                        "inform_counts": {str(k): int((infL == k).sum()) for k in np.unique(infL)}, "qn_memory": qnm or 256,
-                        "iters_mean": float(ooL["iters"].float().mean().item()), "nfev_mean": float(ooL["nfev"].float().mean().item())}
-            del wL, planL
+            loLn, upLn = bnds(nbL)
+            loL = torch.tensor(loLn, device=dev); upL = torch.tensor(upLn, device=dev)
+            entry = {"batch": nbL, "workload": "%s: nC %d, %d breakpoints, %d nonlinear trajectory rows per problem" % (specL.name, specL.nC, specL.nbps, specL.ncnln)}
+            for mode, oL in (("newton", api.default_opts(hessian=2)), ("quasi_newton", api.default_opts(hessian=1, qn_memory=qnm))):
+                wL = torch.empty(planL.workspace_bytes(nbL, oL), dtype=torch.uint8, device=dev)
+                for rep in range(2):   # first pass builds tables / warms the instruction cache
+                    xL = torch.ones((nbL, specL.nC), dtype=torch.float64, device=dev)
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    ooL = planL.solve(loL, upL, xL, oL, work=wL)
+                    torch.cuda.synchronize(); dtl = time.perf_counter() - t1
+                infL = ooL["inform"].cpu().numpy()
+                e = {"value": nbL / dtl, "unit": "trajectories/s", "ms_per_batch": 1e3 * dtl,
+                     "inform_counts": {str(k): int((infL == k).sum()) for k in np.unique(infL)},
+                     "iters_mean": float(ooL["iters"].float().mean().item()), "iters_max": int(ooL["iters"].max().item()),
+                     "nfev_mean": float(ooL["nfev"].float().mean().item())}
+                if mode == "quasi_newton":
+                    e["qn_memory"] = qnm or 256
+                else:
+                    # matrix-core work of the launch: counters of a separate, untimed run (NTG_AMD_STAMPS=3 makes the kernel report
+                    # factorisations / failed attempts in place of the multipliers)
+                    os.environ["NTG_AMD_STAMPS"] = "3"
+                    xL = torch.ones((nbL, specL.nC), dtype=torch.float64, device=dev)
+                    od = planL.solve(loL, upL, xL, oL, work=wL, want_lambda=True)
+                    torch.cuda.synchronize()
+                    del os.environ["NTG_AMD_STAMPS"]
+                    cnt = od["clambda"][:, :3].cpu().numpy()
+                    nfact, nfail = cnt[:, 0].sum(), cnt[:, 1].sum()
+                    go = {"config_D": 4, "config_E": 3}[key]; cgn = {"config_D": 6, "config_E": 3}[key]
+                    ngrp = specL.nout // go
+                    nfree = specL.nC // specL.nout - 2 * specL.maxderiv[0]            # free coefficients per output (flag pinned at both ends)
+                    nbr = (nfree * go + 15) // 16
+                    offs = np.asarray(orc_off(specL))
+                    cnts = np.unique(offs, return_counts=True)[1]
+                    mfma_fact = ngrp * nbr * 12
+                    mfma_asm = ngrp * int(sum(3 * ((c * cgn + 3) // 4) for c in cnts))
+                    flops = 2048.0 * ((nfact - 0.5 * nfail) * mfma_fact + nfact * mfma_asm)
+                    m_rows = specL.nclin + specL.ncnln
+                    e["mfma"] = {"instr": "v_mfma_f64_16x16x4_f64", "flops_executed": flops, "achieved_tflops": flops / dtl / 1e12,
+                                 "peak_tflops": MFMA_PEAK_TF, "util": flops / dtl / 1e12 / MFMA_PEAK_TF,
+                                 "factorisations_per_problem": float(nfact / nbL), "not_positive_definite_per_problem": float(nfail / nbL),
+                                 "what": "band assembly (M' B M per knot interval) + trailing updates of the band Cholesky; structured count, "
+                                         "not the dense 2 m^2 nC bound of SURVEY 8d (%.3g flop per iteration per problem)" % (2.0 * m_rows * m_rows * specL.nC)}
+                entry[mode] = e
+                del wL
+            entry["value"] = entry["newton"]["value"]; entry["unit"] = "trajectories/s"; entry["value_mode"] = "newton"
+            res[key] = entry
+            del planL
         # ---- funobj + funcon with banded Jacobian rows (the constraint-Jacobian assembly), configs D and E ----
         for key, mk, nbJ in (("jacobian_assembly_D", cf.config_D, 4096), ("jacobian_assembly_E", cf.config_E, 2048)):
             specJ = mk(); planJ = api.Plan(specJ, local)
@@ -285,21 +334,44 @@ def main():
         del xe
 
     if rank == 0 and world == 1 and not args.no_cpu:
-        # ---- CPU baseline: the oracle on a bounded sample of the same workload ----
+        # ---- CPU baseline: the oracle on a bounded sample of the same workload, on the host cores of this box.  Two flavours
+        #      (SURVEY 8d): "ref" = the reference's loops and dense temporaries (cost.c:117-134), "opt" = banded, allocation-free
+        #      evaluation; each with one thread and with one problem per thread on every core, >= 2 s of work per thread ----
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
         ncore = os.cpu_count() or 1
-        ns = min(args.cpu_sample, B)
-        oo = orc.default_opts(itlim=args.iters, fixed_iters=1, hessian=0)
-        t1 = time.perf_counter()
-        r = orc.solve_batch(spec, lo_all[:ns], up_all[:ns], np.ones((ns, spec.nC)), oo, nthreads=ncore)
-        dtc = time.perf_counter() - t1
-        res["cpu_baseline"] = {"value": ns / dtc, "unit": "trajectories/s", "cores": ncore, "kind": "port",
-                               "sample": f"first {ns} problems of the same batch, same 50 fixed majors, oracle/sqp.c with "
-                                         f"reference-faithful dense assembly, OpenMP one problem per thread, {dtc:.2f} s wall"}
+        ns = args.cpu_sample if args.cpu_sample > 0 else 4 * ncore
+        ns = min(ns, lo_all.shape[0])
+        model = "unknown"
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip(); break
+        except OSError:
+            pass
+        cflags = "gcc -O2 -fopenmp -ffp-contract=off (oracle/Makefile)"
+        flav = {}
+        r_ref = None
+        for fl, banded in (("ref", 0), ("opt", 1)):
+            oo = orc.default_opts(itlim=args.iters, fixed_iters=1, hessian=0, banded=banded)
+            t1 = time.perf_counter()
+            r = orc.solve_batch(spec, lo_all[:ns], up_all[:ns], np.ones((ns, spec.nC)), oo, nthreads=ncore)
+            dta = time.perf_counter() - t1
+            n1 = 64   # >= 2 s of single-thread work
+            t1 = time.perf_counter()
+            orc.solve_batch(spec, lo_all[:n1], up_all[:n1], np.ones((n1, spec.nC)), oo, nthreads=1)
+            dt1 = time.perf_counter() - t1
+            flav[fl] = {"all_cores": ns / dta, "one_thread": n1 / dt1, "all_cores_problems": ns, "all_cores_wall_s": dta, "one_thread_problems": n1, "one_thread_wall_s": dt1}
+            if fl == "ref":
+                r_ref = r
+        res["cpu_baseline"] = {"value": flav["ref"]["all_cores"], "unit": "trajectories/s", "cores": ncore, "kind": "port",
+                               "sample": f"first {ns} problems of the same batch (4 per host thread), same 50 fixed majors, oracle/sqp.c with the "
+                                         f"reference-faithful dense assembly, OpenMP one problem per thread, {flav['ref']['all_cores_wall_s']:.2f} s wall",
+                               "flavours": flav, "cpu_model": model, "compiler": cflags}
         # same inputs -> same answers (oracle is the checker here, never the thing shipped)
-        gobj = out["objective"][:ns].cpu().numpy()
-        res["cpu_baseline"]["max_rel_objective_diff_vs_gpu"] = float(np.max(np.abs(gobj - r["objective"]) / np.abs(r["objective"])))
+        nchk = min(ns, B)
+        gobj = out["objective"][:nchk].cpu().numpy()
+        res["cpu_baseline"]["max_rel_objective_diff_vs_gpu"] = float(np.max(np.abs(gobj - r_ref["objective"][:nchk]) / np.abs(r_ref["objective"][:nchk])))
 
     if rank == 0:
         print(json.dumps(res))

@@ -173,6 +173,7 @@ NWT_FN int nwt_factor_wave(double *__restrict__ Kc, int ng, int hb, double *pane
 			T22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x2[s], T22, 0, 0, 0);
 		}
 		T00 = T11; T10 = T21; T11 = T22; T20 = N0; T21 = N1; T22 = N2;
+		if (strict && fail) break;   // not positive definite: the caller repeats with the Gauss-Newton terms, the rest is not needed
 	}
 	return fail;
 }

@@ -1215,6 +1215,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	double *nwt_B = NWT ? nwt_K + (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) : nullptr;
 	bool nwt_curv = false;        // the current factor includes the constraint curvature
 	int nwt_bad = 0;              // diagnostic: non-positive pivots replaced in Gauss-Newton factorisations (wave 0's count)
+	int nwt_nfact = 0, nwt_nfail = 0, nwt_napply = 0;   // diagnostic (sp.stamps == 3): factorisations, of which not positive definite, solves
 	bool phase0 = NWT && alprob;  // the pass on the objective alone is still running
 	int *nwt_flag = (int *)(smem_raw + L.red) + 2 * 16 * (NT / 64 + 1) - 2;   // last word pair of the reduction scratch: "not positive definite"
 	// K = model at the trial point buffer `xs` (must be the iterate x; needs the multiplier estimates al_t of the evaluation
@@ -1254,13 +1255,16 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			__syncthreads();
 			if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[7] += now_ - tlast; tlast = now_; }
 			nwt_curv = curv;
+			nwt_nfact++;
 			if (nwt_flag[0] == 0) break;
+			nwt_nfail++;
 		}
 	};
 	auto nwt_apply = [&](const double *v, double *out) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ylen = 16 * ((ng + 15) >> 4) + 48;
 		const int wave = tid >> 6;
 		double *yv = (double *)(smem_raw + L.nwt_y);
+		nwt_napply++;
 		if (BIG) __syncthreads(); else lds_sync();
 		for (int i = tid; i < ngp * ylen; i += NT) {
 			const int g = i / ylen, pp = i - g * ylen;
@@ -1601,6 +1605,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			clambda[(size_t)b * ntot + i] = v;
 		}
 		if (sp.stamps == 1 && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
+		if (sp.stamps == 3 && tid == 0) {   // diagnostic: work counters of the structured Newton mode
+			double *o = clambda + (size_t)b * ntot;
+			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev;
+		}
 		if (sp.stamps == 2 && tid == 0) {   // diagnostic: state of the augmented-Lagrangian loop at exit
 			double *o = clambda + (size_t)b * ntot;
 			o[0] = sqrt(rv2); o[1] = al.mu; o[2] = outer; o[3] = sri; o[4] = rvprev; o[5] = inner_inform; o[6] = NWT ? (double)nwt_bad : mfres; o[7] = F;

@@ -470,12 +470,47 @@ void orc_problem_free(orc_problem *p)
 	free(p->Z); free(p->A); free(p->cJac); free(p->bl); free(p->bu); free(p);
 }
 
+/* "cpu-opt" flavour of the running cost: same numbers as cost_T up to summation order, without its dense
+ * nbps x nC temporary: Z of the cost variables at a breakpoint, the callback, the trapezoid as node weights, the banded
+ * M' (w df) accumulated straight into the gradient.  No allocation per call beyond two small stack arrays. */
+static void cost_T_banded(double *I, double *dI, const orc_problem *p, const double *x)
+{
+	const orc_colloc *cc = p->cc;
+	int P = cc->nbps, i, a, q, md = 2, ns = 0, o;
+	double z[64], df[64], *zp[16], f, acc = 0.0;
+	for (i = 0; i < cc->nC; i++) dI[i] = 0.0;
+	for (o = 0; o < cc->nout; o++) zp[o] = z + cc->iz[o];
+	for (i = 0; i < cc->nz; i++) z[i] = 0.0;
+	for (i = 0; i < P; i++) {
+		double w = 0.0;
+		if (i > 0) w += (cc->bps[i] - cc->bps[i - 1]) / 2;
+		if (i < P - 1) w += (cc->bps[i + 1] - cc->bps[i]) / 2;
+		for (a = 0; a < p->ntcostav; a++) {
+			const int oo = p->tcostav[a].output, r = p->tcostav[a].deriv, k = cc->order[oo];
+			const double *c = x + cc->iC[oo] + cc->off[oo][i];
+			double s = 0.0;
+			for (q = 0; q < k; q++) s += BLK(cc, oo, i, q, r) * c[q];
+			z[cc->iz[oo] + r] = s;
+		}
+		p->ucf(&md, &ns, &i, &f, df, zp);
+		acc += w * f;
+		for (a = 0; a < p->ntcostav; a++) {
+			const int oo = p->tcostav[a].output, r = p->tcostav[a].deriv, k = cc->order[oo];
+			double *g = dI + cc->iC[oo] + cc->off[oo][i];
+			const double wd = w * df[cc->iz[oo] + r];
+			for (q = 0; q < k; q++) g[q] += wd * BLK(cc, oo, i, q, r);
+		}
+	}
+	*I = acc;
+}
+
 /* ntg.c:274-335.  Quirk kept: mode 0 tests n?cf==1, modes 1/2 test !=0 (ntg.c:297-301 vs 309-313). */
 void orc_funobj(orc_problem *p, int *mode, const double *x, double *y, double *yprime, int *nstate)
 {
 	const orc_colloc *cc = p->cc;
 	double I = 0.0, In = 0.0, F = 0.0, *dI, *dIn, *dF;
 	int i;
+	if (p->banded && *mode == 2 && p->nicf == 0 && p->nfcf == 0 && p->nucf != 0 && cc->nz <= 64 && cc->nout <= 16) { cost_T_banded(y, yprime, p, x); return; }
 	if (p->nicf != 0) orc_updateZ(p->Z, cc, x, p->icostav, p->nicostav, ORC_AVINITIAL);
 	if (p->nucf != 0) orc_updateZ(p->Z, cc, x, p->tcostav, p->ntcostav, ORC_AVTRAJECTORY);
 	if (p->nfcf != 0) orc_updateZ(p->Z, cc, x, p->fcostav, p->nfcostav, ORC_AVFINAL);

@@ -81,6 +81,9 @@ typedef struct {
 	/* structured Newton mode (opts.hessian = 2): outputs per coupling group of the family and the constraint flag entries of
 	 * group 0 as a bit mask (bit maxderiv*o + r); couple = 0: the family does not offer the mode (host callbacks never do) */
 	int couple; unsigned long long group_mask;
+	/* CPU baseline flavour (SURVEY 8d "cpu-opt"): 1 = banded, allocation-free evaluation of the running cost (no dense
+	 * nbps x nC temporary, node-wise trapezoid weights); 0 = the reference's loops (cost.c:117-134).  Values agree to rounding. */
+	int banded;
 } orc_problem;
 
 orc_problem *orc_problem_make(
@@ -119,6 +122,7 @@ typedef struct {
 	int fixed_iters;     /* 1: run exactly itlim majors, no convergence exit */
 	int verbose;
 	int qn_memory;       /* BFGS updates kept before W restarts from W0 (the device's pair memory); <= 0: 256 */
+	int banded;          /* 1: evaluate with the banded, allocation-free path (orc_problem.banded) -- timing flavour only */
 } orc_sqp_opts;
 void orc_sqp_default_opts(orc_sqp_opts *o);
 

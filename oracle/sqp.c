@@ -40,7 +40,7 @@
 void orc_sqp_default_opts(orc_sqp_opts *o)
 {
 	o->itlim = 0; o->opttol = 0.0; o->steplimit = 2.0; o->ls_mu = 1e-4; o->ls_eta = 0.9;
-	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->verbose = 0; o->qn_memory = 0;
+	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->verbose = 0; o->qn_memory = 0; o->banded = 0;
 }
 
 /* ---------------- dense helpers (column-major, ld explicit) ---------------- */
@@ -682,6 +682,7 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	al_t al;
 
 	memset(res, 0, sizeof(*res));
+	p->banded = o->banded;
 	/* linear rows with lower == upper are kept satisfied by projection; the others join the nonlinear rows
 	 * in the augmented Lagrangian */
 	for (i = 0; i < mall; i++) { if (p->bl[n + i] == p->bu[n + i]) erow[m++] = i; else irow[nI++] = i; }

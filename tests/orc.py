@@ -38,7 +38,7 @@ class AVc(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("itlim", C.c_int), ("opttol", C.c_double), ("steplimit", C.c_double),
                 ("ls_mu", C.c_double), ("ls_eta", C.c_double), ("ls_maxfev", C.c_int),
-                ("hessian", C.c_int), ("fixed_iters", C.c_int), ("verbose", C.c_int), ("qn_memory", C.c_int)]
+                ("hessian", C.c_int), ("fixed_iters", C.c_int), ("verbose", C.c_int), ("qn_memory", C.c_int), ("banded", C.c_int)]
 
 
 class Result(C.Structure):
