@@ -75,6 +75,16 @@ def lib():
     return _lib
 
 
+def _check_tensor(t, dev, dtype=None):
+    """the C ABI takes raw device pointers: a tensor of the wrong dtype / device / layout would corrupt memory silently"""
+    import torch
+    if t is None:
+        return
+    want = dtype if dtype is not None else torch.float64
+    if not (t.is_cuda and t.device == dev and t.dtype == want and t.is_contiguous()):
+        raise NtgError(f"tensor must be a contiguous {want} tensor on {dev}, got {t.dtype} on {t.device} (contiguous: {t.is_contiguous()})")
+
+
 def _check(rc):
     if rc != 0:
         raise NtgError(f"libntg_amd error {rc}: {lib().ntg_last_error().decode()}")
@@ -180,7 +190,11 @@ class Plan:
         dev = x.device
         if out is not None:
             f, g, c, jb = out["f"], out["g"], out.get("c"), out.get("jband")
-            cj = None
+            cj = out.get("_cj")   # the [batch][nC][ncnln] buffer behind an earlier dense Jacobian, reused
+            if want_dense_jac and sp.ncnln and cj is None:
+                cj = torch.empty((batch, sp.nC, sp.ncnln), dtype=torch.float64, device=dev)
+            for t in (f, g, c, jb):
+                _check_tensor(t, dev)
         else:
             f = torch.empty(batch, dtype=torch.float64, device=dev)
             g = torch.empty((batch, sp.nC), dtype=torch.float64, device=dev)
@@ -196,6 +210,7 @@ class Plan:
             out.update(c=c, jband=jb)
             if want_dense_jac:
                 out["cJac"] = cj.transpose(1, 2).contiguous()
+                out["_cj"] = cj
         return out
 
     def interp(self, x, times):
@@ -242,6 +257,14 @@ class Plan:
         if work is None:
             work = torch.empty(need, dtype=torch.uint8, device=dev)
         assert work.numel() * work.element_size() >= need
+        _check_tensor(lower, dev); _check_tensor(upper, dev)
+        if lower.shape != (batch, sp.nbounds) or upper.shape != (batch, sp.nbounds):
+            raise NtgError(f"bounds must be [{batch}, {sp.nbounds}]")
+        if out is not None:
+            _check_tensor(out["objective"], dev)
+            for k in ("inform", "iters", "nfev"):
+                _check_tensor(out[k], dev, torch.int32)
+            _check_tensor(out.get("clambda"), dev)
         if out is None:
             out = dict(objective=torch.empty(batch, dtype=torch.float64, device=dev),
                        inform=torch.empty(batch, dtype=torch.int32, device=dev),

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <string>
+#include <mutex>
 #include <vector>
 #include <utility>
 #include "ntg_dev.hpp"
@@ -199,8 +200,8 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		if (e != hipSuccess || e2 != hipSuccess) { ntg_plan_destroy(p); return fail(NTG_E_HIP, "basis kernel failed"); }
 	}
 	p->h_blk.resize(blk_total); p->h_off.resize((size_t)D.nclass * s->nbps);
-	HIPCHK(hipMemcpy(p->h_blk.data(), d_blk, (size_t)blk_total * 8, hipMemcpyDeviceToHost));
-	HIPCHK(hipMemcpy(p->h_off.data(), d_off, p->h_off.size() * 4, hipMemcpyDeviceToHost));
+	if (hipMemcpy(p->h_blk.data(), d_blk, (size_t)blk_total * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+	    hipMemcpy(p->h_off.data(), d_off, p->h_off.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { ntg_plan_destroy(p); return fail(NTG_E_HIP, "reading the basis tables back failed"); }
 	NtgTables &T = p->T;
 	std::memset(&T, 0, sizeof(T));
 	T.bps = d_bps; T.blk = d_blk; T.off = d_off;
@@ -273,8 +274,8 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		for (void *q : tmp_own) hipFree(q);
 		if (e != hipSuccess || e2 != hipSuccess) { ntg_plan_destroy(p); return fail(NTG_E_HIP, "linrows kernel failed"); }
 		p->h_aband.resize((size_t)D.nclin * sumk); p->h_rbp.resize(D.nclin);
-		HIPCHK(hipMemcpy(p->h_aband.data(), d_ab, p->h_aband.size() * 8, hipMemcpyDeviceToHost));
-		HIPCHK(hipMemcpy(p->h_rbp.data(), d_rbp, p->h_rbp.size() * 4, hipMemcpyDeviceToHost));
+		if (hipMemcpy(p->h_aband.data(), d_ab, p->h_aband.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+		    hipMemcpy(p->h_rbp.data(), d_rbp, p->h_rbp.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) { ntg_plan_destroy(p); return fail(NTG_E_HIP, "reading the linear rows back failed"); }
 		T.aband = d_ab; T.rbp = d_rbp;
 		// dense rows; split into the equality rows (kept satisfied by projection) and the rows declared as
 		// inequalities (spec->lin_ineq, handled by the augmented-Lagrangian loop like nonlinear rows)
@@ -587,9 +588,10 @@ static int precond_block(const std::vector<double> &H0, const std::vector<double
 	};
 	form_hr(1e-12);
 	if (!chol_lower(Hr, nr)) { form_hr(1e-6); if (!chol_lower(Hr, nr)) return fail(NTG_E_UNSUPPORTED, "preconditioner not positive definite"); }
-	else {
+	{
 		// H0 singular on null(A) (no equality rows: constants and ramps cost nothing): the regularised inverse would scale
-		// those directions by 1e12 -- no preconditioner then, the solve starts from the identity
+		// those directions by 1e12 (1e6 after the harder regularisation) -- no preconditioner then, the solve starts from
+		// the identity.  Checked after whichever factorisation succeeded.
 		double lo = 1e300, hi = 0.0;
 		for (int i = 0; i < nr; i++) { const double dd = Hr[(size_t)i * nr + i] * Hr[(size_t)i * nr + i]; lo = std::min(lo, dd); hi = std::max(hi, dd); }
 		if (lo < 1e-9 * hi) return 1;
@@ -809,7 +811,10 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
 	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
-	if (sp.hessian == 1 && !p->precond_ready) { int rc = build_precond(p); if (rc) return rc; }
+	if (sp.hessian == 1) {   // built on first use, once: two threads or streams may first-solve the same plan
+		std::lock_guard<std::mutex> lk(p->precond_mutex);
+		if (!p->precond_ready) { int rc = build_precond(p); if (rc) return rc; }
+	}
 	if (sp.hessian == 1 && p->precond_singular) sp.hessian = 0;
 	SmemLayout L; int big;
 	if (solve_layout(p->D, nt, &L, &big)) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
@@ -878,18 +883,21 @@ extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x,
 	std::vector<int> base(D.nclass);
 	size_t tot = 0;
 	for (int c = 0; c < D.nclass; c++) { base[c] = (int)tot; tot += (size_t)ntimes * D.cls_k[c] * D.cls_d[c]; }
-	HIPCHK(hipMallocAsync((void **)&d_tblk, tot * 8, st));
-	HIPCHK(hipMallocAsync((void **)&d_toff, (size_t)D.nclass * ntimes * 4, st));
-	HIPCHK(hipMallocAsync((void **)&d_base, (size_t)D.nclass * 4, st));
-	HIPCHK(hipMemcpyAsync(d_base, base.data(), (size_t)D.nclass * 4, hipMemcpyHostToDevice, st));
-	hipError_t e = hipSuccess;
+	// (the three buffers are released on every path: failures fall through to the frees below)
+	hipError_t e = hipMallocAsync((void **)&d_tblk, tot * 8, st);
+	if (e == hipSuccess) e = hipMallocAsync((void **)&d_toff, (size_t)D.nclass * ntimes * 4, st);
+	if (e == hipSuccess) e = hipMallocAsync((void **)&d_base, (size_t)D.nclass * 4, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_base, base.data(), (size_t)D.nclass * 4, hipMemcpyHostToDevice, st);
 	for (int c = 0; c < D.nclass && e == hipSuccess; c++)
 		e = ntg_launch_basis(1, D.cls_l[c], D.cls_k[c], D.cls_m[c], D.cls_d[c], ntimes, p->d_knots[c], d_times, 0, 0,
 		                     d_tblk + base[c], d_toff + (size_t)c * ntimes, st);
 	if (e == hipSuccess) e = ntg_launch_interp(D, batch, ntimes, d_x, d_tblk, d_toff, d_base, d_z, st);
-	HIPCHK(hipStreamSynchronize(st));   // `base` is read by the async copy above
-	(void)hipFreeAsync(d_tblk, st); (void)hipFreeAsync(d_toff, st); (void)hipFreeAsync(d_base, st);
+	const hipError_t es = hipStreamSynchronize(st);   // `base` is read by the async copy above
+	if (d_tblk) (void)hipFreeAsync(d_tblk, st);
+	if (d_toff) (void)hipFreeAsync(d_toff, st);
+	if (d_base) (void)hipFreeAsync(d_base, st);
 	HIPCHK(e);
+	HIPCHK(es);
 	return 0;
 }
 

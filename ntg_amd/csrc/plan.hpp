@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <mutex>
 #include "ntg_dev.hpp"
 
 struct ntg_plan {
@@ -9,6 +10,7 @@ struct ntg_plan {
 	NtgDims D;
 	NtgTables T;
 	bool lin_ok = true;
+	std::mutex precond_mutex;                   // guards the lazy build of the preconditioner
 	bool precond_ready = false;                 // W0 tables (T.n0 or T.n0b) built
 	bool precond_singular = false;              // the cost Hessian model is singular on null(A_E): hessian = 1 falls back to the identity
 	std::vector<void *> owned;                  // device allocations

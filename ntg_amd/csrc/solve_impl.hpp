@@ -1573,8 +1573,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						continue;
 					}
 				} else inform = (inner_inform == 0 && weak) ? 1 : inner_inform;
-				if (clambda && m > 0 && (D.q_use || al.mu > 0.0)) {   // one more pass for the multipliers (the Q form does not produce
-				                                                       // them; projecting directions overwrote the estimate)
+				if (clambda && m > 0 && (D.q_use || al.mu > 0.0 || !at_x)) {   // one more pass for the multipliers (the Q form does not
+				                                                       // produce them; projecting directions overwrote the estimate; a solve that
+				                                                       // ended on a rejected line-search trial projected last at that trial, not at x)
 					state = ST_FINAL;
 					lds_sync();
 					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });

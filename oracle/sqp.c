@@ -217,18 +217,19 @@ static int w0_dense(const double *H0, const double *AE, int m, int n, double *W0
 	for (i = 0; i < nr; i++) tr += M_(Hr, nr, i, i);
 	for (i = 0; i < nr; i++) M_(Hr, nr, i, i) += 1e-12 * tr / nr + 1e-300;
 	rc = chol_(Hr, nr);
-	if (!rc) {
-		/* H0 singular on null(A) (e.g. no equality rows at all: constants and ramps cost nothing): the regularised
-		 * inverse would scale those directions by 1e12.  No preconditioner then -- the caller starts from the identity. */
-		double lo = 1e300, hi = 0.0;
-		for (i = 0; i < nr; i++) { double dd = M_(Hr, nr, i, i) * M_(Hr, nr, i, i); if (dd < lo) lo = dd; if (dd > hi) hi = dd; }
-		if (lo < 1e-9 * hi) { free(Q); free(T); free(Hr); return 2; }
-	}
 	if (rc) {
 		/* not positive definite on null(A): regularise harder once */
 		for (j = 0; j < nr; j++) for (i = 0; i < nr; i++) M_(Hr, nr, i, j) = dot_(&M_(Q, n, 0, m + i), &M_(T, n, 0, j), n);
 		for (i = 0; i < nr; i++) M_(Hr, nr, i, i) += 1e-6 * tr / nr + 1e-300;
 		rc = chol_(Hr, nr);
+	}
+	if (!rc) {
+		/* H0 singular on null(A) (e.g. no equality rows at all: constants and ramps cost nothing): the regularised
+		 * inverse would scale those directions by 1e12.  No preconditioner then -- the caller starts from the identity.
+		 * Checked after whichever factorisation succeeded. */
+		double lo = 1e300, hi = 0.0;
+		for (i = 0; i < nr; i++) { double dd = M_(Hr, nr, i, i) * M_(Hr, nr, i, i); if (dd < lo) lo = dd; if (dd > hi) hi = dd; }
+		if (lo < 1e-9 * hi) { free(Q); free(T); free(Hr); return 2; }
 	}
 	if (!rc) {
 		/* W0 = Z Hr^-1 Z' : solve Hr X = Z' column by column (X is nr x n), W0 = Z X */

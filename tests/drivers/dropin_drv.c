@@ -7,7 +7,10 @@
  * "obstacle": the kincar lane change with order-6 splines on 10 intervals and the nonlinear trajectory
  * inequality (x-20)^2 + (y-0.5)^2 >= 9 (host callback) -- exercises the nonlinear-constraint path of ntg().
  * "ineq": the shipped kincar problem with two final-flag rows relaxed to ranges (linear inequality rows).
- * Usage: dropin_drv vanderpol|kincar|obstacle|ineq   -> prints "RESULT inform objective c0 c1 ..."
+ * "sequence": vanderpol, kincar, vanderpol again in ONE process (ntg() keeps file-scope state like the reference,
+ * ntg.c:17-41: repeated calls with different shapes must not leak into each other); options persist across the calls
+ * as NPSOL's do.  "kincarR": kincar, then the returned factor R (row-major, n x n).
+ * Usage: dropin_drv vanderpol|kincar|obstacle|ineq|sequence|kincarR   -> prints "RESULT inform objective c0 c1 ..."
  */
 #include <math.h>
 #include "ntg.h"
@@ -32,7 +35,7 @@ static void obs_con(int *mode, int *nstate, int *i, double *c, double **dc, doub
 	if (*mode == 0 || *mode == 2) c[0] = dx * dx + dy * dy;
 	if (*mode == 1 || *mode == 2) { for (v = 0; v < 6; v++) dc[0][v] = 0; dc[0][0] = 2 * dx; dc[0][3] = 2 * dy; }
 }
-static int g_obstacle = 0;
+static int g_obstacle = 0, g_printR = 0;
 
 static int run(int nout, int order_, int mult_, int ninterv_, int nbps, int nlic, double **lic, int nlfc, double **lfc,
                double *lowerb, double *upperb, void (*ucf)(int *, int *, int *, double *, double *, double **),
@@ -68,10 +71,29 @@ static int run(int nout, int order_, int mult_, int ninterv_, int nbps, int nlic
 	printf("ISTATE");
 	for (i = 0; i < nc; i++) printf(" %d", istate[ncoef + i]);
 	printf("\n");
+	if (g_printR) {   /* R as NPSOL leaves it: column-major, leading dimension n (ntg.c:234-236: ldR = n) */
+		int j;
+		printf("RMAT %d", ncoef);
+		for (i = 0; i < ncoef; i++) for (j = 0; j < ncoef; j++) printf(" %.17g", R[(size_t)j * ncoef + i]);
+		printf("\n");
+	}
 	return inform;
 }
 
+static int one(int argc, char **argv);
 int main(int argc, char **argv)
+{
+	if (argc > 1 && !strcmp(argv[1], "sequence")) {
+		char *a1[2] = {argv[0], "vanderpol"}, *a2[2] = {argv[0], "kincar"};
+		int rc = one(2, a1);
+		rc |= one(2, a2);
+		rc |= one(2, a1);
+		return rc;
+	}
+	if (argc > 1 && !strcmp(argv[1], "kincarR")) { char *a2[2] = {argv[0], "kincar"}; g_printR = 1; return one(2, a2); }
+	return one(argc, argv);
+}
+static int one(int argc, char **argv)
 {
 	if (argc > 1 && !strcmp(argv[1], "vanderpol")) {
 		static AV tav[3] = {{0, 0}, {0, 1}, {0, 2}};

@@ -25,6 +25,23 @@ def build(tmp_path, name):
     return exe
 
 
+@pytest.mark.parametrize("name", ["vanderpol", "kincar"])
+def test_examples_link_against_the_product_library(tmp_path, name):
+    """the unchanged example sources also compile against include/ntg.h and LINK against libntg_amd.so (the product; it needs
+    a GPU to run, so this container only links): every symbol the examples use is exported with a compatible prototype"""
+    lib = os.path.join(ROOT, "ntg_amd", "libntg_amd.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as ge
+        ge.build()
+    exe = tmp_path / (name + "_amd")
+    subprocess.check_call(["gcc", "-O1", "-w", "-I", os.path.join(ROOT, "include"), os.path.join(REF_EX, name + ".c"),
+                           "-o", str(exe), "-L", os.path.join(ROOT, "ntg_amd"), "-lntg_amd", "-lm",
+                           "-Wl,-rpath," + os.path.join(ROOT, "ntg_amd"), "-Wl,--no-undefined"])
+    und = subprocess.run(["nm", "-u", str(exe)], capture_output=True, text=True, check=True).stdout
+    for sym in ("ntg", "npsoloption", "linspace") + (("SplineInterp",) if name == "kincar" else ("PrintVector",)):
+        assert any(l.split()[-1].split("@")[0] == sym for l in und.splitlines() if l.split()), sym
+
+
 def test_vanderpol_unchanged(tmp_path):
     exe = build(tmp_path, "vanderpol")
     out = subprocess.run([str(exe)], cwd=tmp_path, capture_output=True, text=True, check=True).stdout

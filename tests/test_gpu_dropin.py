@@ -47,6 +47,51 @@ def test_kincar_dropin(drv):
     assert istate == [3] * 12
 
 
+def test_ntg_called_repeatedly_in_one_process(drv):
+    """ntg() three times in one process with two different shapes (SURVEY 8b 'Threading': sequential repeated calls, the MPC use):
+    each call reaches its own optimum, the third equals the first bit for bit"""
+    out = subprocess.run([str(drv), "sequence"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    res = [np.array(l.split()[1:], dtype=float) for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert len(res) == 3
+    assert int(res[0][0]) == 0 and int(res[1][0]) == 0 and int(res[2][0]) == 0
+    assert abs(res[0][1] - 1.7022142628309958) <= 1e-9 and abs(res[1][1] - 2.457581141950512) <= 1e-9
+    assert len(res[0]) == 2 + 7 and len(res[1]) == 2 + 14
+    assert np.array_equal(res[0], res[2])
+
+
+def test_returned_R_factors_the_reduced_hessian(drv):
+    """R (ntg.h:64-68): upper triangular, R'R = W^-1.  The shipped kincar problem is a QP with two degrees of freedom
+    (14 coefficients, 12 equality rows): after its few majors the quasi-Newton matrix carries the exact curvature there,
+    so Z'(R'R)Z must equal the reduced Hessian Z'HZ of the cost (H from central differences of the oracle's gradient)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc, scipy.linalg as sl
+    from ntg_amd import configs as cf
+    out = subprocess.run([str(drv), "kincarR"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    rl = [l for l in out.stdout.splitlines() if l.startswith("RMAT")][0].split()
+    n = int(rl[1]); R = np.array(rl[2:], dtype=float).reshape(n, n)
+    assert n == 14 and np.isfinite(R).all()
+    assert np.abs(np.tril(R, -1)).max() <= 1e-12 * np.abs(R).max()          # upper triangular
+    assert (np.diag(R) > 0).all()
+    spec = cf.config_K0()
+    X = np.vstack([np.zeros((1, n)), np.eye(n)])
+    g = orc.eval_batch(spec, X, 2)["g"]
+    H = g[1:] - g[0]; H = 0.5 * (H + H.T)                                    # the cost is quadratic: exact
+    lo, up = cf.bounds_K0_shipped()
+    Z = sl.null_space(orc.export_tables(spec, lo, up)["A"])
+    Hr = Z.T @ H @ Z; Br = Z.T @ (R.T @ R) @ Z
+    # here Z'HZ = 1.1948 I: the very first search direction is already the Newton direction, so the solve ends after the one
+    # update it needs -- the factor carries the exact curvature along that step and the cold-start identity across it
+    eh = np.linalg.eigvalsh(Hr); eb = np.linalg.eigvalsh(Br)
+    assert abs(eb[-1] - eh[-1]) <= 1e-6 * eh[-1], (eb, eh)
+    assert eb[0] >= 1.0 - 1e-9 and eb[0] <= eh[-1] * (1 + 1e-6)
+    # outside null(A) the approximation was never touched: R'R acts as the identity on range(A')
+    Pr = np.eye(n) - Z @ Z.T
+    assert np.abs(Pr @ (R.T @ R) @ Pr - Pr).max() <= 1e-9
+
+
 def test_exported_callbacks_all_slots_vs_oracle(tmp_path):
     """npsolCostFunction / npsolConstraintFunction (exported NPfunobj / NPfuncon) with host callbacks in
     all six slots, opened with ntg_open(): f, g, c and the dense column-major cJac against the oracle."""
