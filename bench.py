@@ -191,6 +191,29 @@ def main():
                                  "iters_mean": float(oo["iters"].float().mean().item()),
                                  "iters_max": int(oo["iters"].max().item())}
         del wc
+        # ---- the same mode at a saturating batch (65536 problems = 64 per resident workgroup slot): throughput and the
+        #      contract roofline of its launch (algorithmic bytes of the evaluations performed / kernel time) ----
+        nbig = 65536
+        loG, upG = cf.kincar_random_bounds(ncars, 4096)
+        loG = torch.tensor(np.tile(loG, (nbig // 4096, 1)), device=dev); upG = torch.tensor(np.tile(upG, (nbig // 4096, 1)), device=dev)
+        xG = torch.ones((nbig, spec.nC), dtype=torch.float64, device=dev)
+        wG = torch.empty(plan.workspace_bytes(nbig, oc), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            xG.fill_(1.0); ooG = plan.solve(loG, upG, xG, oc, work=wG)
+        torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        tot_ms = 0.0
+        for _ in range(5):
+            xG.fill_(1.0); g0.record(); ooG = plan.solve(loG, upG, xG, oc, work=wG); g1.record(); torch.cuda.synchronize()
+            tot_ms += g0.elapsed_time(g1)
+        msG = tot_ms / 5
+        nfG = int(ooG["nfev"].sum().item())
+        res["to_convergence"]["saturating_batch"] = {
+            "batch": nbig, "ms_per_batch": msG, "value": nbig / (msG * 1e-3), "unit": "trajectories/s", "nfev_per_problem": nfG / nbig,
+            "converged_frac": float((ooG["inform"] == 0).float().mean().item()),
+            "roofline": {"bound": "hbm", "kernel": "sqp_kernel", "achieved": nfG * spec.eval_bytes() / (msG * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": nfG * spec.eval_bytes() / (msG * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+        del wG, xG, loG, upG
         # ---- BASELINE configs[1]: kincar 2 outputs, order 6, 20 intervals, batch 256 ----
         specB = cf.config_B(); planB = api.Plan(specB, local)
         loB, upB = cf.kincar_random_bounds(1, 256)

@@ -10,8 +10,8 @@
 
 struct FastEvalDims {
 	int P, nC, nco, W;          // breakpoints, coefficients, coefficients per output, column width (entries)
-	int chrow[5], chcol[5];     // channel offsets into rowv / colp per derivative (only the CHM ones are used)
-	int row_total, col_total;
+	int chrow[5], chcol[5];     // channel offsets into rowv / colv per derivative (only the CHM ones are used)
+	int row_total, col_total;   // doubles in rowv / colv
 };
 
 // OPG = outputs per lane in the gradient pass (compile time: NOUT / number of lane groups, see launch_eval_fast)
@@ -21,13 +21,13 @@ eval_fast_kernel(FastEvalDims D, NtgTables T, int batch, int mode, const double 
                  double *__restrict__ g)
 {
 	using Fam = Family<FAM>;
-	constexpr int DM = Fam::DM, NCH = chm_count(CHM), NZ = NOUT * DM, NW = NT / 64, XE = 4, WW = colp_words(W);
+	constexpr int DM = Fam::DM, NCH = chm_count(CHM), NZ = NOUT * DM, NW = NT / 64, XE = 4, WP = W + 2;
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	const int P = D.P, nC = D.nC, nco = D.nco, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	// LDS carve-up (all sizes multiples of 16 bytes)
 	double *s_rowv = (double *)smem_raw;
-	unsigned int *s_colp = (unsigned int *)(s_rowv + ((D.row_total + 1) & ~1));
-	int *s_off = (int *)(s_colp + ((D.col_total + 3) & ~3));
+	double *s_colv = s_rowv + ((D.row_total + 1) & ~1);   // 16-byte aligned: row_total is rounded up to even
+	int *s_off = (int *)(s_colv + ((D.col_total + 1) & ~1));
 	double *s_dt = (double *)(s_off + ((P + 3) & ~3));            // bps[i+1] - bps[i]
 	double *s_wts = s_dt + ((P + 1) & ~1);                         // trapezoid weight of node i
 	double *s_x = s_wts + ((P + 1) & ~1);
@@ -35,7 +35,7 @@ eval_fast_kernel(FastEvalDims D, NtgTables T, int batch, int mode, const double 
 	double *s_dfz = s_f + ((P + 1) & ~1);                          // [NOUT*NCH][P+1] + W zeros
 	double *s_red = s_dfz + ((NOUT * NCH * (P + 1) + W + 1) & ~1); // [2][NW] wave partial sums of F, double buffered
 	for (int i = tid; i < D.row_total; i += NT) s_rowv[i] = T.rowv[i];
-	for (int i = tid; i < D.col_total; i += NT) s_colp[i] = T.colp[i];
+	for (int i = tid; i < D.col_total; i += NT) s_colv[i] = T.colv[i];
 	for (int i = tid; i < P; i += NT) {
 		s_off[i] = T.off[i];
 		double w = 0.0;
@@ -123,12 +123,12 @@ eval_fast_kernel(FastEvalDims D, NtgTables T, int batch, int mode, const double 
 #pragma unroll
 			for (int r = 0; r < DM; r++) {
 				if (!((CHM >> r) & 1)) continue;
-				const double *rv = s_rowv + D.chrow[r];
-				int i0; unsigned int pe[W];
-				colp_load<W>(s_colp + D.chcol[r] + cl * WW, i0, pe);
+				// the column's W basis values and its first breakpoint: WP/2 aligned 16-byte reads, 16 lanes = 16 distinct bank groups
 				double vv[W];
+				const double2 *cv = (const double2 *)(s_colv + D.chcol[r] + cl * WP);
 #pragma unroll
-				for (int s2 = 0; s2 < W; s2++) vv[s2] = rv[pe[s2]];
+				for (int s2 = 0; s2 < W / 2; s2++) { const double2 t2 = cv[s2]; vv[2 * s2] = t2.x; vv[2 * s2 + 1] = t2.y; }
+				const int i0 = (int)cv[W / 2].x;
 #pragma unroll
 				for (int j = 0; j < OPG; j++) {
 					const int o = o0 + j;
@@ -163,7 +163,7 @@ static inline size_t eval_fast_lds(const FastEvalDims &D, int nout, int nch, int
 {
 	size_t n = 0;
 	n += (size_t)((D.row_total + 1) & ~1) * 8;
-	n += (size_t)((D.col_total + 3) & ~3) * 4;
+	n += (size_t)((D.col_total + 1) & ~1) * 8;
 	n += (size_t)((D.P + 3) & ~3) * 4;
 	n += 2 * (size_t)((D.P + 1) & ~1) * 8;
 	n += (size_t)((D.nC + 1) & ~1) * 8;
@@ -180,7 +180,7 @@ static inline bool eval_fast_match(const NtgDims &D, int chm, int dm, int nt, Fa
 	const int W = D.cls_W[0];
 	if (W != 8 && W != 12 && W != 16) return false;
 	if (D.ncoef[0] > nt || D.nC > 4 * nt || D.P > 4 * nt) return false;
-	F->P = D.P; F->nC = D.nC; F->nco = D.ncoef[0]; F->W = W; F->row_total = D.row_total; F->col_total = D.col_total;
+	F->P = D.P; F->nC = D.nC; F->nco = D.ncoef[0]; F->W = W; F->row_total = D.row_total; F->col_total = D.colv_total;
 	return true;
 }
 
@@ -188,7 +188,7 @@ template <int FAM, int NOUT, int K, int CHM, int NT>
 static hipError_t launch_eval_fast(const NtgDims &D, const NtgTables &T, FastEvalDims F, const EvalArgs &a)
 {
 	const int ncu = a.ncu > 0 ? a.ncu : 256;
-	for (int r = 0; r < 5; r++) { F.chrow[r] = D.ch_row0[r]; F.chcol[r] = D.ch_col0[r]; }
+	for (int r = 0; r < 5; r++) { F.chrow[r] = D.ch_row0[r]; F.chcol[r] = D.ch_colv0[r]; }
 	const size_t lds = eval_fast_lds(F, NOUT, chm_count(CHM), NT);
 	const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(std::min(8, 32 / (NT / 64)), (160 * 1024) / lds));
 	const int grid = std::min(a.batch, ncu * wg_per_cu);

@@ -42,6 +42,10 @@ struct NtgDims {
 	int n0_blk[NTG_MAX_OUT];            // which dense preconditioner block an output uses (NtgTables::n0b)
 	int ch_row0[NTG_MAX_ORDER], ch_col0[NTG_MAX_ORDER];   // host copy of class 0's channel offsets (NtgTables::chrow/chcol)
 	int tav_rmask;                      // union over outputs of the derivative indices with a cost AV
+	// column form by VALUE for the lean evaluation kernel (class 0 only): per active derivative channel [nco][colv_stride]
+	// doubles = the W basis values of the column at its consecutive breakpoints, then its first breakpoint (as a double);
+	// colv_stride = W + 2: lanes that are consecutive columns read 16-byte words from 16 distinct bank groups
+	int colv_total, colv_stride, ch_colv0[NTG_MAX_ORDER];
 	// structured Newton mode (newton.hpp): coupling groups of nwt_go outputs, nwt_ng free coefficients each (interleaved by
 	// output), half bandwidth nwt_hb, nwt_cg constraint flag entries per group; nwt_on = 0: the plan does not qualify
 	int nwt_on, nwt_ngrp, nwt_go, nwt_ng, nwt_hb, nwt_cg;
@@ -77,6 +81,7 @@ struct NtgTables {
 	// zero); the s-th entry multiplies the weighted gradient at breakpoint i0+s.  WW = colp_words(W) words per column.
 	// chrow/chcol[class*NTG_MAX_ORDER + r] = channel offsets, -1 when no active variable uses D^r
 	const double *rowv; const unsigned int *colp; const int *chrow, *chcol;
+	const double *colv;    // see NtgDims::colv_total
 	// linear rows: erow[mE] = original row of equality e; rowmap[nclin] = e, or -(j+1) for inequality j; linflag[slot]
 	// = 1 for slots declared as inequalities; inequality rows as CSR (by row) and CSC (by coefficient)
 	const int *erow, *rowmap, *linflag, *irow;

@@ -251,6 +251,30 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 				}
 			}
 		}
+		// the same columns by value (class 0; see NtgDims::colv_total)
+		{
+			std::vector<double> colv;
+			const int c = 0, k = D.cls_k[c], P = s->nbps, nc = D.ncoef[rep[c]], W4 = D.cls_W[c], WP = W4 + 2, WW = (W4 / 2 + 1 + 3) & ~3;
+			D.colv_stride = WP;
+			for (int r = 0; r < NTG_MAX_ORDER; r++) D.ch_colv0[r] = -1;
+			for (int r = 0; r < D.cls_d[c]; r++) {
+				if (chcol[(size_t)c * NTG_MAX_ORDER + r] < 0) continue;
+				D.ch_colv0[r] = (int)colv.size();
+				const double *rv = rowv.data() + chrow[(size_t)c * NTG_MAX_ORDER + r];
+				for (int cl = 0; cl < nc; cl++) {
+					const unsigned int *w = &colp[(size_t)chcol[(size_t)c * NTG_MAX_ORDER + r] + (size_t)cl * WW];
+					for (int s2 = 0; s2 < W4; s2++) colv.push_back(rv[(w[1 + s2 / 2] >> (16 * (s2 & 1))) & 0xffffu]);
+					colv.push_back((double)w[0]);
+					colv.push_back(0.0);
+				}
+			}
+			(void)k; (void)P;
+			D.colv_total = (int)colv.size();
+			if (colv.empty()) colv.push_back(0.0);
+			double *d_colv = nullptr;
+			if (dev_upload(&d_colv, colv.data(), colv.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+			T.colv = d_colv;
+		}
 		D.row_total = (int)rowv.size(); D.col_total = (int)colp.size();
 		if (colp.empty()) colp.push_back(0);
 		double *d_rowv = nullptr; unsigned int *d_colp = nullptr; int *d_chrow = nullptr, *d_chcol = nullptr;
