@@ -4,10 +4,17 @@
 // compiles next to fam_kincar.hip.
 #include "solve_impl.hpp"
 #include "eval_fast.hpp"
+#include <cstdlib>
 
 hipError_t ntg_launch_eval_kincar_chm(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a)
 {
 	// values and gradient only (no Jacobian outputs: the family has no constraints): the lean kernel
+	IntervalEvalDims FI;
+	if (!a.c && !a.jb && !a.cj && !getenv("NTG_AMD_EVAL_V1")) {   // one lane per (knot interval, pair of outputs)
+		// (instances for 20 knot intervals: BASELINE's kincar configs; other grids take the breakpoint-lane kernel below)
+		if (D.nout == 2 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 2, 2, 6, 4, 4, 20>(T, FI, a);
+		if (D.nout == 6 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 6, 2, 6, 4, 4, 20>(T, FI, a);
+	}
 	FastEvalDims F;
 	if (a.nt == 128 && !a.c && !a.jb && !a.cj && eval_fast_match(D, 4, 3, 128, &F)) {
 		if (D.nout == 2) return launch_eval_fast<NTG_FAM_KINCAR, 2, 6, 4, 128>(D, T, F, a);

@@ -42,6 +42,7 @@ struct DenseTraj {
 
 template <> struct Family<NTG_FAM_KINCAR> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr bool PER_OUTPUT_COST = true;   // ucf(nout, ...) is a sum of identical terms over the outputs: a subset of the outputs gives its share
 	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
@@ -65,6 +66,7 @@ template <> struct Family<NTG_FAM_KINCAR> {
 
 template <> struct Family<NTG_FAM_VANDERPOL> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
 	static constexpr int NNLIC = 0, NNLTC = 0, NNLFC = 0;
@@ -89,6 +91,7 @@ template <> struct Family<NTG_FAM_VANDERPOL> {
 // dc is [ncon][nz] row-major (== the reference's dc[constraint][variable])
 template <> struct Family<NTG_FAM_TESTFAM> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
 	static constexpr int NNLIC = 1, NNLTC = 2, NNLFC = 1;
@@ -153,6 +156,7 @@ template <> struct Family<NTG_FAM_TESTFAM> {
 
 template <> struct Family<NTG_FAM_OBSTACLE> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 2, CG = 2;   // one group (x, y); constraint flag entries x, y
 	// B (CG x CG) = mu a a' [row active] + t d2c/dz2 [curv]: the second-order model of the row's augmented-Lagrangian term
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *z, const double *t, double mu, bool curv, double *B)
@@ -179,6 +183,7 @@ template <> struct Family<NTG_FAM_OBSTACLE> {
 
 template <> struct Family<NTG_FAM_QUADROTOR> {
 	static constexpr int DM = 5, TAPE = 1;
+	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 4, CG = 6;   // one group; constraint flag entries in flag order: x', x'', y', y'', z', z''
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *z, const double *t, double mu, bool curv, double *B)
 	{
@@ -232,6 +237,7 @@ template <> struct Family<NTG_FAM_QUADROTOR> {
 
 template <> struct Family<NTG_FAM_MANIP> {
 	static constexpr int DM = 3;
+	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int MAXARMS = NTG_MAX_OUT / 3, TAPE = 3 * (NTG_MAX_OUT / 3);
 	static constexpr int COUPLE = 3, CG = 3;   // one group per arm; constraint flag entries qa, qb, qc
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int g, const double *z, const double *t, double mu, bool curv, double *B)

@@ -304,7 +304,7 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 		const int ntc = (nint - color + cover - 1) / cover;   // intervals of this colour
 		for (int w = wave; w < ngp * ntc; w += NW) {
 			const int g = w / ntc, t = color + (w - g * ntc) * cover;
-			const int bp0 = D.nwt_igb[t], cnt = D.nwt_igb[t + 1] - bp0, of = offt[bp0];
+			const int bp0 = D.igb[t], cnt = D.igb[t + 1] - bp0, of = offt[bp0];
 			const int kdim = cnt * cg, ksteps = (kdim + 3) >> 2, nb = cnt * cg * cg;
 			// requests: the interval's blocks ...
 			const double *Bsrc = Bz + ((size_t)g * P + bp0) * cg * cg;

@@ -46,6 +46,10 @@ struct NtgDims {
 	// doubles = the W basis values of the column at its consecutive breakpoints, then its first breakpoint (as a double);
 	// colv_stride = W + 2: lanes that are consecutive columns read 16-byte words from 16 distinct bank groups
 	int colv_total, colv_stride, ch_colv0[NTG_MAX_ORDER];
+	// breakpoint groups of class 0 (consecutive breakpoints with the same block offset = one knot interval): ig_n groups,
+	// group t = breakpoints [igb[t], igb[t+1]); ig_n = 0 when there are more than 64 groups or a group has more than 6 breakpoints
+	int ig_n;
+	unsigned short igb[66];
 	// structured Newton mode (newton.hpp): coupling groups of nwt_go outputs, nwt_ng free coefficients each (interleaved by
 	// output), half bandwidth nwt_hb, nwt_cg constraint flag entries per group; nwt_on = 0: the plan does not qualify
 	int nwt_on, nwt_ngrp, nwt_go, nwt_ng, nwt_hb, nwt_cg;
@@ -55,7 +59,6 @@ struct NtgDims {
 	int nwt_nint, nwt_cover;
 	u64 nwt_upack;
 	int nwt_clo, nwt_chi;               // the free local coefficients of every output: [clo, chi); free index p = (cl - clo) go + o
-	unsigned short nwt_igb[66];         // first breakpoint of every group, nwt_igb[nint] = P
 };
 
 struct NtgTables {

@@ -275,6 +275,14 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 			if (dev_upload(&d_colv, colv.data(), colv.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 			T.colv = d_colv;
 		}
+		// breakpoint groups of class 0 (NtgDims::ig_n)
+		{
+			const int P = s->nbps; const int *off = p->h_off.data();
+			int n = 0; bool ok = true;
+			for (int i = 0; i < P && ok;) { int j = i; while (j < P && off[j] == off[i]) j++; if (n >= 64 || j - i > 6) ok = false; else D.igb[n++] = (unsigned short)i; i = j; }
+			D.ig_n = ok ? n : 0;
+			if (ok) D.igb[n] = (unsigned short)P;
+		}
 		D.row_total = (int)rowv.size(); D.col_total = (int)colp.size();
 		if (colp.empty()) colp.push_back(0);
 		double *d_rowv = nullptr; unsigned int *d_colp = nullptr; int *d_chrow = nullptr, *d_chcol = nullptr;
@@ -509,9 +517,7 @@ static int build_newton_tables(ntg_plan *p)
 		for (int o = 0; o < go; o++) for (int r = 0; r < dm; r++) if ((gmask >> (dm * o + r)) & 1ull) { upack |= (u64)((o << 4) | r) << (8 * u); u++; }
 		if (u != cg || cg > 8) return 0;
 	}
-	if (nint > 64) return 0;
-	for (int t = 0; t < nint; t++) { D.nwt_igb[t] = (unsigned short)ig[2 * t]; if (ig[2 * t + 1] > 6) return 0; }   // at most 6 breakpoints per knot interval
-	D.nwt_igb[nint] = (unsigned short)P;
+	if (D.ig_n != nint) return 0;   // more than 64 groups or more than 6 breakpoints in one (see NtgDims::ig_n)
 	D.nwt_nint = nint; D.nwt_cover = cover; D.nwt_upack = upack;
 	// the free coefficients must be the same contiguous range [clo, chi) of every output (pinned ends)
 	{
