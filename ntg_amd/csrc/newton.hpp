@@ -81,96 +81,140 @@ __device__ __forceinline__ nwt_d4 nwt_load_tile2(const double *__restrict__ Kc, 
 	return t;
 }
 
+__device__ __forceinline__ double nwt_rcp(double p)      // 1/p: hardware estimate + two Newton steps with fused residuals
+{
+	double r = __builtin_amdgcn_rcp(p);
+	r = fma(r, fma(-p, r, 1.0), r);
+	r = fma(r, fma(-p, r, 1.0), r);
+	return r;
+}
+__device__ __forceinline__ double nwt_rsqrt(double p)    // 1/sqrt(p): hardware estimate, then coupled Goldschmidt steps (g -> sqrt, h -> 1/(2 sqrt))
+{
+	const double y0 = __builtin_amdgcn_rsq(p);
+	double g = p * y0, h = 0.5 * y0, rr = fma(-h, g, 0.5);
+	g = fma(g, rr, g); h = fma(h, rr, h);
+	rr = fma(-h, g, 0.5);
+	g = fma(g, rr, g); h = fma(h, rr, h);
+	rr = fma(-h, g, 0.5);
+	h = fma(h, rr, h);
+	return 2.0 * h;
+}
+
 // Band Cholesky K = L L' of one group by ONE wavefront, in place; the diagonal of the factor is stored INVERTED (1 / L_jj:
 // the triangular solves multiply).  panel: LDS scratch of 48 * NWT_PSTRIDE doubles owned by this wave.  Returns the number of
-// non-positive pivots: with strict the factor is then unusable; otherwise each was replaced by a tiny positive number
-// (the Gauss-Newton matrix is positive definite up to rounding).
+// non-positive pivots: with strict the factor is then unusable (the sweep stops at that block column); otherwise each was
+// replaced by a tiny positive number (the Gauss-Newton matrix is positive definite up to rounding).
 // The six window tiles stay in the accumulator layout of the matrix instruction throughout (lane l, register r <->
-// element (4 r + l/16, l%16)).  Pivot j of the 48 x 16 panel: the 12 entries of column j go to LDS (the four lanes that
-// hold them), every lane reads back the pivot, the multipliers of its rows and the multiplier of its column, and
-// applies the rank-1 update  T = keep T + c m  per element:  keep = 0, m = 1/l_jj on column j itself (scaling: those lanes
-// hold c), keep = 1, m = -l_kj / l_jj^2 on the columns k > j, m = 0 on the finished columns.
-NWT_FN int nwt_factor_wave(double *__restrict__ Kc, int ng, int hb, double *panel, int strict)
+// element (4 r + l/16, l%16)).  Per block column:
+//   1. the 16 pivots run over the diagonal tile T00 and an identity tile E only: column j of both goes to LDS (the four lanes
+//      that hold it), every lane reads back the pivot, the entry of its own column in row... (row l%16) and the multipliers of
+//      its rows, and applies  T += c m,  m = -c_j[k] / pivot  on the columns k > j -- columns are NOT scaled inside the sweep
+//      (no special case for column j, and the reciprocal of the pivot replaces a reciprocal square root on the critical path);
+//      afterwards every lane scales its own column once by 1/sqrt(pivot): T00 = L00, E = L00^-T;
+//   2. the sub-diagonal tiles by the matrix cores, X = T L00^-T: E in the accumulator layout IS the B operand, T goes
+//      through LDS into the operand layout;
+//   3. the trailing update T -= X X' of the window, 12 matrix instructions, X through LDS into the operand layout.
+__device__ __forceinline__ void nwt_to_operand(const nwt_d4 &T, double *xb, int li, int lk, double (&op)[4])
+{
+#pragma unroll
+	for (int r = 0; r < 4; r++) xb[(4 * r + lk) * NWT_PSTRIDE + li] = T[r];
+	nwt_wave_sync();
+#pragma unroll
+	for (int s = 0; s < 4; s++) op[s] = xb[li * NWT_PSTRIDE + 4 * s + lk];   // X[l%16][4 s + l/16]: A[i][k] as well as B[k][j] = X'[k][j]
+	nwt_wave_sync();
+}
+__device__ __attribute__((noinline)) int nwt_factor_wave(double *__restrict__ Kc, int ng, int hb, double *panel, int strict)
 {
 	const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
-	double *colbuf = panel, *xbuf = panel + 64;   // 48 doubles; 2 tiles of 16 x NWT_PSTRIDE
+	double *colbuf = panel, *xbuf = panel + 64;   // 32 doubles; one tile of 16 x NWT_PSTRIDE
 	int fail = 0;
-	nwt_d4 T00 = nwt_load_tile2(Kc, ng, hb, 0, 0, lane), T10 = nwt_load_tile2(Kc, ng, hb, 1, 0, lane), T11 = nwt_load_tile2(Kc, ng, hb, 1, 1, lane);
-	nwt_d4 T20 = nwt_load_tile2(Kc, ng, hb, 2, 0, lane), T21 = nwt_load_tile2(Kc, ng, hb, 2, 1, lane), T22 = nwt_load_tile2(Kc, ng, hb, 2, 2, lane);
+	// Addressing of the window relative to block column J: element (tile row a, register r) of a tile whose columns are block J + b sits
+	// at  Kc[16 J ld + off],  off = (16 a + 4 r + lk) (ld - 1) + 16 b + li + hb  -- a lane constant; whether it lies inside the band
+	// is a lane constant too.  Only "row < ng" (the end of the matrix) and "column >= 0" move with J.
+	auto off_of = [&](int a, int b, int r) { return (16 * a + 4 * r + lk) * (ld - 1) + 16 * b + li + hb; };
+	auto inband = [&](int a, int b, int r) { const int d = 16 * (a - b) + 4 * r + lk - li; return d >= 0 && d <= hb; };   // row - column
+	auto load_tile = [&](int J, int a, int b) {   // tile (J + a, J + b) in the accumulator layout; identity beyond the end of the matrix
+		nwt_d4 t;
+		const double *base = Kc + (size_t)16 * J * ld;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int row = 16 * (J + a) + 4 * r + lk;
+			const bool ok = inband(a, b, r) && row < ng;
+			const double v = base[ok ? off_of(a, b, r) : 0];
+			t[r] = ok ? v : ((row >= ng && a == b && 4 * r + lk == li) ? 1.0 : 0.0);
+		}
+		return t;
+	};
+	nwt_d4 T00 = load_tile(0, 0, 0), T10 = load_tile(0, 1, 0), T11 = load_tile(0, 1, 1);
+	nwt_d4 T20 = load_tile(0, 2, 0), T21 = load_tile(0, 2, 1), T22 = load_tile(0, 2, 2);
 	for (int J = 0; J < nbr; J++) {
 		// next block row of the window: in flight during the panel factorisation
-		const nwt_d4 N0 = nwt_load_tile2(Kc, ng, hb, J + 3, J + 1, lane), N1 = nwt_load_tile2(Kc, ng, hb, J + 3, J + 2, lane), N2 = nwt_load_tile2(Kc, ng, hb, J + 3, J + 3, lane);
-		double dinv = 0.0;   // 1 / l_jj of this lane's column (kept by the lanes of the diagonal element)
+		const nwt_d4 N0 = load_tile(J, 3, 1), N1 = load_tile(J, 3, 2), N2 = load_tile(J, 3, 3);
+		nwt_d4 E;
+#pragma unroll
+		for (int r = 0; r < 4; r++) E[r] = (4 * r + lk == li) ? 1.0 : 0.0;
+		double mypiv = 1.0;   // pivot of this lane's column
 #pragma unroll
 		for (int j = 0; j < 16; j++) {
-			if (li == j) {   // column j: rows 4 r + lk of the three tiles
+			if (li == j) {   // column j: rows 4 r + lk of the two tiles
 #pragma unroll
-				for (int r = 0; r < 4; r++) { colbuf[4 * lk + r] = T00[r]; colbuf[16 + 4 * lk + r] = T10[r]; colbuf[32 + 4 * lk + r] = T20[r]; }
+				for (int r = 0; r < 4; r++) { colbuf[4 * lk + r] = T00[r]; colbuf[16 + 4 * lk + r] = E[r]; }
 			}
 			nwt_wave_sync();
 			double piv = colbuf[(j & 3) * 4 + (j >> 2)];
-			double c0[4], c1[4], c2[4];
+			const double ckj = colbuf[(li & 3) * 4 + (li >> 2)];   // entry (row li, column j) of the diagonal tile
+			double c0[4], cE[4];
 #pragma unroll
-			for (int r = 0; r < 4; r++) { c0[r] = colbuf[4 * lk + r]; c1[r] = colbuf[16 + 4 * lk + r]; c2[r] = colbuf[32 + 4 * lk + r]; }
-			const double lkj = colbuf[(li & 3) * 4 + (li >> 2)];   // raw entry (row li, column j) of the diagonal tile
+			for (int r = 0; r < 4; r++) { c0[r] = colbuf[4 * lk + r]; cE[r] = colbuf[16 + 4 * lk + r]; }
 			if (!(piv > 0.0)) {
 				fail++;
 				piv = strict ? 1.0 : 1e-30;
 			}
-#ifdef NWT_EXACT_SQRT
-			const double y = 1.0 / sqrt(piv);
-#else
-			// 1/sqrt(piv): hardware estimate, then two coupled Goldschmidt steps with fused residuals (g -> sqrt, h -> 1/(2 sqrt))
-			double y;
-			{
-				const double y0 = __builtin_amdgcn_rsq(piv);
-				double g = piv * y0, h = 0.5 * y0, rr = fma(-h, g, 0.5);
-				g = fma(g, rr, g); h = fma(h, rr, h);
-				rr = fma(-h, g, 0.5);
-				g = fma(g, rr, g); h = fma(h, rr, h);
-				rr = fma(-h, g, 0.5);
-				h = fma(h, rr, h);
-				y = 2.0 * h;
-			}
-#endif
-			// column j itself is scaled (T = c y: these lanes hold c), the columns k > j get T -= c l_kj / l_jj, the finished
-			// columns stay: one multiply and one fused multiply-add per element, each result rounded once
-			const double keep = li == j ? 0.0 : 1.0;
-			const double m = li == j ? y : (li > j ? -(lkj * y) * y : 0.0);
-			if (li == j) dinv = y;
+			const double m = li > j ? -ckj * nwt_rcp(piv) : 0.0;
+			if (li == j) mypiv = piv;
 #pragma unroll
-			for (int r = 0; r < 4; r++) { T00[r] = fma(c0[r], m, T00[r] * keep); T10[r] = fma(c1[r], m, T10[r] * keep); T20[r] = fma(c2[r], m, T20[r] * keep); }
+			for (int r = 0; r < 4; r++) { T00[r] = fma(c0[r], m, T00[r]); E[r] = fma(cE[r], m, E[r]); }
 			nwt_wave_sync();   // the column is consumed before the next one overwrites it
 		}
+		const double dinv = nwt_rsqrt(mypiv);
+#pragma unroll
+		for (int r = 0; r < 4; r++) { T00[r] *= dinv; E[r] *= dinv; }
+		// sub-diagonal tiles: X = T L00^-T = T E  (E[k][j] in the accumulator layout = operand B[k = 4 s + l/16][j = l%16])
+		{
+			double a1[4], a2[4];
+			nwt_to_operand(T10, xbuf, li, lk, a1);
+			nwt_to_operand(T20, xbuf, li, lk, a2);
+			nwt_d4 X1 = {0.0, 0.0, 0.0, 0.0}, X2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+			for (int s = 0; s < 4; s++) {
+				X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], E[s], X1, 0, 0, 0);
+				X2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[s], E[s], X2, 0, 0, 0);
+			}
+			T10 = X1; T20 = X2;
+		}
 		// the finished block column of L to HBM (band entries only; the diagonal inverted)
+		{
+			double *base = Kc + (size_t)16 * J * ld;
+			const int rows_left = ng - 16 * J;
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
-			const int rr = 4 * r + lk, col = 16 * J + li;
-			const int row0 = 16 * J + rr, row1 = row0 + 16, row2 = row0 + 32;
-			if (row0 < ng && col <= row0 && row0 - col <= hb) Kc[NWT_IDX((long long)row0 * ld + (col - row0 + hb), (long long)ng * ld, "st0")] = rr == li ? dinv : T00[r];
-			if (row1 < ng && row1 - col <= hb) Kc[NWT_IDX((long long)row1 * ld + (col - row1 + hb), (long long)ng * ld, "st1")] = T10[r];
-			if (row2 < ng && row2 - col <= hb) Kc[NWT_IDX((long long)row2 * ld + (col - row2 + hb), (long long)ng * ld, "st2")] = T20[r];
+			for (int r = 0; r < 4; r++) {
+				const int rr = 4 * r + lk;
+				if (inband(0, 0, r) && rr < rows_left) base[off_of(0, 0, r)] = rr == li ? dinv : T00[r];
+				if (inband(1, 0, r) && 16 + rr < rows_left) base[off_of(1, 0, r)] = T10[r];
+				if (inband(2, 0, r) && 32 + rr < rows_left) base[off_of(2, 0, r)] = T20[r];
+			}
 		}
-		// the two sub-diagonal tiles X1, X2 through LDS into the operand layout of the matrix instruction:
-		// lane l supplies X[l%16][4 s + l/16] both as A[i][k] and as B[k][j] = X'[k][j]
+		// trailing update of the window
+		{
+			double x1[4], x2[4];
+			nwt_to_operand(T10, xbuf, li, lk, x1);
+			nwt_to_operand(T20, xbuf, li, lk, x2);
 #pragma unroll
-		for (int r = 0; r < 4; r++) {
-			xbuf[(4 * r + lk) * NWT_PSTRIDE + li] = T10[r];
-			xbuf[(16 + 4 * r + lk) * NWT_PSTRIDE + li] = T20[r];
-		}
-		nwt_wave_sync();
-		double x1[4], x2[4];
-#pragma unroll
-		for (int s = 0; s < 4; s++) {
-			x1[s] = xbuf[li * NWT_PSTRIDE + 4 * s + lk];
-			x2[s] = xbuf[(16 + li) * NWT_PSTRIDE + 4 * s + lk];
-		}
-		nwt_wave_sync();
-#pragma unroll
-		for (int s = 0; s < 4; s++) {
-			T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s], x1[s], T11, 0, 0, 0);
-			T21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x1[s], T21, 0, 0, 0);
-			T22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x2[s], T22, 0, 0, 0);
+			for (int s = 0; s < 4; s++) {
+				T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s], x1[s], T11, 0, 0, 0);
+				T21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x1[s], T21, 0, 0, 0);
+				T22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x2[s], T22, 0, 0, 0);
+			}
 		}
 		T00 = T11; T10 = T21; T11 = T22; T20 = N0; T21 = N1; T22 = N2;
 		if (strict && fail) break;   // not positive definite: the caller repeats with the Gauss-Newton terms, the rest is not needed
@@ -281,8 +325,10 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(const double *__restric
 // Bz: [ngrp][P][cg*cg] of this problem, or nullptr (cost model alone: phase 0, mu == 0).  wbuf: LDS, 216 doubles per wave.
 template <int NT>
 NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *rowv, const int *chrow, const int *offt,
-                                                       const double *__restrict__ Bz, double *__restrict__ Kc, double *wbuf_all)
+                                                       const double *__restrict__ Bz, double *__restrict__ Kc, double *wbuf_all,
+                                                       unsigned long long *tkx = nullptr)
 {
+	unsigned long long tx0 = tkx ? __builtin_amdgcn_s_memtime() : 0;
 	constexpr int NW = NT / 64;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
 	const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ld = hb + 1, go = D.nwt_go, cg = D.nwt_cg, P = D.P;
@@ -290,6 +336,7 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 	const u64 upack = D.nwt_upack;
 	for (int e = tid; e < total; e += NT) Kc[e] = T.nwt_k0[e];
 	__syncthreads();
+	if (tkx) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tkx[0] += t1 - tx0; tx0 = t1; }
 	if (!Bz) return;
 	double *wbuf = wbuf_all + wave * 216;
 	// the two local columns (block-coefficient index a = q go + o) this lane stands for in the operand tiles

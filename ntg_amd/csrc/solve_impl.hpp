@@ -1168,8 +1168,10 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 // NWT: the structured Newton mode (ntg_solve_opts.hessian = 2, newton.hpp): W is the inverse of the banded second-order
 // model of the augmented Lagrangian, refactored at every major iteration; no quasi-Newton pairs.  The solve starts with
 // a pass on the objective alone (mu = 0, "phase 0") before the augmented-Lagrangian passes.
+// (The Newton instances of 256 lanes run one wave per SIMD anyway -- one workgroup per CU, by LDS -- and are compiled for it: the
+// inlined factorisation and assembly then keep their window tiles and addresses in registers instead of scratch.)
 template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS, int CHM, bool NWT = false>
-__global__ void __launch_bounds__(NT, NTG_SQP_WAVES)
+__global__ void __launch_bounds__(NT, (NWT && NT <= 256) ? 1 : NTG_SQP_WAVES)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
            double *__restrict__ objective, int *__restrict__ inform_out, int *__restrict__ iters_out,
@@ -1245,7 +1247,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[6] += now_ - tlast; tlast = now_; }
 			if (tid == 0) nwt_flag[0] = 0;
-			nwt_assemble<NT>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y));   // ends with a full barrier
+			nwt_assemble<NT>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), sp.stamps == 4 ? tk : nullptr);   // ends with a full barrier
 			NTG_STAMP(3);
 			if (wave < ngp) {
 				const int f = nwt_factor_wave(nwt_K + (size_t)wave * ng * (hb + 1), ng, hb, panel + (size_t)wave * 48 * NWT_PSTRIDE, curv ? 1 : 0);
@@ -1605,7 +1607,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			clambda[(size_t)b * ntot + i] = v;
 		}
-		if (sp.stamps == 1 && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
+		if ((sp.stamps == 1 || sp.stamps == 4) && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
 		if (sp.stamps == 3 && tid == 0) {   // diagnostic: work counters of the structured Newton mode
 			double *o = clambda + (size_t)b * ntot;
 			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev;

@@ -8,17 +8,21 @@
 #include <vector>
 #include "../../ntg_amd/csrc/solve_impl.hpp"
 
-__global__ void unit_kernel(double *K, int ng, int hb, double *yio, int *fail)
+__global__ void __launch_bounds__(64) unit_kernel(double *K, int ng, int hb, double *yio, int *fail, long long *cyc)
 {
 	extern __shared__ double sm[];
 	double *y = sm, *panel = sm + 16 * ((ng + 15) / 16) + 48;
 	const int ylen = 16 * ((ng + 15) / 16) + 48;
 	for (int i = threadIdx.x; i < ylen; i += 64) y[i] = i < ng ? yio[i] : 0.0;
 	__syncthreads();
+	const long long t0 = __builtin_amdgcn_s_memtime();
 	const int f = nwt_factor_wave(K, ng, hb, panel, 1);
 	__syncthreads();
+	const long long t1 = __builtin_amdgcn_s_memtime();
 	nwt_solve_wave(K, ng, hb, y);
 	__syncthreads();
+	const long long t2 = __builtin_amdgcn_s_memtime();
+	if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = t2 - t1; }
 	for (int i = threadIdx.x; i < ng; i += 64) yio[i] = y[i];
 	if (threadIdx.x == 0) *fail = f;
 }
@@ -51,14 +55,16 @@ int main(int argc, char **argv)
 	x = rhs;
 	for (int i = 0; i < ng; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[(size_t)i * ng + k] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
 	for (int i = ng - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < ng; k++) s -= L[(size_t)k * ng + i] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
-	double *dK, *dy; int *df;
-	hipMalloc(&dK, K.size() * 8); hipMalloc(&dy, ng * 8); hipMalloc(&df, 4);
+	double *dK, *dy; int *df; long long *dc, hc[2] = {0, 0};
+	hipMalloc(&dK, K.size() * 8); hipMalloc(&dy, ng * 8); hipMalloc(&df, 4); hipMalloc(&dc, 16);
 	hipMemcpy(dK, K.data(), K.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dy, rhs.data(), ng * 8, hipMemcpyHostToDevice);
 	const size_t lds = (size_t)(16 * ((ng + 15) / 16) + 48 + 48 * NWT_PSTRIDE) * 8;
-	hipLaunchKernelGGL(unit_kernel, dim3(1), dim3(64), lds, 0, dK, ng, hb, dy, df);
+	hipLaunchKernelGGL(unit_kernel, dim3(1), dim3(64), lds, 0, dK, ng, hb, dy, df, dc);
 	std::vector<double> y(ng), Lg(K.size()); int fail = -1;
 	if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
 	hipMemcpy(y.data(), dy, ng * 8, hipMemcpyDeviceToHost); hipMemcpy(&fail, df, 4, hipMemcpyDeviceToHost); hipMemcpy(Lg.data(), dK, K.size() * 8, hipMemcpyDeviceToHost);
+	hipMemcpy(hc, dc, 16, hipMemcpyDeviceToHost);
+	printf("  clock ticks (s_memtime, 100 MHz): factor %lld (%.1f per block column), solve %lld (%.1f per block)\n", hc[0], (double)hc[0] / ((ng + 15) / 16), hc[1], (double)hc[1] / ((ng + 15) / 16));
 	double errL = 0.0, err = 0.0, nx = 0.0;
 	for (int i = 0; i < ng; i++) for (int e = 0; e <= hb; e++) { const int j = i - hb + e; if (j < 0) continue; const double ref = (i == j) ? 1.0 / L[(size_t)i * ng + i] : L[(size_t)i * ng + j]; errL = fmax(errL, fabs(Lg[(size_t)i * ld + e] - ref) / fabs(ref)); }
 	for (int i = 0; i < ng; i++) { err = fmax(err, fabs(y[i] - x[i])); nx = fmax(nx, fabs(x[i])); }

@@ -30,6 +30,12 @@ for hess in (2, 1):
     dt = time.time() - t0
     inf = out["inform"].cpu().numpy(); it = out["iters"].cpu().numpy(); nf = out["nfev"].cpu().numpy()
     print(f"{which} hessian={hess} batch {B}: {dt*1e3:.2f} ms -> {B/dt:.0f} traj/s; inform {np.bincount(inf)} majors mean {it.mean():.1f} max {it.max()} nfev mean {nf.mean():.1f}", flush=True)
+    if os.environ.get("NTG_AMD_STAMPS") == "4" and hess == 2:
+        x.fill_(1.0)
+        o2 = plan.solve(lo_t, up_t, x, opts, want_lambda=True)
+        torch.cuda.synchronize()
+        tk = o2["clambda"][:, :8].cpu().numpy()
+        print("  assemble: K0 copy ticks/problem %.0f ; all phases" % tk[:, 0].mean(), tk.mean(axis=0))
     if os.environ.get("NTG_AMD_STAMPS") == "1":
         x.fill_(1.0)
         o2 = plan.solve(lo_t, up_t, x, opts, want_lambda=True)
