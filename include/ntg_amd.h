@@ -19,6 +19,8 @@
  *   npsolCostFunction / npsolConstraintFunction
  *                        ntg.c:274-280 / ntg.c:337-346  (static NPfunobj / NPfuncon; exported
  *                        under the names BASELINE.json uses, same Fortran-style signature)
+ *   ntg_batch_interp     colloc.c:449-484 SplineInterp, for a batch
+ *   ntg_batch_kincar_reverse  examples/kincar.c:68-92 kincar_flat_reverse (the example's flat-to-state map), for a batch
  *   ntg(), npsoloption(), linspace(), SplineInterp(), matrix helpers: see include/ntg.h
  */
 #ifndef NTG_AMD_H
@@ -144,6 +146,13 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
  * D^r z_o(t).  This is the input of a flat-to-state map such as kincar_flat_reverse (kincar.c:68-92). */
 int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times, double *d_z,
                      void *stream);
+
+/* The flat-to-state map of the kinematic car for a whole ntg_batch_interp result (examples/kincar.c:68-92 kincar_flat_reverse,
+ * called per sample by the example's output loop, kincar.c:392-406): d_z [batch][ntimes][nz] -> d_state [batch][ntimes][ncars][5] =
+ * x, y, theta, v, delta for every car (ncars = nout / 2; outputs 2c, 2c+1 are the rear-axle position of car c).  reverse_gear != 0
+ * is the reference's dir == 'r'.  kincar-family plans only. */
+int ntg_batch_kincar_reverse(const ntg_plan *p, int batch, int ntimes, const double *d_z, double wheelbase, int reverse_gear,
+                             double *d_state, void *stream);
 
 /* Receding-horizon step (the warm-start use NPSOL's istate/clambda/R were meant for, ntg.h:64-68):
  * re-pin the linear initial-constraint bounds of every problem to the flat flag of its current

@@ -70,6 +70,7 @@ def lib():
         L.ntg_basis_batch.argtypes = [C.c_int] * 6 + [C.c_void_p] * 5
         L.ntg_batch_mpc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_longlong, C.c_void_p]
         L.ntg_batch_interp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ntg_batch_kincar_reverse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.ntg_batch_mpc_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -220,6 +221,14 @@ class Plan:
         z = torch.empty((x.shape[0], times.numel(), self.spec.nz), dtype=torch.float64, device=x.device)
         _check(lib().ntg_batch_interp(self.h, x.shape[0], _ptr(x), times.numel(), _ptr(times.contiguous()), _ptr(z), self._stream()))
         return z
+
+    def kincar_reverse(self, z, wheelbase: float = 3.0, reverse_gear: bool = False):
+        """Flat flag -> (x, y, theta, v, delta) per car: z [batch, ntimes, nz] (from interp) -> [batch, ntimes, ncars, 5]."""
+        import torch
+        _check_tensor(z, z.device)
+        out = torch.empty((z.shape[0], z.shape[1], self.spec.nout // 2, 5), dtype=torch.float64, device=z.device)
+        _check(lib().ntg_batch_kincar_reverse(self.h, z.shape[0], z.shape[1], _ptr(z), C.c_double(wheelbase), int(reverse_gear), _ptr(out), self._stream()))
+        return out
 
     def mpc_shift(self, x, lower, upper, shift_bp: int, shift_knots: int):
         """Receding-horizon step in place: re-pin initial bounds to the solution's flag at breakpoint

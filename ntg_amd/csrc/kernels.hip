@@ -475,6 +475,32 @@ hipError_t ntg_launch_interp(const NtgDims &D, int batch, int ntimes, const doub
 	return hipGetLastError();
 }
 
+// Flat flag -> state and input of the kinematic car, the map of examples/kincar.c:68-92 (kincar_flat_reverse), for every car
+// of every problem at every time of an ntg_batch_interp result: z [n][nz] with the flag of car c at entries 6 c .. 6 c + 5
+// (x, x', x'', y, y', y'') -> out [n][ncars][5] = x, y, theta, v, delta.  One thread per (sample, car).
+__global__ void kincar_reverse_kernel(long long nsamp, int nz, int ncars, double wheelbase, int reverse_gear,
+                                      const double *__restrict__ z, double *__restrict__ out)
+{
+	const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= nsamp * ncars) return;
+	const long long smp = idx / ncars; const int c = (int)(idx - smp * ncars);
+	const double *f = z + smp * nz + 6 * c;
+	const double xd = f[1], xdd = f[2], yd = f[4], ydd = f[5];
+	const double th = reverse_gear ? atan2(-yd, -xd) : atan2(yd, xd);   // kincar.c:78-86
+	double sn, cs;
+	sincos(th, &sn, &cs);
+	const double thdot_v = ydd * cs - xdd * sn, v = xd * cs + yd * sn;   // kincar.c:89-90
+	double *o = out + idx * 5;
+	o[0] = f[0]; o[1] = f[3]; o[2] = th; o[3] = v; o[4] = atan2(thdot_v, v * v / wheelbase);   // kincar.c:91 (pow(u[0], 2.0) / b)
+}
+hipError_t ntg_launch_kincar_reverse(long long nsamp, int nz, int ncars, double wheelbase, int reverse_gear, const double *z, double *out, hipStream_t st)
+{
+	const long long total = nsamp * ncars;
+	if (total == 0) return hipSuccess;
+	hipLaunchKernelGGL(kincar_reverse_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, nsamp, nz, ncars, wheelbase, reverse_gear, z, out);
+	return hipGetLastError();
+}
+
 // receding-horizon bookkeeping: how many problems of the last re-solve did not end with inform 0
 __global__ void count_notconv_kernel(int batch, const int *__restrict__ inform, int *__restrict__ count)
 {

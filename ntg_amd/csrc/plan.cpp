@@ -931,6 +931,21 @@ extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x,
 	return 0;
 }
 
+extern "C" int ntg_batch_kincar_reverse(const ntg_plan *p, int batch, int ntimes, const double *d_z, double wheelbase, int reverse_gear,
+                                        double *d_state, void *stream)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0 || ntimes <= 0) return 0;
+	if (!d_z || !d_state) return fail(NTG_E_BADARG, "null argument");
+	const NtgDims &D = p->D;
+	if ((D.family != NTG_FAM_KINCAR && D.family != NTG_FAM_OBSTACLE) || D.nout % 2 || D.nz != 3 * D.nout)
+		return fail(NTG_E_UNSUPPORTED, "kincar_flat_reverse needs a kincar-family plan (two outputs per car, three flag entries per output)");
+	if (!(wheelbase > 0.0)) return fail(NTG_E_BADARG, "wheelbase must be positive");
+	HIPCHK(hipSetDevice(p->device));
+	HIPCHK(ntg_launch_kincar_reverse((long long)batch * ntimes, D.nz, D.nout / 2, wheelbase, reverse_gear, d_z, d_state, (hipStream_t)stream));
+	return 0;
+}
+
 extern "C" int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, int nbps, const double *d_knots,
                                const double *d_bps, double *d_blk, int *d_off, void *stream)
 {

@@ -35,6 +35,7 @@ hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const
                             long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st);
 hipError_t ntg_launch_interp(const NtgDims &D, int batch, int ntimes, const double *x, const double *tblk, const int *toff,
                              const int *tblk_base, double *z, hipStream_t st);
+hipError_t ntg_launch_kincar_reverse(long long nsamp, int nz, int ncars, double wheelbase, int reverse_gear, const double *z, double *out, hipStream_t st);
 hipError_t ntg_launch_count_notconv(int batch, const int *inform, int *count, hipStream_t st);
 hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,
                               const double *lfc, double *aband, int *rbp, hipStream_t st);

@@ -145,6 +145,35 @@ def test_batch_interp_matches_spline_interp(name):
     assert rel(z, ref) <= 1e-13
 
 
+def test_kincar_flat_reverse_round_trip():
+    """ntg_batch_kincar_reverse (examples/kincar.c:68-92) after ntg_batch_interp: at both ends of solved config-M problems the
+    state and inputs are the ones the bounds were built from with kincar_flat_forward (kincar.c:46-65; the end flags are pinned
+    by the equality rows), and at interior times the output equals a numpy restatement of the reference's formulas."""
+    spec = SPECS["M"](); p = plan_for("M")
+    nb = 6
+    lo, up = cf.kincar_random_bounds(3, nb)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=1))
+    assert (out["inform"] == 0).all()
+    times = np.array([0.0, 1.3, 2.5, 4.1, float(spec.bps[-1])])
+    z = p.interp(x, dev(times))
+    st = p.kincar_reverse(z, cf.WHEELBASE).cpu().numpy()
+    zz = z.cpu().numpy().reshape(nb, len(times), 3, 2, 3)          # [problem, time, car, x/y, derivative]
+    th = np.arctan2(zz[..., 1, 1], zz[..., 0, 1])
+    v = zz[..., 0, 1] * np.cos(th) + zz[..., 1, 1] * np.sin(th)
+    dl = np.arctan2(zz[..., 1, 2] * np.cos(th) - zz[..., 0, 2] * np.sin(th), v * v / cf.WHEELBASE)
+    ref = np.stack([zz[..., 0, 0], zz[..., 1, 0], th, v, dl], axis=-1)
+    assert np.abs(st - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    # ends: the states and inputs the random bounds were drawn as (same stream as kincar_random_bounds)
+    rng = np.random.default_rng(cf.SEED)
+    for b in range(nb):
+        for c in range(3):
+            x0 = rng.uniform(-5, 5); y0 = rng.uniform(-3, 3); th0 = rng.uniform(-0.3, 0.3); v0 = rng.uniform(4, 12); d0 = rng.uniform(-0.1, 0.1)
+            xf = x0 + rng.uniform(30, 50); yf = rng.uniform(-3, 3); thf = rng.uniform(-0.3, 0.3); vf = rng.uniform(4, 12); df = rng.uniform(-0.1, 0.1)
+            np.testing.assert_allclose(st[b, 0, c], [x0, y0, th0, v0, d0], atol=1e-7)
+            np.testing.assert_allclose(st[b, -1, c], [xf, yf, thf, vf, df], atol=1e-7)
+
+
 def test_full_size_eval_properties_config_M():
     """BASELINE size (4096 x config M), no oracle run: the kincar cost is a quadratic form, so the evaluation must be
     homogeneous of degree 2 in f and linear in g; f = g.x / 2 (Euler) ties the two outputs together; the three NPSOL
