@@ -355,6 +355,37 @@ def main():
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eb / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "evals_per_s": nb / (ems * 1e-3)}
         del xe
+        # ---- per-problem grids (free final time): every problem on its own horizon; the basis rows and weights are then per-problem
+        #      input (counted in the algorithmic bytes) and eval_kernel stages them per problem ----
+        nbg = 16384
+        k0 = np.asarray(spec.knots[0]); rngg = np.random.default_rng(3)
+        scale = rngg.uniform(0.6, 1.6, nbg)[:, None]
+        kn = k0[None, :] * scale
+        jj = np.minimum(np.searchsorted(k0, spec.bps, side="right") - 1, spec.kninterv[0] - 1)
+        fr = (np.asarray(spec.bps) - k0[jj]) / (k0[jj + 1] - k0[jj])
+        bpg = kn[:, jj] + fr[None, :] * (kn[:, jj + 1] - kn[:, jj])
+        inner = jj < spec.kninterv[0] - 1
+        bpg = np.maximum(bpg, kn[:, jj]); bpg[:, inner] = np.minimum(bpg[:, inner], np.nextafter(kn[:, jj + 1][:, inner], -np.inf))
+        bpg[:, -1] = kn[:, -1]
+        pg = api.Plan(spec, local)
+        tg = time.perf_counter()
+        pg.set_grids(torch.tensor(kn, device=dev), torch.tensor(bpg, device=dev), with_precond=False)
+        setup_s = time.perf_counter() - tg
+        xg = torch.randn((nbg, spec.nC), dtype=torch.float64, device=dev)
+        og = pg.eval(xg, 2); pg.eval(xg, 2, out=og); torch.cuda.synchronize()
+        g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        g0.record()
+        for _ in range(10):
+            pg.eval(xg, 2, out=og)
+        g1.record(); torch.cuda.synchronize()
+        gms = g0.elapsed_time(g1) / 10
+        row_bytes = 8 * (sum(1 for r in range(spec.maxderiv[0]) if any(a[1] == r for a in list(spec.tcostav) + list(spec.icostav) + list(spec.fcostav) + list(spec.tcav) + list(spec.icav) + list(spec.fcav))) * spec.order[0] * spec.nbps + spec.nbps)
+        gb = nbg * (spec.eval_bytes() + row_bytes)
+        res["per_problem_grids"] = {"workload": spec.name + ", %d horizons in [0.6, 1.6] x the plan's" % nbg, "kernel": "eval_kernel (general instance, value tables staged per problem)",
+                                    "batch": nbg, "ms": gms, "alg_bytes_per_eval": spec.eval_bytes() + row_bytes, "achieved": gb / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "evals_per_s": nbg / (gms * 1e-3),
+                                    "set_grids_host_s": setup_s}
+        del og, xg, pg
 
     if rank == 0 and world == 1 and not args.no_cpu:
         # ---- CPU baseline: the oracle on a bounded sample of the same workload, on the host cores of this box.  Two flavours

@@ -13,6 +13,7 @@
  *                        colloc.c:57-117 CollocMatrix: knots_/interv_/bsplvd_ at every breakpoint
  *   ntg_plan_tables      colloc.h:42-71  read-back of Block.matrix / Block.offset / A
  *   ntg_basis_batch      colloc.c:92-111 the same basis evaluation for many grids at once
+ *   ntg_plan_set_grids   ntg.c:114-229 per problem: own knots and breakpoints for every problem of a batch
  *   ntg_batch_eval       ntg.c:274-371   NPfunobj + NPfuncon (cost.c, constraints.c, integrator.c)
  *   ntg_batch_bounds     constraints.c:5-33 bounds()
  *   ntg_batch_solve      ntg.c:237-253   the npsol_() call, for `batch` problems at once
@@ -140,6 +141,17 @@ const char *ntg_solve_kernel_name(void);
 int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, int nbps,
                     const double *d_knots, const double *d_bps, double *d_blk, int *d_off,
                     void *stream);
+
+/* Per-problem grids (free final time / per-problem horizons): every problem of a batch gets its own break sequence and breakpoints --
+ * the setup phase of ntg() (ntg.c:114-229: CollocMatrix per output, colloc.c:57-117; LinearConstraintsMatrix, constraints.c:198-261)
+ * run per problem, as the reference runs it per call.  d_knots [batch][ninterv+1], d_bps [batch][nbps] (device).  The combinatorial
+ * structure must be the plan's: one basis class, and every breakpoint in the same knot interval as in the plan's grid (checked;
+ * NTG_E_BADARG otherwise) -- the index tables stay shared, the VALUES (basis blocks, trapezoid weights, linear-constraint rows,
+ * (A A')^-1, projector, with_precond != 0: the preconditioner blocks) become per problem.  Plans with linear equality rows only.
+ * Afterwards ntg_batch_eval / ntg_batch_solve of exactly `batch` problems use these grids (hessian = 2 acts as 1; ntg_batch_interp and
+ * ntg_batch_mpc_run refuse) until ntg_plan_clear_grids(). */
+int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream);
+void ntg_plan_clear_grids(ntg_plan *p);
 
 /* SplineInterp (colloc.c:449-484) for a whole batch: the flat flag of every problem at ntimes points in time shared by
  * the batch (d_times [ntimes], inside the knot range of every output) -> d_z [batch][ntimes][nz], entry iz[o]+r =

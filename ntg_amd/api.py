@@ -70,6 +70,9 @@ def lib():
         L.ntg_basis_batch.argtypes = [C.c_int] * 6 + [C.c_void_p] * 5
         L.ntg_batch_mpc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_longlong, C.c_void_p]
         L.ntg_batch_interp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ntg_plan_set_grids.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.ntg_plan_clear_grids.argtypes = [C.c_void_p]
+        L.ntg_plan_clear_grids.restype = None
         L.ntg_batch_kincar_reverse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.ntg_batch_mpc_shift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -221,6 +224,16 @@ class Plan:
         z = torch.empty((x.shape[0], times.numel(), self.spec.nz), dtype=torch.float64, device=x.device)
         _check(lib().ntg_batch_interp(self.h, x.shape[0], _ptr(x), times.numel(), _ptr(times.contiguous()), _ptr(z), self._stream()))
         return z
+
+    def set_grids(self, knots, bps, with_precond: bool = True):
+        """Per-problem grids: knots [batch, ninterv+1], bps [batch, nbps] (device, float64).  See ntg_plan_set_grids."""
+        _check_tensor(knots, knots.device); _check_tensor(bps, bps.device)
+        if knots.shape[0] != bps.shape[0] or knots.shape[1] != self.spec.kninterv[0] + 1 or bps.shape[1] != self.spec.nbps:
+            raise NtgError("knots must be [batch, ninterv+1] and bps [batch, nbps]")
+        _check(lib().ntg_plan_set_grids(self.h, knots.shape[0], _ptr(knots), _ptr(bps), int(with_precond), self._stream()))
+
+    def clear_grids(self):
+        lib().ntg_plan_clear_grids(self.h)
 
     def kincar_reverse(self, z, wheelbase: float = 3.0, reverse_gear: bool = False):
         """Flat flag -> (x, y, theta, v, delta) per car: z [batch, ntimes, nz] (from interp) -> [batch, ntimes, ncars, 5]."""

@@ -10,13 +10,14 @@ hipError_t ntg_launch_eval_kincar_chm(const NtgDims &D, const NtgTables &T, cons
 {
 	// values and gradient only (no Jacobian outputs: the family has no constraints): the lean kernel
 	IntervalEvalDims FI;
-	if (!a.c && !a.jb && !a.cj && !getenv("NTG_AMD_EVAL_V1")) {   // one lane per (knot interval, pair of outputs)
+	const bool shared_grid = T.pp_rowv == 0;   // the lean kernels stage one grid per workgroup: per-problem grids take eval_kernel
+	if (shared_grid && !a.c && !a.jb && !a.cj && !getenv("NTG_AMD_EVAL_V1")) {   // one lane per (knot interval, pair of outputs)
 		// (instances for 20 knot intervals: BASELINE's kincar configs; other grids take the breakpoint-lane kernel below)
 		if (D.nout == 2 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 2, 2, 6, 4, 4, 20>(T, FI, a);
 		if (D.nout == 6 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 6, 2, 6, 4, 4, 20>(T, FI, a);
 	}
 	FastEvalDims F;
-	if (a.nt == 128 && !a.c && !a.jb && !a.cj && eval_fast_match(D, 4, 3, 128, &F)) {
+	if (shared_grid && a.nt == 128 && !a.c && !a.jb && !a.cj && eval_fast_match(D, 4, 3, 128, &F)) {
 		if (D.nout == 2) return launch_eval_fast<NTG_FAM_KINCAR, 2, 6, 4, 128>(D, T, F, a);
 		if (D.nout == 6) return launch_eval_fast<NTG_FAM_KINCAR, 6, 6, 4, 128>(D, T, F, a);
 	}

@@ -85,6 +85,10 @@ struct NtgTables {
 	// chrow/chcol[class*NTG_MAX_ORDER + r] = channel offsets, -1 when no active variable uses D^r
 	const double *rowv; const unsigned int *colp; const int *chrow, *chcol;
 	const double *colv;    // see NtgDims::colv_total
+	// Per-problem grids (ntg_plan_set_grids): the index tables above stay shared, the VALUES become per problem.  Problem b reads
+	// rowv + b pp_rowv, bps + b pp_bps, csr_val + b pp_lin, csc_val + b pp_lin, sinv_val + b pp_sinv, q_val + b pp_q, n0b + b pp_n0b
+	// (strides in elements; all 0 = one shared grid).
+	long long pp_rowv, pp_bps, pp_lin, pp_sinv, pp_q, pp_n0b;
 	// linear rows: erow[mE] = original row of equality e; rowmap[nclin] = e, or -(j+1) for inequality j; linflag[slot]
 	// = 1 for slots declared as inequalities; inequality rows as CSR (by row) and CSC (by coefficient)
 	const int *erow, *rowmap, *linflag, *irow;

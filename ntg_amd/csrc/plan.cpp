@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <string>
 #include <mutex>
+#include <thread>
+#include <atomic>
 #include <vector>
 #include <utility>
 #include "ntg_dev.hpp"
@@ -290,6 +292,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		    dev_upload(&d_chrow, chrow.data(), chrow.size(), own) ||
 		    dev_upload(&d_chcol, chcol.data(), chcol.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 		T.rowv = d_rowv; T.colp = d_colp; T.chrow = d_chrow; T.chcol = d_chcol;
+		p->h_chrow = chrow;
 		for (int r = 0; r < NTG_MAX_ORDER; r++) { D.ch_row0[r] = chrow[r]; D.ch_col0[r] = chcol[r]; }
 	}
 
@@ -383,6 +386,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		    dev_upload(&d_rv, rval.data(), rval.size(), own) || dev_upload(&d_cp, cptr.data(), cptr.size(), own) ||
 		    dev_upload(&d_cr, crow.data(), crow.size(), own) || dev_upload(&d_cv, cval.data(), cval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 		T.csr_ptr = d_rp; T.csr_col = d_rc; T.csr_val = d_rv; T.csc_ptr = d_cp; T.csc_row = d_cr; T.csc_val = d_cv;
+		p->h_csr_ptr = rptr; p->h_csr_col = rcol; p->h_csc_ptr = cptr; p->h_csc_row = crow; p->h_erow = erow;
 		// (A A')^-1 as CSR, exact zeros dropped (block diagonal when constraint rows decouple)
 		std::vector<int> sptr(m + 1, 0), scol; std::vector<double> sval;
 		for (int i = 0; i < m; i++) { for (int j = 0; j < m; j++) if (Sinv[(size_t)i * m + j] != 0.0) { scol.push_back(j); sval.push_back(Sinv[(size_t)i * m + j]); } sptr[i + 1] = (int)scol.size(); }
@@ -392,6 +396,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		if (dev_upload(&d_sp, sptr.data(), sptr.size(), own) || dev_upload(&d_sc, scol.data(), scol.size(), own) ||
 		    dev_upload(&d_sv, sval.data(), sval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 		T.sinv_ptr = d_sp; T.sinv_col = d_sc; T.sinv_val = d_sv;
+		p->h_sinv_ptr = sptr; p->h_sinv_col = scol;
 		// projector Q = A'(AA')^-1 A: only the coefficients some constraint touches have a non-zero
 		// row; keep those rows as ELL (zero padded) when that is small
 		{
@@ -408,6 +413,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 				    dev_upload(&d_qv, qval.data(), qval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 				T.q_idx = d_qi; T.q_col = d_qc; T.q_val = d_qv;
 				D.q_use = 1; D.q_nt = nt; D.q_w = w;
+				p->h_qidx = qidx; p->h_qcol = qcol;
 			}
 		}
 		// the general three-step operator (A g, (AA')^-1, A' lam) is staged in LDS only when Q is not used
@@ -418,6 +424,9 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 		p->lin_ok = true;
 	}
 	if (s->nlic > 0 && dev_upload(&p->d_lic, s->lic, (size_t)s->nlic * nz, own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+	if (s->nlic > 0) p->h_lic.assign(s->lic, s->lic + (size_t)s->nlic * nz);
+	if (s->nltc > 0) p->h_ltc.assign(s->ltc, s->ltc + (size_t)s->nltc * nz);
+	if (s->nlfc > 0) p->h_lfc.assign(s->lfc, s->lfc + (size_t)s->nlfc * nz);
 	// keep what the preconditioner build needs
 	p->tcostav.assign(s->tcostav, s->tcostav + s->ntcostav);
 	p->icostav.assign(s->icostav, s->icostav + s->nicostav);
@@ -553,6 +562,7 @@ extern "C" void ntg_plan_destroy(ntg_plan *p)
 	if (!p) return;
 	hipSetDevice(p->device);
 	for (void *q : p->owned) hipFree(q);
+	for (void *q : p->grid_owned) hipFree(q);
 	delete p;
 }
 
@@ -805,6 +815,7 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	if (!d_x) return fail(NTG_E_BADARG, "null x");
 	if (mode < 0 || mode > 2) return fail(NTG_E_BADARG, "mode must be 0, 1 or 2");
 	if (p->D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans evaluate through npsolCostFunction");
+	if (p->grid_batch && batch != p->grid_batch) return fail(NTG_E_BADARG, "the plan carries per-problem grids for another batch size");
 	if (batch <= 0) return 0;
 	HIPCHK(hipSetDevice(p->device));
 	const NtgDims &D = p->D;
@@ -835,12 +846,15 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	if (batch <= 0) return 0;
 	if (!d_x || !d_lower || !d_upper) return fail(NTG_E_BADARG, "null argument");
 	if (p->D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans are solved by ntg()");
+	if (p->grid_batch && batch != p->grid_batch) return fail(NTG_E_BADARG, "the plan carries per-problem grids for another batch size");
 	if (!p->lin_ok) return fail(NTG_E_BADARG, "linear constraint rows are rank deficient");
 	if (batch <= 0) return 0;
 	HIPCHK(hipSetDevice(p->device));
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
 	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
+	if (p->grid_batch && sp.hessian == 2) sp.hessian = 1;
+	if (p->grid_batch && sp.hessian == 1 && !p->T.pp_n0b) return fail(NTG_E_BADARG, "per-problem grids were set without the preconditioner (with_precond = 0): solve with hessian = 0");
 	if (sp.hessian == 1) {   // built on first use, once: two threads or streams may first-solve the same plan
 		std::lock_guard<std::mutex> lk(p->precond_mutex);
 		if (!p->precond_ready) { int rc = build_precond(p); if (rc) return rc; }
@@ -868,6 +882,7 @@ extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int s
 	if (batch <= 0 || nsteps <= 0) return 0;
 	if (!d_x || !d_lower || !d_upper || !d_inform) return fail(NTG_E_BADARG, "null argument");
 	if (shift_bp < 0 || shift_bp >= p->D.P || shift_knots < 0) return fail(NTG_E_BADARG, "shift out of range");
+	if (p->grid_batch) return fail(NTG_E_UNSUPPORTED, "the receding-horizon run works on the plan's shared grid");
 	HIPCHK(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream, own = nullptr;
 	if (!st) { HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking)); st = own; }   // the legacy default stream cannot be captured
@@ -905,6 +920,7 @@ extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x,
 	if (!p) return fail(NTG_E_BADARG, "null plan");
 	if (batch <= 0 || ntimes <= 0) return 0;
 	if (!d_x || !d_times || !d_z) return fail(NTG_E_BADARG, "null argument");
+	if (p->grid_batch) return fail(NTG_E_UNSUPPORTED, "ntg_batch_interp evaluates on the plan's shared knots: clear the per-problem grids first");
 	HIPCHK(hipSetDevice(p->device));
 	const NtgDims &D = p->D;
 	hipStream_t st = (hipStream_t)stream;
@@ -928,6 +944,205 @@ extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x,
 	if (d_base) (void)hipFreeAsync(d_base, st);
 	HIPCHK(e);
 	HIPCHK(es);
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-problem grids: the setup phase of ntg() (ntg.c:114-229: CollocMatrix per output, LinearConstraintsMatrix) run for every
+// problem of a batch on its own break sequence and breakpoints.  The basis blocks come from basis_kernel (one launch for the whole
+// batch); what the host derives from them per problem is small dense algebra over the equality rows ((A A')^-1 is nclin x nclin), done
+// here on a few host threads like the one-grid setup of ntg_plan_create.
+// ---------------------------------------------------------------------------------------------------------------------
+static void dense_AE_pp(const ntg_plan *p, const double *blk, std::vector<double> &AE)   // AE: [mE][nC] row-major
+{
+	const NtgDims &D = p->D;
+	const int n = D.nC, m = D.mE, P = D.P, nz = D.nz;
+	AE.assign((size_t)std::max(m, 1) * n, 0.0);
+	for (int e = 0; e < m; e++) {
+		const int r = p->h_erow[e];
+		const double *row; int bp;
+		if (r < D.nlic) { row = p->h_lic.data() + (size_t)r * nz; bp = 0; }
+		else if (r < D.nlic + D.nltc * P) { const int rr = r - D.nlic; row = p->h_ltc.data() + (size_t)(rr / P) * nz; bp = rr % P; }
+		else { row = p->h_lfc.data() + (size_t)(r - D.nlic - D.nltc * P) * nz; bp = P - 1; }
+		for (int o = 0; o < D.nout; o++) {
+			const int k = D.order[o], d = D.d[o], col0 = D.iC[o] + p->h_off[bp];   // one basis class: offsets of class 0
+			for (int q = 0; q < k; q++) {
+				double acc = 0.0;
+				for (int l = 0; l < d; l++) acc += row[D.iz[o] + l] * blk[((size_t)bp * k + q) * d + l];
+				AE[(size_t)e * n + col0 + q] = acc;
+			}
+		}
+	}
+}
+
+// preconditioner blocks of one grid (the distinct blocks of build_precond, same order): all[q][spad][nb]
+static int precond_blocks_pp(const ntg_plan *p, const double *blk, const double *bps, const std::vector<double> &AE, double *all)
+{
+	const NtgDims &D = p->D;
+	const int n = D.nC, m = D.mE, P = D.P, nb = p->T.n0b_n, spad = p->T.n0b_sp;
+	for (int q = 0; q < p->T.n0b_nblk; q++) {
+		int o0 = -1;
+		for (int o = 0; o < D.nout; o++) if (D.n0_blk[o] == q) { o0 = o; break; }
+		if (o0 < 0) return NTG_E_UNSUPPORTED;
+		const int k = D.order[o0], d = D.d[o0], c0 = D.iC[o0];
+		std::vector<double> H0((size_t)nb * nb, 0.0), Wb;
+		auto add = [&](const std::vector<ntg_av> &av, int bp, double w) {
+			for (const ntg_av &a : av) {
+				if (a.output != o0) continue;
+				const int base = p->h_off[bp], r = a.deriv;
+				const double *b = blk + (size_t)bp * k * d;
+				for (int q1 = 0; q1 < k; q1++) for (int q2 = 0; q2 < k; q2++) H0[(size_t)(base + q1) * nb + base + q2] += w * b[q1 * d + r] * b[q2 * d + r];
+			}
+		};
+		for (int i = 0; i < P; i++) {
+			double w = 0.0;
+			if (i > 0) w += (bps[i] - bps[i - 1]) / 2;
+			if (i < P - 1) w += (bps[i + 1] - bps[i]) / 2;
+			if (D.nucf) add(p->tcostav, i, w);
+		}
+		if (D.nicf) add(p->icostav, 0, 1.0);
+		if (D.nfcf) add(p->fcostav, P - 1, 1.0);
+		std::vector<int> rsel;
+		for (int r = 0; r < m; r++) { bool hit = false; for (int j = 0; j < nb && !hit; j++) if (p->h_AE[(size_t)r * n + c0 + j] != 0.0) hit = true; if (hit) rsel.push_back(r); }
+		const int mb = (int)rsel.size();
+		std::vector<double> Ab((size_t)std::max(mb, 1) * nb, 0.0);
+		for (int i = 0; i < mb; i++) for (int j = 0; j < nb; j++) Ab[(size_t)i * nb + j] = AE[(size_t)rsel[i] * n + c0 + j];
+		if (precond_block(H0, Ab, mb, nb, Wb)) return NTG_E_UNSUPPORTED;
+		std::copy(Wb.begin(), Wb.end(), all + (size_t)q * spad * nb);
+	}
+	return 0;
+}
+
+extern "C" void ntg_plan_clear_grids(ntg_plan *p)
+{
+	if (!p || !p->grid_batch) return;
+	hipSetDevice(p->device);
+	hipDeviceSynchronize();
+	for (void *q : p->grid_owned) hipFree(q);
+	p->grid_owned.clear();
+	p->T = p->T_shared;
+	p->grid_batch = 0;
+}
+
+extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0 || !d_knots || !d_bps) return fail(NTG_E_BADARG, "bad argument");
+	const NtgDims &D = p->D;
+	if (D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans have one grid");
+	if (D.nclass != 1) return fail(NTG_E_UNSUPPORTED, "per-problem grids need one basis class (every output on the same knots / order / multiplicity)");
+	if (D.nI > 0 || D.ncnln > 0) return fail(NTG_E_UNSUPPORTED, "per-problem grids: plans with linear equality rows only (no inequality or nonlinear rows) so far");
+	HIPCHK(hipSetDevice(p->device));
+	ntg_plan_clear_grids(p);
+	if (with_precond) {
+		std::lock_guard<std::mutex> lk(p->precond_mutex);
+		if (!p->precond_ready) { int rc = build_precond(p); if (rc) return rc; }
+		if (p->precond_singular || !p->T.n0b) return fail(NTG_E_UNSUPPORTED, "per-problem grids with the preconditioner need its block form (one dense block per output)");
+	}
+	hipStream_t st = (hipStream_t)stream;
+	const int P = D.P, k = D.cls_k[0], d = D.cls_d[0], l = D.cls_l[0], n = D.nC, m = D.mE;
+	const size_t nblk = (size_t)P * k * d;
+	// 1. basis blocks and offsets of every problem: one launch of basis_kernel (bsplvd at every collocation point, colloc.c:95-111)
+	double *d_blk = nullptr; int *d_off = nullptr;
+	HIPCHK(hipMalloc((void **)&d_blk, (size_t)batch * nblk * 8));
+	if (hipMalloc((void **)&d_off, (size_t)batch * P * 4) != hipSuccess) { hipFree(d_blk); return fail(NTG_E_HIP, "hipMalloc"); }
+	hipError_t e = ntg_launch_basis(batch, l, k, D.cls_m[0], d, P, d_knots, d_bps, l + 1, P, d_blk, d_off, st);
+	std::vector<double> hblk((size_t)batch * nblk), hbps((size_t)batch * P); std::vector<int> hoff((size_t)batch * P);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e == hipSuccess) e = hipMemcpy(hblk.data(), d_blk, hblk.size() * 8, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(hoff.data(), d_off, hoff.size() * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(hbps.data(), d_bps, hbps.size() * 8, hipMemcpyDeviceToHost);
+	hipFree(d_blk); hipFree(d_off);
+	if (e != hipSuccess) return fail(NTG_E_HIP, hipGetErrorString(e));
+	// 2. same combinatorial structure as the plan's grid: every breakpoint in the same knot interval
+	for (int b = 0; b < batch; b++) for (int i = 0; i < P; i++)
+		if (hoff[(size_t)b * P + i] != p->h_off[i]) return fail(NTG_E_BADARG, "per-problem grid: a breakpoint lies in another knot interval than in the plan's grid (problem " + std::to_string(b) + ", breakpoint " + std::to_string(i) + ")");
+	// 3. per-problem values behind the shared index tables
+	const int row_total = D.row_total, lin_nnz = std::max(D.lin_nnz, 1), sinv_nnz = std::max(D.sinv_nnz, 1), qn = D.q_use ? D.q_nt * D.q_w : 0;
+	const size_t n0b_sz = with_precond ? (size_t)p->T.n0b_nblk * p->T.n0b_sp * p->T.n0b_n + 16 : 0;
+	std::vector<double> rowv((size_t)batch * row_total, 0.0), csrv((size_t)batch * lin_nnz, 0.0), cscv((size_t)batch * lin_nnz, 0.0),
+		sinvv((size_t)batch * sinv_nnz, 0.0), qv((size_t)batch * std::max(qn, 1), 0.0), n0bv((size_t)batch * n0b_sz, 0.0);
+	std::atomic<int> next(0), err(0);
+	auto worker = [&]() {
+		std::vector<double> AE, S, Sinv, col(std::max(m, 1));
+		for (;;) {
+			const int b = next.fetch_add(1);
+			if (b >= batch || err.load()) break;
+			const double *blk = hblk.data() + (size_t)b * nblk;
+			// channel rows: rowv[chrow[r] + q P + i] = D^r B_{off+q}(bps[i]); one trailing zero per channel (see ntg_plan_create)
+			double *rv = rowv.data() + (size_t)b * row_total;
+			for (int r = 0; r < d; r++) {
+				const int ch = p->h_chrow[r];
+				if (ch < 0) continue;
+				for (int q = 0; q < k; q++) for (int i = 0; i < P; i++) rv[ch + q * P + i] = blk[((size_t)i * k + q) * d + r];
+			}
+			if (m > 0) {
+				dense_AE_pp(p, blk, AE);
+				// values of A_E in the plan's CSR / CSC patterns; an entry outside the pattern must vanish
+				double *cr = csrv.data() + (size_t)b * lin_nnz, *cc = cscv.data() + (size_t)b * lin_nnz;
+				std::vector<char> seen((size_t)m * n, 0);
+				for (int i = 0; i < m; i++) for (int eidx = p->h_csr_ptr[i]; eidx < p->h_csr_ptr[i + 1]; eidx++) { cr[eidx] = AE[(size_t)i * n + p->h_csr_col[eidx]]; seen[(size_t)i * n + p->h_csr_col[eidx]] = 1; }
+				for (int c = 0; c < n; c++) for (int eidx = p->h_csc_ptr[c]; eidx < p->h_csc_ptr[c + 1]; eidx++) cc[eidx] = AE[(size_t)p->h_csc_row[eidx] * n + c];
+				for (size_t t = 0; t < (size_t)m * n; t++) if (!seen[t] && std::fabs(AE[t]) > 1e-300) { err.store(1); break; }
+				// (A A')^-1
+				S.assign((size_t)m * m, 0.0);
+				for (int i = 0; i < m; i++) for (int j = 0; j <= i; j++) { double a = 0.0; for (int c = 0; c < n; c++) a += AE[(size_t)i * n + c] * AE[(size_t)j * n + c]; S[(size_t)i * m + j] = a; S[(size_t)j * m + i] = a; }
+				if (!chol_lower(S, m)) { err.store(2); break; }
+				Sinv.assign((size_t)m * m, 0.0);
+				for (int j = 0; j < m; j++) { std::fill(col.begin(), col.end(), 0.0); col[j] = 1.0; chol_solve(S, m, col.data()); for (int i = 0; i < m; i++) Sinv[(size_t)i * m + j] = col[i]; }
+				for (int i = 0; i < m; i++) for (int j = 0; j < i; j++) { const double a = 0.5 * (Sinv[(size_t)i * m + j] + Sinv[(size_t)j * m + i]); Sinv[(size_t)i * m + j] = a; Sinv[(size_t)j * m + i] = a; }
+				double *sv = sinvv.data() + (size_t)b * sinv_nnz;
+				for (int i = 0; i < m; i++) for (int eidx = p->h_sinv_ptr[i]; eidx < p->h_sinv_ptr[i + 1]; eidx++) sv[eidx] = Sinv[(size_t)i * m + p->h_sinv_col[eidx]];
+				// projector Q = A'(AA')^-1 A on the plan's ELL pattern
+				if (D.q_use) {
+					double *qq = qv.data() + (size_t)b * qn;
+					for (int a = 0; a < n; a++) {
+						const int t = p->h_qidx[a];
+						if (t < 0) continue;
+						for (int w2 = 0; w2 < D.q_w; w2++) {
+							const int c = p->h_qcol[(size_t)t * D.q_w + w2];
+							double acc = 0.0;
+							for (int i = 0; i < m; i++) { const double aia = AE[(size_t)i * n + a]; if (aia == 0.0) continue; for (int j = 0; j < m; j++) acc += aia * Sinv[(size_t)i * m + j] * AE[(size_t)j * n + c]; }
+							qq[(size_t)t * D.q_w + w2] = acc;   // padded entries repeat column 0 with value... the pattern's padding has value 0 in the plan
+						}
+					}
+				}
+				if (with_precond && precond_blocks_pp(p, blk, hbps.data() + (size_t)b * P, AE, n0bv.data() + (size_t)b * n0b_sz)) { err.store(3); break; }
+			}
+		}
+	};
+	{
+		const unsigned nthr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+		std::vector<std::thread> pool;
+		for (unsigned t = 0; t + 1 < nthr; t++) pool.emplace_back(worker);
+		worker();
+		for (auto &th : pool) th.join();
+	}
+	if (err.load() == 1) return fail(NTG_E_UNSUPPORTED, "per-problem grid: a linear-constraint entry outside the plan's sparsity pattern");
+	if (err.load() == 2) return fail(NTG_E_BADARG, "per-problem grid: linear constraint rows are rank deficient");
+	if (err.load() == 3) return fail(NTG_E_UNSUPPORTED, "per-problem grid: preconditioner block not positive definite");
+	// the ELL padding of Q (column 0, value 0 in the plan) must stay zero: entries whose plan value is exactly 0 and that repeat an earlier column
+	if (D.q_use) {
+		std::vector<double> q0((size_t)qn);
+		if (hipMemcpy(q0.data(), p->T.q_val, (size_t)qn * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(NTG_E_HIP, "reading the projector back failed");
+		for (int t = 0; t < D.q_nt; t++) for (int w2 = 1; w2 < D.q_w; w2++)
+			if (q0[(size_t)t * D.q_w + w2] == 0.0 && p->h_qcol[(size_t)t * D.q_w + w2] == 0)
+				for (int b = 0; b < batch; b++) qv[(size_t)b * qn + (size_t)t * D.q_w + w2] = 0.0;
+	}
+	// 4. upload; the kernels add b * stride to the value pointers (NtgTables::pp_*)
+	p->T_shared = p->T;
+	double *d_rowv = nullptr, *d_bpsc = nullptr, *d_csr = nullptr, *d_csc = nullptr, *d_sinv = nullptr, *d_q = nullptr, *d_n0b = nullptr;
+	if (dev_upload(&d_rowv, rowv.data(), rowv.size(), p->grid_owned) || dev_upload(&d_bpsc, hbps.data(), hbps.size(), p->grid_owned) ||
+	    dev_upload(&d_csr, csrv.data(), csrv.size(), p->grid_owned) || dev_upload(&d_csc, cscv.data(), cscv.size(), p->grid_owned) ||
+	    dev_upload(&d_sinv, sinvv.data(), sinvv.size(), p->grid_owned) || dev_upload(&d_q, qv.data(), qv.size(), p->grid_owned) ||
+	    dev_upload(&d_n0b, n0bv.data(), n0bv.size(), p->grid_owned)) { ntg_plan_clear_grids(p); for (void *q : p->grid_owned) hipFree(q); p->grid_owned.clear(); return NTG_E_HIP; }
+	NtgTables &T = p->T;
+	T.rowv = d_rowv; T.pp_rowv = row_total;
+	T.bps = d_bpsc; T.pp_bps = P;
+	if (m > 0) { T.csr_val = d_csr; T.csc_val = d_csc; T.pp_lin = lin_nnz; T.sinv_val = d_sinv; T.pp_sinv = sinv_nnz; }
+	if (D.q_use) { T.q_val = d_q; T.pp_q = qn; }
+	if (with_precond) { T.n0b = d_n0b; T.pp_n0b = (long long)n0b_sz; T.n0 = nullptr; T.n0c = nullptr; }
+	p->grid_batch = batch;
 	return 0;
 }
 

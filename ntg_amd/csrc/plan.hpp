@@ -18,6 +18,14 @@ struct ntg_plan {
 	std::vector<double> h_bps, h_blk, h_aband, h_Adense, h_AE;   // h_Adense: all linear rows; h_AE: the equality rows
 	std::vector<int> h_off, h_rbp, class_rep;
 	std::vector<ntg_av> icostav, tcostav, fcostav;
+	// host copies of the shared index tables (per-problem grids recompute the values behind them)
+	std::vector<int> h_chrow, h_csr_ptr, h_csr_col, h_csc_ptr, h_csc_row, h_sinv_ptr, h_sinv_col, h_erow, h_qcol;
+	std::vector<short> h_qidx;
+	std::vector<double> h_lic, h_ltc, h_lfc;    // the user's linear rows [n][nz]
+	// per-problem grids (ntg_plan_set_grids): number of problems they were set for (0: shared grid), their device arrays
+	int grid_batch = 0;
+	std::vector<void *> grid_owned;
+	NtgTables T_shared;                         // the tables of the shared grid, restored by ntg_plan_clear_grids
 	double *d_lic = nullptr;                    // [nlic][nz] kept for the receding-horizon shift
 	std::vector<double *> d_knots;              // break sequence of every basis class (ntg_batch_interp)
 };

@@ -175,7 +175,7 @@ struct Smem {
 	const int *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col; const double *csr_val, *csc_val, *sinv_val;
 	int *oinfo, *tavrow, *tcomp;   // per-output scalars, flag->row map, flag->compact trajectory-constraint index, in LDS
 	short *q_idx; int *q_col; double *q_val;
-	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T)
+	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T, int b = 0)
 	{
 		rowv = (double *)(base + L.rowv); colp = (unsigned int *)(base + L.colp);
 		chrow = (int *)(base + L.chrow); chcol = (int *)(base + L.chcol);
@@ -190,19 +190,23 @@ struct Smem {
 			csc_ptr = (const int *)(base + L.csc_ptr); csc_row = (const int *)(base + L.csc_row); csc_val = (const double *)(base + L.csc_val);
 			sinv_ptr = (const int *)(base + L.sinv_ptr); sinv_col = (const int *)(base + L.sinv_col); sinv_val = (const double *)(base + L.sinv_val);
 		} else {
-			csr_ptr = T.csr_ptr; csr_col = T.csr_col; csr_val = T.csr_val;
-			csc_ptr = T.csc_ptr; csc_row = T.csc_row; csc_val = T.csc_val;
-			sinv_ptr = T.sinv_ptr; sinv_col = T.sinv_col; sinv_val = T.sinv_val;
+			csr_ptr = T.csr_ptr; csr_col = T.csr_col; csr_val = T.csr_val + (size_t)b * T.pp_lin;
+			csc_ptr = T.csc_ptr; csc_row = T.csc_row; csc_val = T.csc_val + (size_t)b * T.pp_lin;
+			sinv_ptr = T.sinv_ptr; sinv_col = T.sinv_col; sinv_val = T.sinv_val + (size_t)b * T.pp_sinv;
 		}
 		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow); tcomp = (int *)(base + L.tcomp);
 		q_idx = (short *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
 	}
 };
 
+// b: the problem whose grid is staged (matters only with per-problem grids, NtgTables::pp_*)
 template <int NT>
-__device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &T, const Smem &S, char *base, const SmemLayout &L)
+__device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &T0, const Smem &S, char *base, const SmemLayout &L, int b = 0)
 {
 	const int tid = threadIdx.x;
+	NtgTables T = T0;
+	T.rowv += (size_t)b * T0.pp_rowv; T.bps += (size_t)b * T0.pp_bps;
+	T.csr_val += (size_t)b * T0.pp_lin; T.csc_val += (size_t)b * T0.pp_lin; T.sinv_val += (size_t)b * T0.pp_sinv; T.q_val += (size_t)b * T0.pp_q;
 	for (int i = tid; i < D.row_total; i += NT) S.rowv[i] = T.rowv[i];
 	for (int i = tid; i < D.col_total; i += NT) S.colp[i] = T.colp[i];
 	for (int i = tid; i < D.nclass * NTG_MAX_ORDER; i += NT) { S.chrow[i] = T.chrow[i]; S.chcol[i] = T.chcol[i]; }
@@ -865,7 +869,8 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	Smem S(smem_raw, L, D, T);
-	stage_tables<NT>(D, T, S, smem_raw, L);
+	const bool pp = T.pp_rowv != 0;   // per-problem grids: the value tables are staged again for every problem
+	if (!pp) stage_tables<NT>(D, T, S, smem_raw, L);
 	double *sg = S.x;   // the gradient is assembled (owner lanes, after the last read of x) into the x buffer
 	lds_sync();
 	CoefMap<EPT> cm;
@@ -881,6 +886,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 	}
 	for (int b = blockIdx.x; b < batch; b += gridDim.x) {
 		lds_sync();
+		if (pp) { stage_tables<NT>(D, T, S, smem_raw, L, b); lds_sync(); }
 		if (xreg) {
 #pragma unroll
 			for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; if (i < D.nC) S.x[i] = xn[e]; }
@@ -1179,9 +1185,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            double *__restrict__ al_all, double *__restrict__ vec_all, double *__restrict__ nwt_all)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-	Smem S(smem_raw, L, D, T);
 	const int b = blockIdx.x, tid = threadIdx.x, n = D.nC, m = D.mE /* rows kept by projection */, P = D.P;
 	if (b >= batch) return;
+	Smem S(smem_raw, L, D, T, b);
 	const int npad = (n + 1) & ~1;
 	double *gv = BIG ? vec_all + (size_t)b * 5 * npad : nullptr;
 	double *sx = BIG ? gv : S.x, *sxt = S.vecs, *sgp = BIG ? gv + npad : S.vecs + npad,
@@ -1189,7 +1195,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	       *st = sxt /* t = W gp+ lives in the trial-point buffer once x is committed */,
 	       *sg = BIG ? gv + 4 * npad : S.vecs + 4 * npad, *tmp = S.vecs + (BIG ? 1 : 5) * npad;
 	double *hist = hist_all + (size_t)b * sp.memcap * (2 * n + 2);   // pair i: [s (n) | u (n) | rho | c2]
-	stage_tables<NT>(D, T, S, smem_raw, L);
+	stage_tables<NT>(D, T, S, smem_raw, L, b);
+	NtgTables Tw = T;   // the preconditioner blocks of this problem (per-problem grids) or the shared ones (stride 0)
+	if (HESS && T.n0b) Tw.n0b = T.n0b + (size_t)b * T.pp_n0b;
 	for (int i = tid; i < n; i += NT) sx[i] = xio[(size_t)b * n + i];
 	lds_sync();
 	CoefMap<EPT> cm;
@@ -1395,7 +1403,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 				for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
 				if (NWT) { nwt_refresh(sxt, true); nwt_apply(sgp, sd); }
-				else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+				else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo);
 				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
 				for_vec<NT>(n, [&](int c) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; });
 				block_sum<NT, 4>(r4, S.red);
@@ -1425,7 +1433,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						// (structured Newton mode: with the Gauss-Newton factor at x; sxt is rebuilt from x first)
 						npairs = 0;
 						if (NWT) { lds_sync(); for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; }); nwt_refresh(sxt, false); nwt_apply(sgp, sd); }
-						else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+						else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo);
 						double r2[2] = {0, 0};
 						for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 						block_sum<NT, 2>(r2, S.red);
@@ -1444,10 +1452,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					alpha = ls_a;
 					// accept: commit x (frees sxt, which then holds t), t = W gp+, u = t - d, pair (s, u) to HBM
 					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
-					if (!NWT && npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
+					if (!NWT && npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
 					NTG_STAMP(5);
 					if (NWT) { nwt_refresh(sxt, true); nwt_apply(sgpt, st); }   // sxt still holds the accepted point; st (= sxt) is written last
-					else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgpt, st, sxt, S.oinfo);
+					else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgpt, st, sxt, S.oinfo);
 					NTG_STAMP(4);
 					// register-resident pairs: 3 coefficients per lane, 6 pairs per round; the 5-coefficient instances (config E)
 					// take 3 pairs per round
@@ -1508,7 +1516,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						if (pnorm != 0.0) { // W lost definiteness numerically: restart from W0 once
 							npairs = 0;
 							if (NWT) { lds_sync(); for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; }); nwt_refresh(sxt, false); nwt_apply(sgp, sd); }
-							else apply_w0<NT, BIG, HESS>(D, T, sp.hessian, sgp, sd, sxt, S.oinfo);
+							else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo);
 							double r2[2] = {0, 0};
 							for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
 							block_sum<NT, 2>(r2, S.red);

@@ -1,0 +1,122 @@
+"""-m gpu: per-problem grids (ntg_plan_set_grids): every problem of a batch on its own break sequence and breakpoints
+-- the setup phase of ntg() (ntg.c:114-229) per problem -- against the oracle built once per problem on that grid.
+
+Tolerances: evaluation 1e-12 relative (same arithmetic, other summation order); optimum as tests/test_gpu_solve.py
+(|dF| <= 1e-9 max(1,|F|), |dx| <= 1e-6 max(1,|x|inf), linear feasibility 1e-8 relative to the row's largest entry:
+short horizons scale the derivative rows by 1/h^r)."""
+import dataclasses
+import numpy as np
+import pytest
+import torch
+
+import orc
+from ntg_amd import api, configs as cf
+from gpu_common import dev, rel
+
+pytestmark = pytest.mark.gpu
+
+
+def grids_for(spec, nb, seed=5, warp=0.0):
+    """nb horizons in [0.6, 1.6] x the plan's, optionally with non-uniform breaks (a smooth monotone warp of the knots);
+    breakpoints stay inside the plan's knot intervals: interpolated between the problem's own knots"""
+    rng = np.random.default_rng(seed)
+    l, P = spec.kninterv[0], spec.nbps
+    k0 = np.asarray(spec.knots[0]); T0 = k0[-1] - k0[0]
+    # position of every plan breakpoint inside its knot interval (interval index, fraction)
+    j = np.minimum(np.searchsorted(k0, spec.bps, side="right") - 1, l - 1)
+    fr = (spec.bps - k0[j]) / (k0[j + 1] - k0[j])
+    knots = np.zeros((nb, l + 1)); bps = np.zeros((nb, P))
+    for b in range(nb):
+        s = (k0 - k0[0]) / T0
+        a = warp * rng.uniform(-1, 1)
+        kn = k0[0] + T0 * rng.uniform(0.6, 1.6) * (s + a * s * (1 - s))
+        knots[b] = kn
+        bp = kn[j] + fr * (kn[j + 1] - kn[j])
+        # keep every breakpoint in the plan's interval in floating point too (linspace puts some an ulp beside a knot)
+        bp = np.maximum(bp, kn[j]); inner = j < l - 1
+        bp[inner] = np.minimum(bp[inner], np.nextafter(kn[j + 1][inner], -np.inf))
+        if spec.bps[-1] >= k0[-1]: bp[-1] = max(bp[-1], kn[-1])
+        bps[b] = bp
+    return knots, bps
+
+
+def spec_on(spec, knots, bps):
+    return dataclasses.replace(spec, bps=bps.copy(), knots=[knots.copy() for _ in range(spec.nout)])
+
+
+@pytest.mark.parametrize("name,warp", [("B", 0.0), ("M", 0.3), ("K0", 0.3)])
+def test_eval_on_per_problem_grids(name, warp):
+    spec = {"B": cf.config_B, "M": cf.config_M, "K0": cf.config_K0}[name]()
+    nb = 16
+    knots, bps = grids_for(spec, nb, warp=warp)
+    p = api.Plan(spec, 0)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((nb, spec.nC))
+    shared = p.eval(dev(x))
+    f_shared = shared["f"].cpu().numpy().copy()
+    p.set_grids(dev(knots), dev(bps), with_precond=False)
+    out = p.eval(dev(x))
+    torch.cuda.synchronize()
+    f = out["f"].cpu().numpy(); g = out["g"].cpu().numpy()
+    for b in range(nb):
+        ref = orc.eval_batch(spec_on(spec, knots[b], bps[b]), x[b:b + 1])
+        assert abs(f[b] - ref["f"][0]) <= 1e-12 * max(1.0, abs(ref["f"][0]))
+        assert rel(g[b], ref["g"][0]) <= 1e-12
+    assert np.abs(f - f_shared).max() > 1e-3          # the grids do differ
+    with pytest.raises(api.NtgError):                  # the grids are for exactly this batch
+        p.eval(dev(x[:3]))
+    p.clear_grids()
+    again = p.eval(dev(x))
+    np.testing.assert_array_equal(again["f"].cpu().numpy(), f_shared)
+
+
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3)])
+@pytest.mark.parametrize("hessian", [0, 1])
+def test_solve_on_per_problem_horizons(name, ncars, hessian):
+    """free-final-time style batch: the same boundary conditions reached over 16 different horizons"""
+    spec = {"B": cf.config_B, "M": cf.config_M}[name]()
+    nb = 16
+    knots, bps = grids_for(spec, nb, warp=0.2)
+    lo, up = cf.kincar_random_bounds(ncars, nb)
+    p = api.Plan(spec, 0)
+    p.set_grids(dev(knots), dev(bps), with_precond=bool(hessian))
+    x = dev(np.ones((nb, spec.nC)))
+    out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=hessian))
+    torch.cuda.synchronize()
+    xs = x.cpu().numpy(); obj = out["objective"].cpu().numpy(); inform = out["inform"].cpu().numpy(); iters = out["iters"].cpu().numpy()
+    assert (inform == 0).all()
+    objs = []
+    for b in range(nb):
+        sb = spec_on(spec, knots[b], bps[b])
+        ref = orc.solve_one(sb, lo[b], up[b], np.ones(spec.nC), orc.default_opts(hessian=hessian))
+        assert ref["inform"] == 0
+        assert abs(obj[b] - ref["objective"]) <= 1e-9 * max(1.0, abs(ref["objective"]))
+        assert np.abs(xs[b] - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
+        A = orc.export_tables(sb)["A"]
+        assert (np.abs(A @ xs[b] - lo[b]) <= 1e-8 * np.maximum(1.0, np.abs(A).max(axis=1))).all()
+        objs.append(ref["objective"])
+        if hessian == 1:
+            assert abs(int(iters[b]) - ref["iters"]) <= 1
+    if hessian == 1:
+        assert iters.max() <= 5          # the per-problem preconditioner is the exact reduced Hessian of each grid
+    assert np.ptp(objs) > 1e-3
+
+
+def test_grid_structure_mismatch_is_refused():
+    spec = cf.config_B()
+    nb = 4
+    knots, bps = grids_for(spec, nb)
+    p = api.Plan(spec, 0)
+    bad = bps.copy()
+    bad[2, 7] = knots[2, 2] + 1e-3           # breakpoint 7 belongs to knot interval 1, moved into interval 2
+    bad[2] = np.sort(bad[2])
+    with pytest.raises(api.NtgError, match="knot interval"):
+        p.set_grids(dev(knots), dev(bad), with_precond=False)
+    with pytest.raises(api.NtgError):
+        p.set_grids(dev(knots[:, :-1]), dev(bps))
+    # a plan with nonlinear rows keeps one grid
+    q = api.Plan(cf.config_D(ninterv=8), 0)
+    sq = q.spec
+    kq, bq = grids_for(sq, 2)
+    with pytest.raises(api.NtgError, match="linear equality"):
+        q.set_grids(dev(kq), dev(bq))
