@@ -369,7 +369,7 @@ def main():
         bpg[:, -1] = kn[:, -1]
         pg = api.Plan(spec, local)
         tg = time.perf_counter()
-        pg.set_grids(torch.tensor(kn, device=dev), torch.tensor(bpg, device=dev), with_precond=False)
+        pg.set_grids(torch.tensor(np.ascontiguousarray(kn), device=dev), torch.tensor(np.ascontiguousarray(bpg), device=dev), with_precond=False)
         setup_s = time.perf_counter() - tg
         xg = torch.randn((nbg, spec.nC), dtype=torch.float64, device=dev)
         og = pg.eval(xg, 2); pg.eval(xg, 2, out=og); torch.cuda.synchronize()

@@ -10,7 +10,7 @@ import numpy as np
 from .spec import Spec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntg_amd.so")
+LIB_PATH = os.environ.get("NTG_AMD_LIB") or os.path.join(_HERE, "libntg_amd.so")   # NTG_AMD_LIB: a tuning build of the same library (tests/tools_variants.py)
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 

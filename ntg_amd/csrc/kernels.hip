@@ -348,7 +348,7 @@ hipError_t ntg_launch_mpc_shift(const NtgDims &D, const NtgTables &T, int batch,
 // ------------------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
 
-SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
+SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x, int hrc_pairs)
 {
 	SmemLayout L;
 	int p = 0;
@@ -374,7 +374,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x)
 	L.dff = p; p = align16(p + (D.nz + 1) * 8);
 	L.vecs = p; p = align16(p + (nvec * npad + 2 * D.nclin + 2) * 8);
 	L.lam = p; p = align16(p + (D.nclin + 1) * 8);
-	L.rho = L.c2 = p;   // rho_i, c2_i travel with the pair in HBM
+	L.rho = L.c2 = p; L.hrc_n = hrc_pairs; p = align16(p + 2 * hrc_pairs * 8);   // (rho_i, c2_i) of a short quasi-Newton memory; longer ones keep them with the pair in HBM
 	L.oinfo = p; p = align16(p + D.nout * 10 * 4);
 	L.tavrow = p; p = align16(p + D.nz * 4);
 	L.tcomp = p; p = align16(p + D.nz * 4);

@@ -107,9 +107,12 @@ __host__ __device__ constexpr int colp_words(int W) { return (W / 2 + 1 + 3) & ~
 __host__ __device__ inline int ntg_dfz_tail(const NtgDims &D) { int w = 16; for (int c = 0; c < D.nclass; c++) w = D.cls_W[c] > w ? D.cls_W[c] : w; return w; }
 
 // byte offsets into dynamic LDS, computed on the host (kernels.hip: make_layout)
+#define NTG_HRC_LDS 64   // quasi-Newton memories up to this many pairs keep the pair scalars (rho, c2) in LDS, when that costs no residency
+
 struct SmemLayout {
 	int rowv, colp, chrow, chcol, off, bps, wts, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
 	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, tcomp, q_idx, q_col, q_val, ls, tI, total;
+	int hrc_n;   // pairs whose scalars (rho, c2) live in LDS at L.rho (0: they travel with the pair in HBM)
 	int nwt_y;   // structured Newton mode: byte offset (inside the dfz area, which is idle between evaluations) of the solve vectors; panels follow
 };
 

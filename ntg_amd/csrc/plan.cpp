@@ -765,13 +765,18 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 }
 
 // does the solve keep all its vectors in LDS, or only the two that are read across lanes (sqp_kernel, BIG)?
-static int solve_layout(const NtgDims &D, int nt, SmemLayout *L, int *big)
+static int solve_layout(const NtgDims &D, int nt, SmemLayout *L, int *big, const SolveParams *sp = nullptr)
 {
+	// a short quasi-Newton memory keeps its pair scalars in LDS -- unless those bytes would cost a resident workgroup
+	const int hrc = (sp && sp->hessian != 2 && sp->memcap < NTG_HRC_LDS) ? sp->memcap + 1 : 0;   // + 1: the one-vector-per-major form wants a slot more than pairs
+	auto resident = [](int total) { return (160 * 1024) / std::max(total, 1); };
 	*big = 0;
-	*L = ntg_make_layout(D, nt, 5, 1);
+	*L = ntg_make_layout(D, nt, 5, 1, hrc);
+	if (hrc && resident(L->total) < resident(L->total - 16 * hrc)) *L = ntg_make_layout(D, nt, 5, 1, 0);
 	if (L->total <= 160 * 1024) return 0;
 	*big = 1;
-	*L = ntg_make_layout(D, nt, 1, 0);
+	*L = ntg_make_layout(D, nt, 1, 0, hrc);
+	if (hrc && L->total > 160 * 1024) *L = ntg_make_layout(D, nt, 1, 0, 0);
 	return L->total <= 160 * 1024 ? 0 : -1;
 }
 static size_t hist_doubles(const NtgDims &D, int batch, const SolveParams &sp)
@@ -793,7 +798,7 @@ extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, con
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
 	SmemLayout L; int big;
-	solve_layout(p->D, nt, &L, &big);
+	solve_layout(p->D, nt, &L, &big, &sp);
 	const size_t npad = (size_t)((p->D.nC + 1) & ~1);
 	return (long long)((hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0) + nwt_doubles(p->D, batch, sp)) * 8 + 256);
 }
@@ -861,7 +866,7 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	}
 	if (sp.hessian == 1 && p->precond_singular) sp.hessian = 0;
 	SmemLayout L; int big;
-	if (solve_layout(p->D, nt, &L, &big)) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
+	if (solve_layout(p->D, nt, &L, &big, &sp)) return fail(NTG_E_UNSUPPORTED, "problem state exceeds 160 KiB of LDS");
 	double *alw = (double *)d_work + hist_doubles(p->D, batch, sp);   // [batch][2][ncnln] multipliers, estimates
 	double *vecw = alw + al_doubles(p->D, batch);                     // [batch][5][npad] x, gp, gp+, d, g (BIG only)
 	double *nwtw = vecw + (big ? (size_t)batch * 5 * ((p->D.nC + 1) & ~1) : 0);   // structured Newton mode: bands and blocks
@@ -1179,7 +1184,7 @@ extern "C" int ntg_debug_layout(const ntg_plan *p, const ntg_solve_opts *o, int 
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
 	SmemLayout L; int big;
-	solve_layout(p->D, nt, &L, &big);
+	solve_layout(p->D, nt, &L, &big, &sp);
 	if (lds_solve) *lds_solve = big ? -L.total : L.total;   // negative: only the cross-lane vectors are in LDS
 	if (lds_eval) *lds_eval = ntg_make_layout(p->D, auto_threads(p->D), 0, 1).total;
 	if (nt_solve) *nt_solve = nt;

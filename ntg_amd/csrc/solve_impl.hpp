@@ -20,6 +20,18 @@
 #ifndef NTG_HIST_G
 #define NTG_HIST_G 6
 #endif
+#ifndef NTG_HIST_PIPE
+#define NTG_HIST_PIPE 2   // pairs per round of the double-buffered sweep (pair scalars in LDS, 3 coefficients per lane); 0 = off
+#endif
+#ifndef NTG_DFORM
+#define NTG_DFORM 1
+#endif
+#ifndef NTG_DF_G
+#define NTG_DF_G 4
+#endif
+#ifndef NTG_HIST_ZIGZAG
+#define NTG_HIST_ZIGZAG 0
+#endif
 
 // ------------------------------------------------------------------------------------------
 // reductions: sum K values over the workgroup, result broadcast to every lane
@@ -1088,9 +1100,69 @@ __device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, i
 // that still hold the pair elements.
 template <int NT, int EPT = 3, int G = NTG_HIST_G>
 __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, const double *hist, int npairs,
-                              const double *v, double *t)
+                              const double *v, double *t, const double *hrc = nullptr)
 {
 	const int n = D.nC, tid = threadIdx.x;
+#if NTG_HIST_PIPE > 0
+	if (EPT <= 3 && n <= EPT * NT && hrc) {
+		constexpr int PG = NTG_HIST_PIPE;
+		// Two register buffers of PG pairs: the loads of round r+1 are in flight while round r is reduced.  Every load is
+		// unconditional (pair index clamped to the newest pair, column clamped to n-1) so that the waits are counted
+		// (vmcnt(loads of the younger round)) instead of vmcnt(0); rounds past the end get rho = c2 = 0.  The pair scalars
+		// come from LDS: nothing but the pair elements in the register buffers.
+		if (npairs == 0) { lds_sync(); return; }
+		double vv[EPT], tt[EPT];
+		int cc[EPT];
+#pragma unroll
+		for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; cc[e] = min(c, n - 1); vv[e] = c < n ? v[c] : 0.0; tt[e] = c < n ? t[c] : 0.0; }
+		{
+			// odd memories are swept newest-first, even ones oldest-first: the pairs a sweep ends on are the ones the next
+			// sweep (one pair longer) starts on, while they are still in L2 / the memory-side cache
+			const bool rev = NTG_HIST_ZIGZAG && (npairs & 1);
+			auto pidx = [&](int i) { const int j = min(i, npairs - 1); return rev ? npairs - 1 - j : j; };
+			double hsA[PG][EPT], huA[PG][EPT], hsB[PG][EPT], huB[PG][EPT];
+			auto load = [&](int base, double (&hs)[PG][EPT], double (&hu)[PG][EPT]) {
+#pragma unroll
+				for (int g = 0; g < PG; g++) {
+					const double *h = hist + (size_t)pidx(base + g) * (2 * n + 2);
+#pragma unroll
+					for (int e = 0; e < EPT; e++) { hs[g][e] = h[cc[e]]; hu[g][e] = h[n + cc[e]]; }
+				}
+			};
+			auto consume = [&](int base, double (&hs)[PG][EPT], double (&hu)[PG][EPT]) {
+				double acc[2 * PG];
+#pragma unroll
+				for (int g = 0; g < PG; g++) {
+					acc[2 * g] = 0.0; acc[2 * g + 1] = 0.0;
+#pragma unroll
+					for (int e = 0; e < EPT; e++) { acc[2 * g] += hs[g][e] * vv[e]; acc[2 * g + 1] += hu[g][e] * vv[e]; }
+				}
+				block_sum<NT, 2 * PG>(acc, S.red);
+#pragma unroll
+				for (int g = 0; g < PG; g++) {
+					const bool on = base + g < npairs;
+					const int pi = pidx(base + g);
+					const double live = on ? 1.0 : 0.0, rho = hrc[2 * pi] * live, c2 = hrc[2 * pi + 1] * live;   // unconditional LDS reads
+#pragma unroll
+					for (int e = 0; e < EPT; e++)
+						tt[e] += -rho * (hs[g][e] * acc[2 * g + 1] + hu[g][e] * acc[2 * g]) + c2 * hs[g][e] * acc[2 * g];
+				}
+			};
+			load(0, hsA, huA);
+			for (int base = 0; base < npairs; base += 2 * PG) {
+				load(base + PG, hsB, huB);
+				consume(base, hsA, huA);
+				if (base + PG >= npairs) break;
+				load(base + 2 * PG, hsA, huA);
+				consume(base + PG, hsB, huB);
+			}
+#pragma unroll
+			for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; if (c < n) t[c] = tt[e]; }
+			lds_sync();
+			return;
+		}
+	}
+#endif
 	if (n <= EPT * NT) {
 		double vv[EPT], tt[EPT];
 #pragma unroll
@@ -1118,7 +1190,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				if (g < cnt) {
-					const double *hh = hist + (size_t)(base + g) * (2 * n + 2) + 2 * n;
+					const double *hh = hrc ? hrc + 2 * (base + g) : hist + (size_t)(base + g) * (2 * n + 2) + 2 * n;
 					const double rho = hh[0], c2 = hh[1];
 #pragma unroll
 					for (int e = 0; e < EPT; e++)
@@ -1152,13 +1224,75 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 			for (int g = 0; g < 4; g++) {
 				if (g < cnt) {
 					const double *h = hist + (size_t)(base + g) * (2 * n + 2);
-					const double s = h[c], u = h[n + c], rho = h[2 * n], c2 = h[2 * n + 1];
+					const double s = h[c], u = h[n + c], rho = hrc ? hrc[2 * (base + g)] : h[2 * n], c2 = hrc ? hrc[2 * (base + g) + 1] : h[2 * n + 1];
 					tt += -rho * (s * acc[2 * g + 1] + u * acc[2 * g]) + c2 * s * acc[2 * g];
 				}
 			}
 			t[c] = tt;
 		}
 	}
+	lds_sync();
+}
+
+// The same quasi-Newton operator from ONE stored vector per major iteration (half the history traffic of apply_history).
+// With exact bookkeeping the pair (s_i, u_i) of major i lies in the span of two consecutive search directions: s_i = -alpha_i d_i and,
+// because d_{i+1} = W_{i+1} g_{i+1} = omega_i t_i + theta_i d_i with t_i = W_i g_{i+1}, u_i = t_i - d_i = beta_i d_{i+1} + gamma_i d_i.
+// Substituting into the rank-two terms gives  W_k v = W0 v + sum_j kappa_j d_j,  kappa = (symmetric tridiagonal) (d_j . v):
+//   kappa_j = f_j delta_j + e_j delta_{j+1} + e_{j-1} delta_{j-1},   e_i = rho_i alpha_i beta_i,  f_i = 2 rho_i alpha_i gamma_i + c2_i alpha_i^2.
+// HBM holds the chain d_0 .. d_{nv-1} (the last one is the current direction), LDS the link scalars (e_i, f_i); a skipped update is a
+// null link (0, 0).  Rounds of G vectors through two register buffers like apply_history; the vector a round ends on is carried in
+// registers into the next round (its link reaches across).
+template <int NT, int EPT, int G>
+__device__ __forceinline__ void apply_dform(const NtgDims &D, const Smem &S, const double *hist, int nv, const double *v, double *t, const double *links)
+{
+	const int n = D.nC, tid = threadIdx.x;
+	double vv[EPT], tt[EPT], dc[EPT], dcl = 0.0;
+	int cc[EPT];
+#pragma unroll
+	for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; cc[e] = min(c, n - 1); vv[e] = c < n ? v[c] : 0.0; tt[e] = c < n ? t[c] : 0.0; dc[e] = 0.0; }
+	double hA[G][EPT], hB[G][EPT];
+	auto load = [&](int base, double (&h)[G][EPT]) {   // unconditional: past the end the newest vector again (its links are masked)
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			const double *p = hist + (size_t)min(base + g, nv - 1) * n;
+#pragma unroll
+			for (int e = 0; e < EPT; e++) h[g][e] = p[cc[e]];
+		}
+	};
+	auto consume = [&](int base, double (&h)[G][EPT]) {
+		double acc[G];
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			acc[g] = 0.0;
+#pragma unroll
+			for (int e = 0; e < EPT; e++) acc[g] += h[g][e] * vv[e];
+		}
+		block_sum<NT, G>(acc, S.red);
+#pragma unroll
+		for (int g = 0; g < G; g++) {
+			const int i = base - 1 + g;   // link i joins vector i (left) and vector i+1 = base+g (right)
+			const bool on = i >= 0 && i < nv - 1;
+			const int ii = on ? i : 0;
+			const double le = on ? links[2 * ii] : 0.0, lf = on ? links[2 * ii + 1] : 0.0;
+			const double dl = g == 0 ? dcl : acc[g > 0 ? g - 1 : 0], dr = acc[g];
+			const double a = le * dr + lf * dl, b = le * dl;
+#pragma unroll
+			for (int e = 0; e < EPT; e++) tt[e] += (g == 0 ? dc[e] : h[g > 0 ? g - 1 : 0][e]) * a + h[g][e] * b;
+		}
+#pragma unroll
+		for (int e = 0; e < EPT; e++) dc[e] = h[G - 1][e];
+		dcl = acc[G - 1];
+	};
+	load(0, hA);
+	for (int base = 0; base < nv; base += 2 * G) {
+		load(base + G, hB);
+		consume(base, hA);
+		if (base + G >= nv) break;
+		load(base + 2 * G, hA);
+		consume(base + G, hB);
+	}
+#pragma unroll
+	for (int e = 0; e < EPT; e++) { const int c = tid + e * NT; if (c < n) t[c] = tt[e]; }
 	lds_sync();
 }
 
@@ -1195,6 +1329,11 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	       *st = sxt /* t = W gp+ lives in the trial-point buffer once x is committed */,
 	       *sg = BIG ? gv + 4 * npad : S.vecs + 4 * npad, *tmp = S.vecs + (BIG ? 1 : 5) * npad;
 	double *hist = hist_all + (size_t)b * sp.memcap * (2 * n + 2);   // pair i: [s (n) | u (n) | rho | c2]
+	const double *hrc = L.hrc_n >= sp.memcap ? S.rho : nullptr;
+	// one vector per major (apply_dform): problems without augmented-Lagrangian passes (the direction is never re-projected), a memory that
+	// cannot fill up before the iteration limit, link scalars in LDS
+	constexpr bool DF_OK = !NWT && !BIG && EPT <= 4 && Family<FAM>::NNLIC + Family<FAM>::NNLTC + Family<FAM>::NNLFC == 0;
+	const bool dform = DF_OK && NTG_DFORM && D.nI == 0 && hrc != nullptr && sp.memcap >= sp.itlim && L.hrc_n > sp.memcap;   // pair scalars (rho, c2): LDS for memories that fit, else with the pair in HBM
 	stage_tables<NT>(D, T, S, smem_raw, L, b);
 	NtgTables Tw = T;   // the preconditioner blocks of this problem (per-problem grids) or the shared ones (stride 0)
 	if (HESS && T.n0b) Tw.n0b = T.n0b + (size_t)b * T.pp_n0b;
@@ -1459,7 +1598,11 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					NTG_STAMP(4);
 					// register-resident pairs: 3 coefficients per lane, 6 pairs per round; the 5-coefficient instances (config E)
 					// take 3 pairs per round
-					apply_history<NT, (EPT > 4 ? 5 : 3), (EPT > 4 ? 3 : NTG_HIST_G)>(D, S, hist, npairs, sgpt, st);
+					if (DF_OK && dform) {
+						if (npairs == 0) for_vec<NT>(n, [&](int c) { hist[c] = sd[c]; });   // a chain starts: d_0 (read back by the owner lanes only)
+						apply_dform<NT, 3, NTG_DF_G>(D, S, hist, npairs + 1, sgpt, st, hrc);
+					} else
+					apply_history<NT, (EPT > 4 ? 5 : 3), (EPT > 4 ? 3 : NTG_HIST_G)>(D, S, hist, npairs, sgpt, st, hrc);
 					NTG_STAMP(3);
 					double r6[6] = {0, 0, 0, 0, 0, 0};
 					for_vec<NT>(n, [&](int c) {
@@ -1470,21 +1613,38 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					const bool upd = !NWT && r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
 					const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
 					r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
+					const bool df = DF_OK && dform;
 					for_vec<NT>(n, [&](int c) {
 						const double s = sg[c], u = st[c] - sd[c];
-						if (upd) { hist[(size_t)npairs * (2 * n + 2) + c] = s; hist[(size_t)npairs * (2 * n + 2) + n + c] = u; }
+						if (upd && !df) { hist[(size_t)npairs * (2 * n + 2) + c] = s; hist[(size_t)npairs * (2 * n + 2) + n + c] = u; }
 						const double dn = upd ? st[c] - rho * (s * r6[3] + u * r6[2]) + c2 * s * r6[2] : st[c];
+						if (df) hist[(size_t)(npairs + 1) * n + c] = dn;   // the chain's next vector
 						const double xn = sx[c], gq = sgpt[c];
 						sgp[c] = gq;
 						sd[c] = dn;
 						r4[0] += gq * dn; r4[1] += dn * dn; r4[2] += xn * xn; r4[3] += gq * gq;
 					});
-					if (upd) {
-						if (tid == 0) { hist[(size_t)npairs * (2 * n + 2) + 2 * n] = rho; hist[(size_t)npairs * (2 * n + 2) + 2 * n + 1] = c2; }
+					if (df) {
+						// link scalars of this major (see apply_dform); omega = -(s.g)/(s.y) > 0 whenever the update is taken
+						double le = 0.0, lf = 0.0;
+						if (upd) {
+							const double omega = 1.0 - rho * r6[2], theta = rho * r6[2] - alpha * c2 * r6[2] + alpha * rho * r6[3];
+							const double beta = 1.0 / omega, gamma = -theta * beta - 1.0;
+							le = rho * alpha * beta; lf = 2.0 * rho * alpha * gamma + c2 * alpha * alpha;
+						}
+						if (tid == 0) { S.rho[2 * npairs] = le; S.rho[2 * npairs + 1] = lf; }
+						npairs++;
+					} else if (upd) {
+						if (tid == 0) {
+							if (hrc) { S.rho[2 * npairs] = rho; S.rho[2 * npairs + 1] = c2; }   // read after the barriers of the block_sum below
+							else { hist[(size_t)npairs * (2 * n + 2) + 2 * n] = rho; hist[(size_t)npairs * (2 * n + 2) + 2 * n + 1] = c2; }
+						}
 						npairs++;
 					}
-					__threadfence_block();
-					__syncthreads();   // rho/c2 of the new pair go through HBM/L2: needs the full barrier (vmcnt(0))
+					if (!hrc) {
+						__threadfence_block();
+						__syncthreads();   // rho/c2 of the new pair go through HBM/L2: needs the full barrier (vmcnt(0))
+					}
 					block_sum<NT, 4>(r4, S.red);
 					F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n;
 					iter++;
