@@ -163,10 +163,10 @@ def main():
                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms,
                        "alg_bytes_per_launch": alg_bytes,
                        "alg_bytes_def": f"{spec.eval_bytes()} B per funobj evaluation (SURVEY 8d) x {nfev_total} evaluations"}
-    # the same launch priced with the quasi-Newton pair history counted as algorithmic traffic (full-memory BFGS
-    # reads every stored pair once per major and writes one pair per major: DESIGN.md section 5)
+    # the same launch priced with the quasi-Newton history counted as algorithmic traffic (full-memory BFGS in the one-vector-per-major
+    # form: major a reads the a stored directions once and writes one)
     it_np = iters_np.astype(np.int64)
-    qn_bytes = int(((it_np * (it_np - 1) // 2) * (2 * spec.nC + 2) * 8 + it_np * (2 * spec.nC + 2) * 8).sum())
+    qn_bytes = int(((it_np * (it_np + 1) // 2) * spec.nC * 8 + (it_np + 1) * spec.nC * 8).sum())
     incl = alg_bytes + qn_bytes
     res["roofline_with_qn_history"] = {"bound": "hbm", "achieved": incl / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": incl / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_launch": incl,
@@ -394,7 +394,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
         ncore = os.cpu_count() or 1
-        ns = args.cpu_sample if args.cpu_sample > 0 else 4 * ncore
+        ns = args.cpu_sample if args.cpu_sample > 0 else 8 * ncore
         ns = min(ns, lo_all.shape[0])
         model = "unknown"
         try:
@@ -411,7 +411,7 @@ def main():
             t1 = time.perf_counter()
             r = orc.solve_batch(spec, lo_all[:ns], up_all[:ns], np.ones((ns, spec.nC)), oo, nthreads=ncore)
             dta = time.perf_counter() - t1
-            n1 = 64   # >= 2 s of single-thread work
+            n1 = 192   # >= 2 s of single-thread work
             t1 = time.perf_counter()
             orc.solve_batch(spec, lo_all[:n1], up_all[:n1], np.ones((n1, spec.nC)), oo, nthreads=1)
             dt1 = time.perf_counter() - t1
@@ -419,7 +419,7 @@ def main():
             if fl == "ref":
                 r_ref = r
         res["cpu_baseline"] = {"value": flav["ref"]["all_cores"], "unit": "trajectories/s", "cores": ncore, "kind": "port",
-                               "sample": f"first {ns} problems of the same batch (4 per host thread), same 50 fixed majors, oracle/sqp.c with the "
+                               "sample": f"first {ns} problems of the same batch ({ns // ncore} per host thread), same 50 fixed majors, oracle/sqp.c with the "
                                          f"reference-faithful dense assembly, OpenMP one problem per thread, {flav['ref']['all_cores_wall_s']:.2f} s wall",
                                "flavours": flav, "cpu_model": model, "compiler": cflags}
         # same inputs -> same answers (oracle is the checker here, never the thing shipped)

@@ -364,7 +364,13 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x,
 	// [row][P+1] + a zero tail: the column form reads W consecutive entries from a column's first breakpoint
 	{
 		// the structured Newton mode borrows this area between evaluations: solve vectors and factorisation panels of every group
-		int dfz_bytes = ((D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + ntg_dfz_tail(D)) * 8;
+		// evaluation layout (nvec == 0): the cost pass touches the cost's rows only, and the constraint pass wants room for the
+		// derivative rows of ONE constraint (it chunks over the constraints)
+		const int ncomp = __builtin_popcountll(D.tcon_mask);
+		L.dfz_rows = nvec > 0 ? D.ntav : std::max(D.ntav_cost, (ncomp * D.P + D.P) / (D.P + 1));
+		if (L.dfz_rows < 1) L.dfz_rows = 1;
+		L.tav_rows = nvec > 0 ? D.ntav : D.ntav_cost;
+		int dfz_bytes = (L.dfz_rows * (D.P + 1) + ntg_dfz_tail(D)) * 8;
 		if (D.nwt_on) dfz_bytes = std::max(dfz_bytes, std::max(D.nwt_ngrp * ((16 * ((D.nwt_ng + 15) / 16) + 48) + 48 * 17) * 8, (nthreads / 64) * 216 * 8));
 		L.dfz = p; L.nwt_y = p; p = align16(p + dfz_bytes);
 	}
@@ -381,13 +387,14 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x,
 	L.ls = p; p = align16(p + 2 * (int)sizeof(LineSearch));   // double buffered (see sqp_kernel)
 	L.tI = p; p = align16(p + (D.nI + 1) * 8);   // multiplier estimates of the linear inequality rows
 	L.q_idx = L.q_col = L.q_val = p;
-	if (D.q_use) {
+	L.with_lin = nvec > 0;
+	if (D.q_use && L.with_lin) {
 		L.q_idx = p; p = align16(p + D.nC * 2);
 		L.q_col = p; p = align16(p + D.q_nt * D.q_w * 4);
 		L.q_val = p; p = align16(p + D.q_nt * D.q_w * 8);
 	}
 	L.csr_ptr = L.csr_col = L.csr_val = L.csc_ptr = L.csc_row = L.csc_val = L.sinv_ptr = L.sinv_col = L.sinv_val = p;
-	if (D.lin_lds) {
+	if (D.lin_lds && L.with_lin) {
 		L.csr_ptr = p; p = align16(p + (D.nclin + 1) * 4);
 		L.csr_col = p; p = align16(p + D.lin_nnz * 4);
 		L.csr_val = p; p = align16(p + D.lin_nnz * 8);

@@ -28,7 +28,7 @@ struct NtgDims {
 	u64 icost_mask, tcost_mask, fcost_mask, icon_mask, tcon_mask, fcon_mask;
 	// running-cost gradient rows kept in LDS: only the flag entries that can be non-zero
 	// (the declared trajectory-cost active variables; all of them for host callbacks)
-	int ntav;
+	int ntav, ntav_cost;   // rows of the weighted-gradient area: all trajectory active variables; those of the cost come first
 	signed char tav_row[NTG_MAX_NZ];   // flat flag index -> compact row, or -1
 	int uniform;                        // 1: one basis class and equal ncoef for every output
 	int mE, nI;                         // linear rows kept by projection (equalities) / handled by the AL loop (declared inequalities)
@@ -112,6 +112,9 @@ __host__ __device__ inline int ntg_dfz_tail(const NtgDims &D) { int w = 16; for 
 struct SmemLayout {
 	int rowv, colp, chrow, chcol, off, bps, wts, x, dfz, fvals, red, dfi, dff, vecs, lam, rho, c2;
 	int csr_ptr, csr_col, csr_val, csc_ptr, csc_row, csc_val, sinv_ptr, sinv_col, sinv_val, oinfo, tavrow, tcomp, q_idx, q_col, q_val, ls, tI, total;
+	int with_lin;   // the linear-constraint operator (projector / CSR tables) is staged: solve layouts only, the evaluation never applies it
+	int tav_rows;   // active-variable rows the cost pass may touch: all (solve) or the cost's only (evaluation: the others are not even allocated)
+	int dfz_rows;   // rows of the weighted-gradient area: every active variable (solve) or the cost's / one constraint chunk's (evaluation)
 	int hrc_n;   // pairs whose scalars (rho, c2) live in LDS at L.rho (0: they travel with the pair in HBM)
 	int nwt_y;   // structured Newton mode: byte offset (inside the dfz area, which is idle between evaluations) of the solve vectors; panels follow
 };

@@ -151,7 +151,10 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 	D.ntav = 0;
 	for (int v = 0; v < NTG_MAX_NZ; v++) D.tav_row[v] = -1;
 	for (int v = 0; v < nz; v++)
-		if (s->family == NTG_FAM_HOST || (((D.tcost_mask | D.tcon_mask) >> v) & 1ull)) D.tav_row[v] = (signed char)D.ntav++;
+		if (s->family == NTG_FAM_HOST || ((D.tcost_mask >> v) & 1ull)) D.tav_row[v] = (signed char)D.ntav++;
+	D.ntav_cost = D.ntav;   // the evaluation's cost pass touches these rows only; the augmented Lagrangian of the solve the ones below too
+	for (int v = 0; v < nz; v++)
+		if (D.tav_row[v] < 0 && ((D.tcon_mask >> v) & 1ull)) D.tav_row[v] = (signed char)D.ntav++;
 
 	// ---- basis classes: outputs with identical (knots, order, mult, maxderiv) share a table ----
 	p->h_knots.resize(s->nout);

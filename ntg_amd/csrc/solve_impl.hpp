@@ -187,6 +187,7 @@ struct Smem {
 	const int *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col; const double *csr_val, *csc_val, *sinv_val;
 	int *oinfo, *tavrow, *tcomp;   // per-output scalars, flag->row map, flag->compact trajectory-constraint index, in LDS
 	short *q_idx; int *q_col; double *q_val;
+	int tav_rows;   // SmemLayout::tav_rows
 	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T, int b = 0)
 	{
 		rowv = (double *)(base + L.rowv); colp = (unsigned int *)(base + L.colp);
@@ -197,7 +198,7 @@ struct Smem {
 		red = (double *)(base + L.red); dfi = (double *)(base + L.dfi); dff = (double *)(base + L.dff);
 		vecs = (double *)(base + L.vecs); lam = (double *)(base + L.lam); rho = (double *)(base + L.rho);
 		c2 = (double *)(base + L.c2);
-		if (D.lin_lds) {
+		if (D.lin_lds && L.with_lin) {
 			csr_ptr = (const int *)(base + L.csr_ptr); csr_col = (const int *)(base + L.csr_col); csr_val = (const double *)(base + L.csr_val);
 			csc_ptr = (const int *)(base + L.csc_ptr); csc_row = (const int *)(base + L.csc_row); csc_val = (const double *)(base + L.csc_val);
 			sinv_ptr = (const int *)(base + L.sinv_ptr); sinv_col = (const int *)(base + L.sinv_col); sinv_val = (const double *)(base + L.sinv_val);
@@ -208,6 +209,7 @@ struct Smem {
 		}
 		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow); tcomp = (int *)(base + L.tcomp);
 		q_idx = (short *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
+		tav_rows = L.tav_rows;
 	}
 };
 
@@ -231,7 +233,7 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 		if (i < D.P - 1) w += (T.bps[i + 1] - T.bps[i]) / 2;
 		S.wts[i] = w;
 	}
-	if (D.lin_lds) {
+	if (D.lin_lds && L.with_lin) {
 		int *rp = (int *)(base + L.csr_ptr), *rc = (int *)(base + L.csr_col), *cp = (int *)(base + L.csc_ptr), *cr = (int *)(base + L.csc_row);
 		double *rv = (double *)(base + L.csr_val), *cv = (double *)(base + L.csc_val), *sv = (double *)(base + L.sinv_val);
 		int *sp_ = (int *)(base + L.sinv_ptr), *sc = (int *)(base + L.sinv_col);
@@ -248,12 +250,12 @@ __device__ __forceinline__ void stage_tables(const NtgDims &D, const NtgTables &
 		q[6] = D.cls[o] * NTG_MAX_ORDER; q[7] = D.cls[o] * D.P; q[8] = D.cls_W[D.cls[o]]; q[9] = D.ncoef[o];
 	}
 	for (int v = tid; v < D.nz; v += NT) {
-		S.tavrow[v] = D.tav_row[v];
+		S.tavrow[v] = D.tav_row[v] < L.tav_rows ? D.tav_row[v] : -1;
 		S.tcomp[v] = ((D.tcon_mask >> v) & 1ull) ? __popcll(D.tcon_mask & ((1ull << v) - 1ull)) : -1;   // see eval_constraints
 	}
-	for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;   // the row's extra element stays 0
-	for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[(D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + i] = 0.0;   // overrun of the last columns' reads (times 0)
-	if (D.q_use) {
+	for (int r = tid; r < L.dfz_rows; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;   // the row's extra element stays 0
+	for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[L.dfz_rows * (D.P + 1) + i] = 0.0;   // overrun of the last columns' reads (times 0)
+	if (D.q_use && L.with_lin) {
 		for (int i = tid; i < D.nC; i += NT) S.q_idx[i] = T.q_idx[i];
 		for (int i = tid; i < D.q_nt * D.q_w; i += NT) { S.q_col[i] = T.q_col[i]; S.q_val[i] = T.q_val[i]; }
 	}
@@ -526,7 +528,7 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 					for (int r = 0; r < DM; r++) { if ((CHM >> r) & 1) S.dfz[(o * NCH + chm_rank(CHM, r)) * (P + 1) + i] = df[DM * o + r]; }
 			} else {
 #pragma unroll
-				for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0) S.dfz[D.tav_row[v] * (P + 1) + i] = df[v]; }
+				for (int v = 0; v < NZ; v++) { if (v < nz && D.tav_row[v] >= 0 && D.tav_row[v] < S.tav_rows) S.dfz[D.tav_row[v] * (P + 1) + i] = df[v]; }
 			}
 		}
 	}
@@ -831,7 +833,11 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 				constexpr int NW = NT / 64, RMAX = NOUT > 0 ? DM : NTG_MAX_ORDER;
 				const int sumk = D.sumk, nrows = jn * P, wv = tid >> 6, ln = tid & 63;
 				double *dst = jband + (size_t)(D.nnlic + j0 * P) * sumk;
-				for (int e = ln; e < sumk; e += 64) {
+				// entries [e0, e0 + width) of 64 / width rows per step: a row narrower than a wave shares it with its neighbours
+				// (sum(k) = 32: two rows per store instruction; the 8 left-over entries of a 72-entry row: eight rows)
+				auto emit_pass = [&](int e0, int width) {
+					const int rpi = 64 / width, rsub = ln / width, e = e0 + ln % width;
+					if (rsub >= rpi) return;
 					int o = 0;
 					if (NOUT > 0 && K > 0) o = e / K;                 // one order for every output
 					else while (o + 1 < nout && D.koff[o + 1] <= e) o++;
@@ -844,18 +850,19 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 						const bool on = comp >= 0 && chr >= 0;
 						cof[r] = on ? comp * P : -1; rof[r] = on ? chr + q * P : 0;
 					}
-					int jc = 0, bp = wv;
-					while (bp >= P) { bp -= P; jc++; }
-					for (int row = wv; row < nrows; row += NW) {
+					const int step = NW * rpi;
+					int row = wv * rpi + rsub, jc = row / P, bp = row - jc * P;
+					for (; row < nrows; row += step) {
 						double a = 0.0;
 #pragma unroll
 						for (int r = 0; r < RMAX; r++)
 							if (cof[r] >= 0) a += scratch[jc * ncomp * P + cof[r] + bp] * S.rowv[rof[r] + bp];
 						dst[(size_t)row * sumk + e] = a;
-						bp += NW;
+						bp += step;
 						while (bp >= P) { bp -= P; jc++; }
 					}
-				}
+				};
+				for (int e0 = 0; e0 < sumk; e0 += 64) emit_pass(e0, min(64, sumk - e0));
 				lds_sync();
 			}
 		}
@@ -916,7 +923,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 			eval_constraints<FAM, NOUT, K, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
 			                                jband ? jband + (size_t)b * D.ncnln * D.sumk : nullptr,
 			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr,
-			                                S.dfz, (D.ntav > 0 ? D.ntav : 1) * (P1) + ntg_dfz_tail(D));
+			                                S.dfz, L.dfz_rows * (P1) + ntg_dfz_tail(D));
 		}
 		double gn2;
 		const double F = eval_cost<FAM, NOUT, K, NT, EPT, (NOUT >= 3), CHM>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr},
@@ -1428,8 +1435,8 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		}
 		if (BIG) __syncthreads(); else lds_sync();
 		// the area borrowed from the weighted-gradient rows goes back with its zero padding restored (stage_tables)
-		for (int r = tid; r < D.ntav; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;
-		for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[(D.ntav > 0 ? D.ntav : 1) * (D.P + 1) + i] = 0.0;
+		for (int r = tid; r < L.dfz_rows; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;
+		for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[L.dfz_rows * (D.P + 1) + i] = 0.0;
 		lds_sync();
 	};
 	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};

@@ -11,6 +11,20 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, %r)
 from ntg_amd import api, configs as cf
 cfg, B = sys.argv[1], int(sys.argv[2])
+if cfg.startswith("eval"):
+    spec = {"evalD": cf.config_D, "evalE": cf.config_E, "evalM": cf.config_M}[cfg]()
+    p = api.Plan(spec, 0)
+    x = torch.randn((B, spec.nC), dtype=torch.float64, device="cuda:0")
+    o = p.eval(x, 2)
+    for _ in range(3): p.eval(x, 2, out=o)
+    torch.cuda.synchronize()
+    tms = []
+    for _ in range(10):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); p.eval(x, 2, out=o); e1.record(); torch.cuda.synchronize(); tms.append(e0.elapsed_time(e1))
+    ms = float(np.median(tms)); byts = B * spec.eval_bytes()
+    print(os.environ.get("NTG_AMD_LIB", "default").split("/")[-1], cfg, "B", B, "med %%.3f ms  %%.0f GB/s  frac %%.3f" %% (ms, byts / ms / 1e6, byts / ms / 1e6 / 8000), flush=True)
+    raise SystemExit(0)
 dev = torch.device("cuda:0")
 if cfg == "M":
     spec = cf.config_M(); lo, up = cf.kincar_random_bounds(3, B); modes = [dict(itlim=50, fixed_iters=1, hessian=0), dict(hessian=1)]
