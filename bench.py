@@ -231,6 +231,35 @@ def main():
             resB[key] = {"value": 256 / dtB, "unit": "trajectories/s", "ms_per_batch": 1e3 * dtB, "iters_mean": float(ooB["iters"].float().mean().item())}
         res["config_B_batch256"] = resB   # one problem per CU: this size measures the latency of a single solve, not throughput
         del planB
+        # ---- cost of specialisation: shapes that take the generic kernel instance (any nout / order at run time) next to tuned ones,
+        #      same fixed-work mode, normalised per flat output ----
+        gen = {}
+        for gname, gspec, ncars in (("kincar-4out-k6-l20 (tuned instance, added this round)", cf._kincar_spec(2, 6, 3, 20, 101, 5.0, "G4"), 2),
+                                    ("kincar-4out-k6-l16, 81 breakpoints (generic instance: 16 knot intervals)", cf._kincar_spec(2, 6, 3, 16, 81, 5.0, "G4b"), 2),
+                                    ("kincar-2out-k6-l20 (tuned instance)", cf.config_B(), 1),
+                                    ("kincar-2out-k5-l2, 20 breakpoints: the shipped example's shape (tuned order-5 instance)", cf.config_K0(), 1),
+                                    ("kincar-2out-k4-l10, 41 breakpoints (generic instance)", cf._kincar_spec(1, 4, 2, 10, 41, 5.0, "G2"), 1)):
+            planG = api.Plan(gspec, local)
+            loG, upG = cf.kincar_random_bounds(ncars, 4096)
+            loG = torch.tensor(loG, device=dev); upG = torch.tensor(upG, device=dev)
+            xG = torch.ones((4096, gspec.nC), dtype=torch.float64, device=dev)
+            oG = api.default_opts(itlim=args.iters, fixed_iters=1, hessian=0)
+            wG = torch.empty(planG.workspace_bytes(4096, oG), dtype=torch.uint8, device=dev)
+            for _ in range(2):
+                xG.fill_(1.0); planG.solve(loG, upG, xG, oG, work=wG)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(5):
+                xG.fill_(1.0); ooG = planG.solve(loG, upG, xG, oG, work=wG)
+            torch.cuda.synchronize(); dtG = (time.perf_counter() - t1) / 5
+            xe4 = torch.randn((1 << 16, gspec.nC), dtype=torch.float64, device=dev)
+            og4 = planG.eval(xe4, 2); planG.eval(xe4, 2, out=og4); torch.cuda.synchronize(); t1 = time.perf_counter()
+            for _ in range(5):
+                planG.eval(xe4, 2, out=og4)
+            torch.cuda.synchronize(); dte = (time.perf_counter() - t1) / 5
+            gen[gname] = {"solve_ms_per_4096": 1e3 * dtG, "trajectories_per_s": 4096 / dtG, "nfev_per_problem": float(ooG["nfev"].float().mean().item()),
+                          "eval_GBps": (1 << 16) * gspec.eval_bytes() / dte / 1e9, "eval_frac_of_hbm_peak": (1 << 16) * gspec.eval_bytes() / dte / 1e9 / HBM_PEAK_GBS}
+            del planG, wG, xe4, og4
+        res["generic_instances"] = gen
         # ---- BASELINE config C: receding-horizon MPC, 100 re-solves x batch 1024, kincar 2-output ----
         specC = cf.config_B(); planC = api.Plan(specC, local)
         nbC = 1024

@@ -284,7 +284,7 @@ eval_interval_kernel(IntervalEvalDims D, NtgTables T, int batch, int mode, const
 #pragma unroll
 	for (int e = 0; e < XE; e++) {
 		int i = lane + 64 * e;
-		if (i >= PW * nC) i -= 64;
+		while (i >= PW * nC) i -= 64;   // (4 outputs: 252 staged doubles, the last two slots repeat earlier ones)
 		sidx[e] = i; spl[e] = i / nC; sof[e] = i - spl[e] * nC;
 	}
 	double xn[XE];

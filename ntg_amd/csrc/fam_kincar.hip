@@ -13,7 +13,7 @@ hipError_t ntg_launch_eval_kincar(const NtgDims &D, const NtgTables &T, const Sm
 	const bool chm = ntg_chm_match(D, 4, 3);
 	(void)ku;
 	// channel-mask instances: the cost's active variables are the second derivative of every output (kincar.c:133-137)
-	if (small && chm && ku == 6 && (D.nout == 2 || D.nout == 6)) return ntg_launch_eval_kincar_chm(D, T, L, a);
+	if (small && chm && ku == 6 && (D.nout == 2 || D.nout == 4 || D.nout == 6)) return ntg_launch_eval_kincar_chm(D, T, L, a);
 	if (small && D.nout == 2 && ku == 6) return launch_eval_small<NTG_FAM_KINCAR, 2, 6>(D, T, L, a);
 	if (small && D.nout == 6 && ku == 6) return launch_eval_small<NTG_FAM_KINCAR, 6, 6>(D, T, L, a);
 	if (small && D.nout == 2 && ku == 5) return launch_eval_small<NTG_FAM_KINCAR, 2, 5>(D, T, L, a);
@@ -26,7 +26,7 @@ hipError_t ntg_launch_sqp_kincar(const NtgDims &D, const NtgTables &T, const Sme
 	const int ku = ntg_uniform_order(D, a.nt, 4);
 	const bool chm = ntg_chm_match(D, 4, 3);
 	(void)ku;
-	if (small && !a.big && chm && ku == 6 && (D.nout == 2 || D.nout == 6)) return ntg_launch_sqp_kincar_chm(D, T, L, sp, a);
+	if (small && !a.big && chm && ku == 6 && (D.nout == 2 || D.nout == 4 || D.nout == 6)) return ntg_launch_sqp_kincar_chm(D, T, L, sp, a);
 	if (small && !a.big && D.nout == 2 && ku == 6) return launch_sqp_small<NTG_FAM_KINCAR, 2, 6>(D, T, L, sp, a);
 	if (small && !a.big && D.nout == 6 && ku == 6) return launch_sqp_small<NTG_FAM_KINCAR, 6, 6>(D, T, L, sp, a);
 	if (small && !a.big && D.nout == 2 && ku == 5) return launch_sqp_small<NTG_FAM_KINCAR, 2, 5>(D, T, L, sp, a);

@@ -1340,7 +1340,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	// one vector per major (apply_dform): problems without augmented-Lagrangian passes (the direction is never re-projected), a memory that
 	// cannot fill up before the iteration limit, link scalars in LDS
 	constexpr bool DF_OK = !NWT && !BIG && EPT <= 4 && Family<FAM>::NNLIC + Family<FAM>::NNLTC + Family<FAM>::NNLFC == 0;
-	const bool dform = DF_OK && NTG_DFORM && D.nI == 0 && hrc != nullptr && sp.memcap >= sp.itlim && L.hrc_n > sp.memcap;   // pair scalars (rho, c2): LDS for memories that fit, else with the pair in HBM
+	const bool dform = DF_OK && NTG_DFORM && D.nI == 0 && D.nC <= 3 * NT && hrc != nullptr && sp.memcap >= sp.itlim && L.hrc_n > sp.memcap;   // pair scalars (rho, c2): LDS for memories that fit, else with the pair in HBM
 	stage_tables<NT>(D, T, S, smem_raw, L, b);
 	NtgTables Tw = T;   // the preconditioner blocks of this problem (per-problem grids) or the shared ones (stride 0)
 	if (HESS && T.n0b) Tw.n0b = T.n0b + (size_t)b * T.pp_n0b;

@@ -66,9 +66,9 @@ def test_eval_matches_reference_fixture(name):
                 koff += k; iC += spec.ncoef[o]
 
 
-@pytest.mark.parametrize("name", ["A", "B", "M", "T"])
+@pytest.mark.parametrize("name", ["A", "B", "M", "T", "M4"])
 def test_eval_vs_oracle_random_batch(name):
-    spec = SPECS[name]()
+    spec = plan_for(name).spec
     rng = np.random.default_rng(11)
     x = rng.normal(size=(37, spec.nC)) * 3.0                         # ragged vs the persistent grid
     ref = orc.eval_batch(spec, x, 2)

@@ -46,7 +46,7 @@ def test_vanderpol_known_answer(hessian):
     assert out["iters"][0] == o["iters"] and out["nfev"][0] == o["nfev"]
 
 
-@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3)])
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3), ("M4", 2)])
 @pytest.mark.parametrize("hessian", [0, 1])
 def test_optimum_matches_kkt_and_oracle(name, ncars, hessian):
     spec = plan_for(name).spec
@@ -71,7 +71,7 @@ def test_optimum_matches_kkt_and_oracle(name, ncars, hessian):
         assert np.abs(out["iters"] - ref["iters"]).max() <= 1
 
 
-@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3)])
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3), ("M4", 2)])
 def test_fixed_50_majors_parity_with_oracle(name, ncars):
     """The benchmark mode: exactly 50 majors, identity cold start."""
     spec = plan_for(name).spec
@@ -80,6 +80,23 @@ def test_fixed_50_majors_parity_with_oracle(name, ncars):
     x, out = solve(name, lo, up, np.ones((nb, spec.nC)), itlim=50, fixed_iters=1)
     ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(itlim=50, fixed_iters=1), nthreads=8)
     assert (out["iters"] == 50).all() and (out["inform"] == 4).all()
+    assert np.array_equal(out["nfev"], ref["nfev"])
+    assert rel(out["objective"], ref["objective"]) <= 1e-7
+    assert np.abs(x - ref["x"]).max() <= 1e-5 * np.abs(ref["x"]).max()
+
+
+@pytest.mark.parametrize("itlim,memory", [(30, 0), (70, 0), (50, 20)])
+def test_fixed_majors_parity_in_every_history_form(itlim, memory):
+    """The device keeps the quasi-Newton operator in three forms, all the matrix of DESIGN 4a.4: one stored direction per major with the
+    link scalars in LDS (short runs: itlim <= memory < 64; the headline mode), pairs (s, u) with (rho, c2) in LDS (memory < 64 < itlim:
+    restarts when full), pairs with their scalars in HBM (longer memories).  Same iterates as the oracle's dense W in each."""
+    spec = plan_for("M").spec
+    nb = 8
+    lo, up = cf.kincar_random_bounds(3, nb)
+    kw = dict(itlim=itlim, fixed_iters=1, qn_memory=memory)
+    x, out = solve("M", lo, up, np.ones((nb, spec.nC)), **kw)
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(**kw), nthreads=8)
+    assert (out["iters"] == itlim).all()
     assert np.array_equal(out["nfev"], ref["nfev"])
     assert rel(out["objective"], ref["objective"]) <= 1e-7
     assert np.abs(x - ref["x"]).max() <= 1e-5 * np.abs(ref["x"]).max()
