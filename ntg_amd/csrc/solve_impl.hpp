@@ -1600,6 +1600,25 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					for_vec<NT>(n, [&](int c) { sg[c] = alpha * (-sd[c]); sx[c] = sxt[c]; });   // sg = the step s
 					if (!NWT && npairs == sp.memcap) { npairs = 0; apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo); } // memory full: restart
 					NTG_STAMP(5);
+					bool conv_now = false;
+					if (NWT && !sp.fixed_iters) {
+						// The exit test of this major needs |x| and |gp+| only.  Taken BEFORE the model is rebuilt: a pass that ends here
+						// (every pass ends on an accepted step) would otherwise assemble and factor a matrix nobody uses -- one of the
+						// 2.7 (config D) refreshes per pass.
+						double r2[2] = {0, 0};
+						for_vec<NT>(n, [&](int c) { const double xn = sx[c], gq = sgpt[c]; r2[0] += xn * xn; r2[1] += gq * gq; });
+						block_sum<NT, 2>(r2, S.red);
+						conv_now = alpha * pnorm <= sri * (1.0 + sqrt(r2[0])) && sqrt(r2[1]) <= sri * (1.0 + fmax(1.0 + fabs(Fn), sqrt(gn2n)));
+						if (conv_now) {
+							for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
+							r4[2] = r2[0]; r4[3] = r2[1];
+							F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n;
+							iter++;
+							inner_inform = 0; finished = true;
+							lds_sync();
+						}
+					}
+					if (!conv_now) {
 					if (NWT) { nwt_refresh(sxt, true); nwt_apply(sgpt, st); }   // sxt still holds the accepted point; st (= sxt) is written last
 					else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgpt, st, sxt, S.oinfo);
 					NTG_STAMP(4);
@@ -1658,6 +1677,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					if (!sp.fixed_iters && alpha * pnorm <= sri * (1.0 + sqrt(r4[2])) &&
 					    sqrt(r4[3]) <= sri * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inner_inform = 0; finished = true; }
 					else new_major = true;
+					}
 				}
 			}
 			}
