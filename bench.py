@@ -235,7 +235,7 @@ def main():
         #      same fixed-work mode, normalised per flat output ----
         gen = {}
         for gname, gspec, ncars in (("kincar-4out-k6-l20 (tuned instance, added this round)", cf._kincar_spec(2, 6, 3, 20, 101, 5.0, "G4"), 2),
-                                    ("kincar-4out-k6-l16, 81 breakpoints (generic instance: 16 knot intervals)", cf._kincar_spec(2, 6, 3, 16, 81, 5.0, "G4b"), 2),
+                                    ("kincar-4out-k6-l16, 81 breakpoints (tuned solve instance; breakpoint-lane evaluation kernel: the interval kernel is compiled for 20 knot intervals)", cf._kincar_spec(2, 6, 3, 16, 81, 5.0, "G4b"), 2),
                                     ("kincar-2out-k6-l20 (tuned instance)", cf.config_B(), 1),
                                     ("kincar-2out-k5-l2, 20 breakpoints: the shipped example's shape (tuned order-5 instance)", cf.config_K0(), 1),
                                     ("kincar-2out-k4-l10, 41 breakpoints (generic instance)", cf._kincar_spec(1, 4, 2, 10, 41, 5.0, "G2"), 1)):

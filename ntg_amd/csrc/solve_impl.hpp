@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 {
 	const int n = D.nC, tid = threadIdx.x;
 #if NTG_HIST_PIPE > 0
-	if (EPT <= 3 && n <= EPT * NT && hrc) {
+	if (EPT <= 3 && NT <= 128 && n <= EPT * NT && hrc) {   // (one workgroup per CU, NT >= 256: fewer, larger rounds are faster -- config D 162 vs 190 ms)
 		constexpr int PG = NTG_HIST_PIPE;
 		// Two register buffers of PG pairs: the loads of round r+1 are in flight while round r is reduced.  Every load is
 		// unconditional (pair index clamped to the newest pair, column clamped to n-1) so that the waits are counted

@@ -29,7 +29,7 @@ label = {"sqp_kernel<0, 6, 6, 128, 4, false, false, 4, false>": "headline sqp_ke
          "sqp_kernel<5, 12, 6, 512, 5, true, true, 5, true>": "sqp_kernel config E, 1024 problems, structured Newton mode",
          "sqp_kernel<5, 12, 6, 512, 5, true, true, 5, false>": "sqp_kernel config E, 1024 problems, quasi-Newton mode",
          "eval_interval_kernel<0, 6, 2, 6, 4, 256, 4, 20, true>": "eval_interval_kernel: 2^18 evaluations of config M",
-         "eval_kernel<4, 4, 8, 512, 4, 0>": "eval_kernel config D with banded Jacobian rows, 4096 evaluations",
+         "eval_kernel<4, 4, 8, 256, 4, 0>": "eval_kernel config D with banded Jacobian rows, 4096 evaluations (two workgroups of 256 per CU)",
          "eval_kernel<5, 12, 6, 512, 5, 0>": "eval_kernel config E with banded Jacobian rows, 2048 evaluations"}
 for k, d in dur.items():
     kk = k.replace("void ", "").strip()
