@@ -22,6 +22,15 @@
 #include "ntg_dev.hpp"
 
 #define NWT_PSTRIDE 17   // LDS row stride (doubles) of the 48 x 16 panel
+// LDS scratch of the out-of-line routines is passed as an address-space-3 pointer: through a generic `double *` the compiler has to
+// emit FLAT loads and stores (it cannot see across the call that the pointer is LDS), which go through the vector-memory path -- every
+// pivot step then waited on vmcnt(0), i.e. also on the prefetched band rows and the stores of the previous block column (measured:
+// factorisation 13.0 k -> 12.0 k ticks per block column standalone; config E's Newton solve 272 -> 231 ms per 1024 problems).
+typedef __attribute__((address_space(3))) double *nwt_lds_dp;
+// ... and the band in HBM as an address-space-1 pointer: FLAT accesses also count in lgkmcnt, so the LDS hand-offs of the pivot sweep
+// (s_waitcnt lgkmcnt(0)) waited for the band rows prefetched for the next block column.
+typedef __attribute__((address_space(1))) double *nwt_glb_dp;
+typedef const __attribute__((address_space(1))) double *nwt_glb_cdp;
 // The factorisation and the assembly are inlined into the solve kernel; only the triangular solves are kept out of line.
 // (With all three out of line the tuned quadrotor instance faulted on the GPU -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION
 // on a flat access -- although every index checked out; inlined, the same code runs clean.  Treated as a code-generation
@@ -114,7 +123,7 @@ __device__ __forceinline__ double nwt_rsqrt(double p)    // 1/sqrt(p): hardware 
 //   2. the sub-diagonal tiles by the matrix cores, X = T L00^-T: E in the accumulator layout IS the B operand, T goes
 //      through LDS into the operand layout;
 //   3. the trailing update T -= X X' of the window, 12 matrix instructions, X through LDS into the operand layout.
-__device__ __forceinline__ void nwt_to_operand(const nwt_d4 &T, double *xb, int li, int lk, double (&op)[4])
+__device__ __forceinline__ void nwt_to_operand(const nwt_d4 &T, nwt_lds_dp xb, int li, int lk, double (&op)[4])
 {
 #pragma unroll
 	for (int r = 0; r < 4; r++) xb[(4 * r + lk) * NWT_PSTRIDE + li] = T[r];
@@ -123,10 +132,10 @@ __device__ __forceinline__ void nwt_to_operand(const nwt_d4 &T, double *xb, int 
 	for (int s = 0; s < 4; s++) op[s] = xb[li * NWT_PSTRIDE + 4 * s + lk];   // X[l%16][4 s + l/16]: A[i][k] as well as B[k][j] = X'[k][j]
 	nwt_wave_sync();
 }
-__device__ __attribute__((noinline)) int nwt_factor_wave(double *__restrict__ Kc, int ng, int hb, double *panel, int strict)
+__device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__ Kc, int ng, int hb, nwt_lds_dp panel, int strict)
 {
 	const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
-	double *colbuf = panel, *xbuf = panel + 64;   // 32 doubles; one tile of 16 x NWT_PSTRIDE
+	nwt_lds_dp colbuf = panel, xbuf = panel + 64;   // 32 doubles; one tile of 16 x NWT_PSTRIDE
 	int fail = 0;
 	// Addressing of the window relative to block column J: element (tile row a, register r) of a tile whose columns are block J + b sits
 	// at  Kc[16 J ld + off],  off = (16 a + 4 r + lk) (ld - 1) + 16 b + li + hb  -- a lane constant; whether it lies inside the band
@@ -135,7 +144,7 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(double *__restrict__ Kc
 	auto inband = [&](int a, int b, int r) { const int d = 16 * (a - b) + 4 * r + lk - li; return d >= 0 && d <= hb; };   // row - column
 	auto load_tile = [&](int J, int a, int b) {   // tile (J + a, J + b) in the accumulator layout; identity beyond the end of the matrix
 		nwt_d4 t;
-		const double *base = Kc + (size_t)16 * J * ld;
+		nwt_glb_cdp base = Kc + (size_t)16 * J * ld;
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
 			const int row = 16 * (J + a) + 4 * r + lk;
@@ -194,7 +203,7 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(double *__restrict__ Kc
 		}
 		// the finished block column of L to HBM (band entries only; the diagonal inverted)
 		{
-			double *base = Kc + (size_t)16 * J * ld;
+			nwt_glb_dp base = Kc + (size_t)16 * J * ld;
 			const int rows_left = ng - 16 * J;
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
@@ -223,7 +232,7 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(double *__restrict__ Kc
 }
 
 // y <- L^-T L^-1 y for one group by ONE wavefront.  y: LDS, 16 nbr + 48 doubles, entries >= ng zero.
-__device__ __attribute__((noinline)) void nwt_solve_wave(const double *__restrict__ Lc, int ng, int hb, double *y)
+__device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict__ Lc, int ng, int hb, nwt_lds_dp y)
 {
 	const int lane = threadIdx.x & 63, q = lane & 15, part = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
 	// ---- forward: L w = y ----

@@ -16,10 +16,10 @@ __global__ void __launch_bounds__(64) unit_kernel(double *K, int ng, int hb, dou
 	for (int i = threadIdx.x; i < ylen; i += 64) y[i] = i < ng ? yio[i] : 0.0;
 	__syncthreads();
 	const long long t0 = __builtin_amdgcn_s_memtime();
-	const int f = nwt_factor_wave(K, ng, hb, panel, 1);
+	const int f = nwt_factor_wave((nwt_glb_dp)K, ng, hb, (nwt_lds_dp)panel, 1);
 	__syncthreads();
 	const long long t1 = __builtin_amdgcn_s_memtime();
-	nwt_solve_wave(K, ng, hb, y);
+	nwt_solve_wave((nwt_glb_cdp)K, ng, hb, (nwt_lds_dp)y);
 	__syncthreads();
 	const long long t2 = __builtin_amdgcn_s_memtime();
 	if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = t2 - t1; }
