@@ -383,7 +383,18 @@ def main():
         res["eval_kernel"] = {"kernel": "eval_interval_kernel (cost-only single-class instance of the evaluation: one lane per knot interval and output pair)", "batch": nb, "ms": ems, "achieved": eb / (ems * 1e-3) / 1e9,
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": eb / (ems * 1e-3) / 1e9 / HBM_PEAK_GBS,
                               "evals_per_s": nb / (ems * 1e-3)}
-        del xe
+        # the practical ceiling next to the 8 TB/s spec: a plain device-to-device copy with the same read and write volume on this box
+        ca = torch.empty(nb * (spec.nC + 1), dtype=torch.float64, device=dev).normal_(); cb_ = torch.empty_like(ca)
+        for _ in range(3):
+            cb_.copy_(ca)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(nrep):
+            cb_.copy_(ca)
+        e1.record(); torch.cuda.synchronize()
+        cms = e0.elapsed_time(e1) / nrep
+        cgb = 2 * ca.numel() * 8 / (cms * 1e-3) / 1e9
+        res["eval_kernel"].update({"device_copy_same_bytes_ms": cms, "device_copy_same_bytes_GBps": cgb, "frac_of_device_copy": res["eval_kernel"]["achieved"] / cgb})
+        del xe, ca, cb_
         # ---- per-problem grids (free final time): every problem on its own horizon; the basis rows and weights are then per-problem
         #      input (counted in the algorithmic bytes) and eval_kernel stages them per problem ----
         nbg = 16384

@@ -415,10 +415,13 @@ static hipError_t launch_eval_interval(const NtgTables &T, const IntervalEvalDim
 {
 	if (F.nint != NINT || F.nco != (K / 2) * NINT + K / 2 || F.nC != NOUT * F.nco) return hipErrorInvalidValue;
 	static_assert(OPL == NOUT || Family<FAM>::PER_OUTPUT_COST, "outputs may be split over lanes only when the cost is a sum over the outputs");
-	constexpr int NT = 256, NW = NT / 64, NCH = chm_count(CHM);
+#ifndef NTG_EVI_NT
+#define NTG_EVI_NT 256
+#endif
+	constexpr int NT = NTG_EVI_NT, NW = NT / 64, NCH = chm_count(CHM);
 	const int ncu = a.ncu > 0 ? a.ncu : 256, PW = 64 / (F.nint * (NOUT / OPL));
 	const size_t lds = ((size_t)NCH * 6 * K * F.nint + 2 * 6 * F.nint + (size_t)NW * (PW * F.nC + 64)) * 8;
-	const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(MINW, (160 * 1024) / lds));   // MINW waves per SIMD = MINW workgroups of 4 waves per CU
+	const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(MINW * 4 / NW, (160 * 1024) / lds));   // MINW waves per SIMD = 4 MINW waves per CU
 	const int need = (a.batch + NW * PW - 1) / (NW * PW);
 	const int grid = std::max(1, std::min(need, ncu * wg_per_cu));
 	if (a.g && a.mode != 0) {
