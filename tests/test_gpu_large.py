@@ -3,7 +3,14 @@
 
 Reduced grids are compared with the oracle's solve (same algorithm); at the full sizes of BASELINE.json
 (nC = 656 / 2196, P = 201 / 301, ncnln = 402 / 1204) the evaluation is compared with the oracle entry by
-entry and the solve through its KKT conditions, which do not depend on how the optimum was reached."""
+entry and the solve through its KKT conditions, which do not depend on how the optimum was reached.
+
+The solves in THIS file run the quasi-Newton augmented-Lagrangian mode (hessian = 1): its passes can end on a stalled BFGS iteration
+(`inform 1`, "optimal but not to the requested accuracy": 99 of 512 config-D problems at the bench batch), so stationarity and objective are
+asserted at that mode's 2e-5.  The mode meant for these configs is the structured Newton step (hessian = 2); its parity is asserted in
+tests/test_gpu_newton.py at the SURVEY 8c tolerances: objective 1e-9 and x* 1e-6 against committed oracle solutions of 8 full-size problems
+per config (tests/golden/sol_{D,E}.npz), scaled stationarity 1.3e-7 (the stopping rule is NPSOL's 5.5e-7; the median reached is 5e-9 --
+1e-8 for EVERY problem would need a tolerance below NPSOL's own), violation 1e-8, and the `inform` histogram at the bench batch."""
 import numpy as np
 import pytest
 import torch
