@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="problems per GPU")
     ap.add_argument("--config", default="M", choices=["M", "B"])
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="problems of the CPU baseline sample (0: 4 per host thread)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="problems of the CPU baseline sample (0: 8 per host thread)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch problems per GPU (default); strong: --batch problems in all, split over the GPUs")
     ap.add_argument("--no-cpu", action="store_true")
