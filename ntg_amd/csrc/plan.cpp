@@ -1188,6 +1188,10 @@ extern "C" int ntg_debug_layout(const ntg_plan *p, const ntg_solve_opts *o, int 
 	resolve_params(p, o, &sp, &nt);
 	SmemLayout L; int big;
 	solve_layout(p->D, nt, &L, &big, &sp);
+	if (getenv("NTG_AMD_DEBUG"))
+		fprintf(stderr, "solve layout (big %d): rowv %d colp %d chrow %d off %d bps %d wts %d x %d dfz %d fvals %d red %d dfi %d vecs %d lam %d rho %d oinfo %d ls %d tI %d q_idx %d q_col %d q_val %d csr_ptr %d sinv_val %d total %d | row_total %d col_total %d ntav %d q_nt %d q_w %d lin_nnz %d sinv_nnz %d lin_lds %d\n",
+		        big, L.rowv, L.colp, L.chrow, L.off, L.bps, L.wts, L.x, L.dfz, L.fvals, L.red, L.dfi, L.vecs, L.lam, L.rho, L.oinfo, L.ls, L.tI, L.q_idx, L.q_col, L.q_val, L.csr_ptr, L.sinv_val, L.total,
+		        p->D.row_total, p->D.col_total, p->D.ntav, p->D.q_nt, p->D.q_w, p->D.lin_nnz, p->D.sinv_nnz, p->D.lin_lds);
 	if (lds_solve) *lds_solve = big ? -L.total : L.total;   // negative: only the cross-lane vectors are in LDS
 	if (lds_eval) *lds_eval = ntg_make_layout(p->D, auto_threads(p->D), 0, 1).total;
 	if (nt_solve) *nt_solve = nt;
