@@ -332,7 +332,10 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 // HBM/L2: the interval's blocks (one coalesced load, staged in LDS) and the band entries the result is added to are
 // requested together, before the products.
 // Bz: [ngrp][P][cg*cg] of this problem, or nullptr (cost model alone: phase 0, mu == 0).  wbuf: LDS, 216 doubles per wave.
-template <int NT>
+// CG: the family's block size (Family::CG) as a compile-time constant: the loop over a block's variables unrolls, kk / CG is a multiply,
+// and what a variable is (its output, the LDS offset of its derivative channel, whether this lane's columns belong to its output) is
+// decoded once per kernel instead of once per k-step and variable.
+template <int NT, int CG>
 NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *rowv, const int *chrow, const int *offt,
                                                        const double *__restrict__ Bz, double *__restrict__ Kc, double *wbuf_all,
                                                        unsigned long long *tkx = nullptr)
@@ -340,7 +343,8 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 	unsigned long long tx0 = tkx ? __builtin_amdgcn_s_memtime() : 0;
 	constexpr int NW = NT / 64;
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-	const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ld = hb + 1, go = D.nwt_go, cg = D.nwt_cg, P = D.P;
+	const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ld = hb + 1, go = D.nwt_go, P = D.P;
+	constexpr int cg = CG;
 	const int kg = D.order[0] * go, cover = D.nwt_cover, nint = D.nwt_nint, total = ngp * ng * ld, clo = D.nwt_clo, chi = D.nwt_chi;
 	const u64 upack = D.nwt_upack;
 	for (int e = tid; e < total; e += NT) Kc[e] = T.nwt_k0[e];
@@ -356,6 +360,16 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 	int qr0[4], or0[4], qr1[4], or1[4];
 #pragma unroll
 	for (int r = 0; r < 4; r++) { const int ar0 = 4 * r + lk, ar1 = 16 + ar0; qr0[r] = ar0 / go; or0[r] = ar0 - qr0[r] * go; qr1[r] = ar1 / go; or1[r] = ar1 - qr1[r] * go; }
+	// per block variable v: output, LDS offset of its channel's rows, and the offsets of this lane's two columns in that channel
+	// (-1: the column belongs to another output)
+	int v_out[CG], v_c0[CG], v_c1[CG];
+#pragma unroll
+	for (int v = 0; v < CG; v++) {
+		const int ov = (int)((upack >> (8 * v + 4)) & 15u), rv2 = (int)((upack >> (8 * v)) & 15u), ch = chrow[rv2];
+		v_out[v] = ov;
+		v_c0[v] = (va0 && ov == oa0) ? ch + qa0 * P : -1;
+		v_c1[v] = (va1 && ov == oa1) ? ch + qa1 * P : -1;
+	}
 	for (int color = 0; color < cover; color++) {
 		const int ntc = (nint - color + cover - 1) / cover;   // intervals of this colour
 		for (int w = wave; w < ngp * ntc; w += NW) {
@@ -391,21 +405,24 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 			for (int s = 0; s < ksteps; s++) {
 				const int kk = 4 * s + lk;
 				const bool kvd = kk < kdim;
-				const int bi = kvd ? kk / cg : 0, u = kvd ? kk - bi * cg : 0, bp = bp0 + bi;
-				const int ou = (int)((upack >> (8 * u + 4)) & 15u), ru = (int)((upack >> (8 * u)) & 15u);
-				const double *rvu = rowv + NWT_IDX(chrow[ru] + bp, D.row_total, "rvu");
-				// A[a][kk] = Mst[kk][a]: the basis value of derivative ru at the breakpoint, if column a belongs to output ou
-				const double A0 = (kvd && va0 && oa0 == ou) ? rvu[qa0 * P] : 0.0;
-				const double A1 = (kvd && va1 && oa1 == ou) ? rvu[qa1 * P] : 0.0;
+				const int bi = kvd ? kk / CG : 0, u = kvd ? kk - bi * CG : 0, bp = bp0 + bi;
+				// A[a][kk] = Mst[kk][a]: the basis value of variable u's derivative at the breakpoint, if column a belongs to u's output
+				int ua0 = -1, ua1 = -1;
+#pragma unroll
+				for (int v = 0; v < CG; v++) { if (u == v) { ua0 = v_c0[v]; ua1 = v_c1[v]; } }
+				// (loads unconditional at a clamped offset, the value selected afterwards: no divergent branch around an LDS read)
+				const double a0v = rowv[NWT_IDX(max(ua0, 0) + bp, D.row_total, "rvu")], a1v = rowv[NWT_IDX(max(ua1, 0) + bp, D.row_total, "rvu")];
+				const double A0 = (kvd && ua0 >= 0) ? a0v : 0.0;
+				const double A1 = (kvd && ua1 >= 0) ? a1v : 0.0;
 				// B[kk][b] = V[kk][b] = sum_v B_i[u][v] Mst_i[v][b]
 				double B0 = 0.0, B1 = 0.0;
-				const double *Bi = wbuf + NWT_IDX((bi * cg + u) * cg, 216, "wbuf");
-				for (int v = 0; v < cg; v++) {
-					const int ov = (int)((upack >> (8 * v + 4)) & 15u), rv2 = (int)((upack >> (8 * v)) & 15u);
+				const double *Bi = wbuf + NWT_IDX((bi * CG + u) * CG, 216, "wbuf");
+#pragma unroll
+				for (int v = 0; v < CG; v++) {
 					const double bb = kvd ? Bi[v] : 0.0;
-					const double *rvv = rowv + NWT_IDX(chrow[rv2] + bp, D.row_total, "rvv");
-					if (va0 && ov == oa0) B0 += bb * rvv[qa0 * P];
-					if (va1 && ov == oa1) B1 += bb * rvv[qa1 * P];
+					const double r0 = rowv[NWT_IDX(max(v_c0[v], 0) + bp, D.row_total, "rvv")], r1 = rowv[NWT_IDX(max(v_c1[v], 0) + bp, D.row_total, "rvv")];
+					B0 += (v_c0[v] >= 0 ? bb : 0.0) * r0;
+					B1 += (v_c1[v] >= 0 ? bb : 0.0) * r1;
 				}
 				S00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, B0, S00, 0, 0, 0);
 				S10 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, B0, S10, 0, 0, 0);

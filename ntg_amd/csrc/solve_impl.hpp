@@ -1401,7 +1401,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[6] += now_ - tlast; tlast = now_; }
 			if (tid == 0) nwt_flag[0] = 0;
-			nwt_assemble<NT>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), sp.stamps == 4 ? tk : nullptr);   // ends with a full barrier
+			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), sp.stamps == 4 ? tk : nullptr);   // ends with a full barrier
 			NTG_STAMP(3);
 			if (wave < ngp) {
 				const int f = nwt_factor_wave((nwt_glb_dp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), curv ? 1 : 0);
