@@ -243,18 +243,22 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 #pragma unroll
 			for (int u = 0; u < 8; u++) {   // entries left of the diagonal block: columns R - hb + e < 16 J  <=>  e < hb - q
 				const int e = part + 4 * u, col = R - hb + e;
-				o[u] = (R < ng && e < hb - q && col >= 0) ? Lc[NWT_IDX((long long)R * ld + e, (long long)ng * ld, "fo")] : 0.0;
+				const bool ok = R < ng && e < hb - q && col >= 0;   // every load unconditional (clamped address, value selected): the wait for the
+				const double lv = Lc[NWT_IDX(ok ? (long long)R * ld + e : 0, (long long)ng * ld, "fo")];   // current block is then a counted vmcnt
+				o[u] = ok ? lv : 0.0;
 			}
 #pragma unroll
 			for (int c = 0; c < 16; c++) {   // row R of the diagonal block (every part loads it: the values are lane-uniform per q)
 				const int e = hb - (q - c);
-				lr[c] = (R < ng && c <= q && e >= 0) ? Lc[NWT_IDX((long long)R * ld + e, (long long)ng * ld, "fd")] : (c == q ? 1.0 : 0.0);
+				const bool ok = R < ng && c <= q && e >= 0;
+				const double lv = Lc[NWT_IDX(ok ? (long long)R * ld + e : 0, (long long)ng * ld, "fd")];
+				lr[c] = ok ? lv : (c == q ? 1.0 : 0.0);
 			}
 		};
 		load(0, off, lrow);
 		for (int J = 0; J < nbr; J++) {
 			double offn[8], lrown[16];
-			if (J + 1 < nbr) load(J + 1, offn, lrown);
+			load(min(J + 1, nbr - 1), offn, lrown);   // always (the last block loads itself again): no branch around the prefetch
 			const int R = 16 * J + q;
 			double acc = 0.0;
 #pragma unroll
@@ -270,12 +274,10 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 			}
 			if (part == 0) y[R] = r;
 			nwt_wave_sync();
-			if (J + 1 < nbr) {
 #pragma unroll
-				for (int u = 0; u < 8; u++) off[u] = offn[u];
+			for (int u = 0; u < 8; u++) off[u] = offn[u];
 #pragma unroll
-				for (int c = 0; c < 16; c++) lrow[c] = lrown[c];
-			}
+			for (int c = 0; c < 16; c++) lrow[c] = lrown[c];
 		}
 	}
 	// ---- backward: L' z = w ----
@@ -286,18 +288,22 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 #pragma unroll
 			for (int u = 0; u < 8; u++) {   // rows below the diagonal block: j = 16 J + 16 + part + 4 u,  j - i <= hb
 				const int j = 16 * J + 16 + part + 4 * u;
-				o[u] = (j < ng && j - i <= hb) ? Lc[NWT_IDX((long long)j * ld + (i - j + hb), (long long)ng * ld, "bo")] : 0.0;
+				const bool ok = j < ng && j - i <= hb;
+				const double lv = Lc[NWT_IDX(ok ? (long long)j * ld + (i - j + hb) : 0, (long long)ng * ld, "bo")];
+				o[u] = ok ? lv : 0.0;
 			}
 #pragma unroll
 			for (int c = 0; c < 16; c++) {   // column q of the diagonal block: L[16 J + c][16 J + q], c >= q
 				const int j = 16 * J + c, e = hb - (c - q);
-				lc[c] = (j < ng && c >= q && e >= 0) ? Lc[NWT_IDX((long long)j * ld + e, (long long)ng * ld, "bd")] : (c == q ? 1.0 : 0.0);
+				const bool ok = j < ng && c >= q && e >= 0;
+				const double lv = Lc[NWT_IDX(ok ? (long long)j * ld + e : 0, (long long)ng * ld, "bd")];
+				lc[c] = ok ? lv : (c == q ? 1.0 : 0.0);
 			}
 		};
 		load(nbr - 1, off, lcol);
 		for (int J = nbr - 1; J >= 0; J--) {
 			double offn[8], lcoln[16];
-			if (J > 0) load(J - 1, offn, lcoln);
+			load(max(J - 1, 0), offn, lcoln);
 			const int i = 16 * J + q;
 			double acc = 0.0;
 #pragma unroll
@@ -313,12 +319,10 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 			}
 			if (part == 0) y[i] = r;
 			nwt_wave_sync();
-			if (J > 0) {
 #pragma unroll
-				for (int u = 0; u < 8; u++) off[u] = offn[u];
+			for (int u = 0; u < 8; u++) off[u] = offn[u];
 #pragma unroll
-				for (int c = 0; c < 16; c++) lcol[c] = lcoln[c];
-			}
+			for (int c = 0; c < 16; c++) lcol[c] = lcoln[c];
 		}
 	}
 }
