@@ -163,27 +163,44 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 #pragma unroll
 		for (int r = 0; r < 4; r++) E[r] = (4 * r + lk == li) ? 1.0 : 0.0;
 		double mypiv = 1.0;   // pivot of this lane's column
+		// Two pivots per LDS round trip: columns j and j + 1 go to LDS together; every lane then redoes the step-j update of column j + 1
+		// (its own rows, the pivot entry and the entry of its own column) in registers -- the same operations in the same order as two
+		// single-pivot steps, so the results are bit-identical -- and applies both column operations.  (The round trip, write -> wait ->
+		// read -> wait, is about half of a single-pivot step's latency.)
 #pragma unroll
-		for (int j = 0; j < 16; j++) {
-			if (li == j) {   // column j: rows 4 r + lk of the two tiles
+		for (int j = 0; j < 16; j += 2) {
+			if (li == j || li == j + 1) {   // columns j, j + 1: rows 4 r + lk of the two tiles
+				const int o = (li - j) * 32;
 #pragma unroll
-				for (int r = 0; r < 4; r++) { colbuf[4 * lk + r] = T00[r]; colbuf[16 + 4 * lk + r] = E[r]; }
+				for (int r = 0; r < 4; r++) { colbuf[o + 4 * lk + r] = T00[r]; colbuf[o + 16 + 4 * lk + r] = E[r]; }
 			}
 			nwt_wave_sync();
-			double piv = colbuf[(j & 3) * 4 + (j >> 2)];
-			const double ckj = colbuf[(li & 3) * 4 + (li >> 2)];   // entry (row li, column j) of the diagonal tile
-			double c0[4], cE[4];
+			double piv0 = colbuf[(j & 3) * 4 + (j >> 2)];                       // (j, j)
+			const double b = colbuf[((j + 1) & 3) * 4 + ((j + 1) >> 2)];      // (j + 1, j)
+			const double d = colbuf[32 + ((j + 1) & 3) * 4 + ((j + 1) >> 2)]; // (j + 1, j + 1) before step j
+			const double ck0 = colbuf[(li & 3) * 4 + (li >> 2)];               // (row li, column j)
+			const double ck1 = colbuf[32 + (li & 3) * 4 + (li >> 2)];          // (row li, column j + 1) before step j
+			double c0[4], cE0[4], c1[4], cE1[4];
 #pragma unroll
-			for (int r = 0; r < 4; r++) { c0[r] = colbuf[4 * lk + r]; cE[r] = colbuf[16 + 4 * lk + r]; }
-			if (!(piv > 0.0)) {
-				fail++;
-				piv = strict ? 1.0 : 1e-30;
+			for (int r = 0; r < 4; r++) { c0[r] = colbuf[4 * lk + r]; cE0[r] = colbuf[16 + 4 * lk + r]; c1[r] = colbuf[32 + 4 * lk + r]; cE1[r] = colbuf[48 + 4 * lk + r]; }
+			if (!(piv0 > 0.0)) { fail++; piv0 = strict ? 1.0 : 1e-30; }
+			const double ia = nwt_rcp(piv0);
+			const double mj1 = -b * ia;                     // step j's multiplier of column j + 1
+			double piv1 = fma(b, mj1, d);                   // (j + 1, j + 1) after step j
+			const double ck1n = fma(ck0, mj1, ck1);         // (row li, column j + 1) after step j
+#pragma unroll
+			for (int r = 0; r < 4; r++) { c1[r] = fma(c0[r], mj1, c1[r]); cE1[r] = fma(cE0[r], mj1, cE1[r]); }
+			if (!(piv1 > 0.0)) { fail++; piv1 = strict ? 1.0 : 1e-30; }
+			const double m0 = li > j ? -ck0 * ia : 0.0;
+			const double m1 = li > j + 1 ? -ck1n * nwt_rcp(piv1) : 0.0;
+			if (li == j) mypiv = piv0;
+			if (li == j + 1) mypiv = piv1;
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				T00[r] = fma(c1[r], m1, fma(c0[r], m0, T00[r]));
+				E[r] = fma(cE1[r], m1, fma(cE0[r], m0, E[r]));
 			}
-			const double m = li > j ? -ckj * nwt_rcp(piv) : 0.0;
-			if (li == j) mypiv = piv;
-#pragma unroll
-			for (int r = 0; r < 4; r++) { T00[r] = fma(c0[r], m, T00[r]); E[r] = fma(cE[r], m, E[r]); }
-			nwt_wave_sync();   // the column is consumed before the next one overwrites it
+			nwt_wave_sync();   // the columns are consumed before the next pair overwrites them
 		}
 		const double dinv = nwt_rsqrt(mypiv);
 #pragma unroll
