@@ -22,6 +22,10 @@
 #include "ntg_dev.hpp"
 
 #define NWT_PSTRIDE 17   // LDS row stride (doubles) of the 48 x 16 panel
+#ifndef NWT_PIVOTS
+#define NWT_PIVOTS 2     // pivots per LDS round trip of the factorisation's sweep (1, 2 or 4; 4 is no faster standalone and 15-30 % slower
+                         // inside the solve kernels, whose instances compile the routine for at most 256 registers)
+#endif
 // LDS scratch of the out-of-line routines is passed as an address-space-3 pointer: through a generic `double *` the compiler has to
 // emit FLAT loads and stores (it cannot see across the call that the pointer is LDS), which go through the vector-memory path -- every
 // pivot step then waited on vmcnt(0), i.e. also on the prefetched band rows and the stores of the previous block column (measured:
@@ -135,7 +139,7 @@ __device__ __forceinline__ void nwt_to_operand(const nwt_d4 &T, nwt_lds_dp xb, i
 __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__ Kc, int ng, int hb, nwt_lds_dp panel, int strict)
 {
 	const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
-	nwt_lds_dp colbuf = panel, xbuf = panel + 64;   // 32 doubles; one tile of 16 x NWT_PSTRIDE
+	nwt_lds_dp colbuf = panel, xbuf = panel + 32 * NWT_PIVOTS;   // NWT_PIVOTS columns of both tiles; one tile of 16 x NWT_PSTRIDE
 	int fail = 0;
 	// Addressing of the window relative to block column J: element (tile row a, register r) of a tile whose columns are block J + b sits
 	// at  Kc[16 J ld + off],  off = (16 a + 4 r + lk) (ld - 1) + 16 b + li + hb  -- a lane constant; whether it lies inside the band
@@ -163,44 +167,52 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 #pragma unroll
 		for (int r = 0; r < 4; r++) E[r] = (4 * r + lk == li) ? 1.0 : 0.0;
 		double mypiv = 1.0;   // pivot of this lane's column
-		// Two pivots per LDS round trip: columns j and j + 1 go to LDS together; every lane then redoes the step-j update of column j + 1
-		// (its own rows, the pivot entry and the entry of its own column) in registers -- the same operations in the same order as two
-		// single-pivot steps, so the results are bit-identical -- and applies both column operations.  (The round trip, write -> wait ->
-		// read -> wait, is about half of a single-pivot step's latency.)
+		// NP pivots per LDS round trip: columns j .. j + NP - 1 go to LDS together; every lane then redoes, in registers, what the earlier
+		// steps of the group do to the later columns of the group (its own rows of both tiles, the entries of the NP x NP pivot block, the
+		// entry of its own column) -- the same operations in the same order as NP single-pivot steps, so the results are bit-identical --
+		// and applies the NP column operations.  (The round trip, write -> wait -> read -> wait, is about half of a single-pivot step's
+		// latency: 12.0 k ticks per block column with one pivot per trip, 10.6 k with two or four.)
+		constexpr int NP = NWT_PIVOTS;
 #pragma unroll
-		for (int j = 0; j < 16; j += 2) {
-			if (li == j || li == j + 1) {   // columns j, j + 1: rows 4 r + lk of the two tiles
+		for (int j = 0; j < 16; j += NP) {
+			if (li >= j && li < j + NP) {   // columns j .. j + NP - 1: rows 4 r + lk of the two tiles
 				const int o = (li - j) * 32;
 #pragma unroll
 				for (int r = 0; r < 4; r++) { colbuf[o + 4 * lk + r] = T00[r]; colbuf[o + 16 + 4 * lk + r] = E[r]; }
 			}
 			nwt_wave_sync();
-			double piv0 = colbuf[(j & 3) * 4 + (j >> 2)];                       // (j, j)
-			const double b = colbuf[((j + 1) & 3) * 4 + ((j + 1) >> 2)];      // (j + 1, j)
-			const double d = colbuf[32 + ((j + 1) & 3) * 4 + ((j + 1) >> 2)]; // (j + 1, j + 1) before step j
-			const double ck0 = colbuf[(li & 3) * 4 + (li >> 2)];               // (row li, column j)
-			const double ck1 = colbuf[32 + (li & 3) * 4 + (li >> 2)];          // (row li, column j + 1) before step j
-			double c0[4], cE0[4], c1[4], cE1[4];
+			double blk[NP][NP], ck[NP], c[NP][4], cE[NP][4];   // blk[p][q]: (row j + q, column j + p), q >= p;  ck[p]: (row li, column j + p)
 #pragma unroll
-			for (int r = 0; r < 4; r++) { c0[r] = colbuf[4 * lk + r]; cE0[r] = colbuf[16 + 4 * lk + r]; c1[r] = colbuf[32 + 4 * lk + r]; cE1[r] = colbuf[48 + 4 * lk + r]; }
-			if (!(piv0 > 0.0)) { fail++; piv0 = strict ? 1.0 : 1e-30; }
-			const double ia = nwt_rcp(piv0);
-			const double mj1 = -b * ia;                     // step j's multiplier of column j + 1
-			double piv1 = fma(b, mj1, d);                   // (j + 1, j + 1) after step j
-			const double ck1n = fma(ck0, mj1, ck1);         // (row li, column j + 1) after step j
+			for (int p = 0; p < NP; p++) {
 #pragma unroll
-			for (int r = 0; r < 4; r++) { c1[r] = fma(c0[r], mj1, c1[r]); cE1[r] = fma(cE0[r], mj1, cE1[r]); }
-			if (!(piv1 > 0.0)) { fail++; piv1 = strict ? 1.0 : 1e-30; }
-			const double m0 = li > j ? -ck0 * ia : 0.0;
-			const double m1 = li > j + 1 ? -ck1n * nwt_rcp(piv1) : 0.0;
-			if (li == j) mypiv = piv0;
-			if (li == j + 1) mypiv = piv1;
+				for (int q = p; q < NP; q++) blk[p][q] = colbuf[32 * p + ((j + q) & 3) * 4 + ((j + q) >> 2)];
+				ck[p] = colbuf[32 * p + (li & 3) * 4 + (li >> 2)];
 #pragma unroll
-			for (int r = 0; r < 4; r++) {
-				T00[r] = fma(c1[r], m1, fma(c0[r], m0, T00[r]));
-				E[r] = fma(cE1[r], m1, fma(cE0[r], m0, E[r]));
+				for (int r = 0; r < 4; r++) { c[p][r] = colbuf[32 * p + 4 * lk + r]; cE[p][r] = colbuf[32 * p + 16 + 4 * lk + r]; }
 			}
-			nwt_wave_sync();   // the columns are consumed before the next pair overwrites them
+			double mown[NP];
+#pragma unroll
+			for (int p = 0; p < NP; p++) {
+				double piv = blk[p][p];
+				if (!(piv > 0.0)) { fail++; piv = strict ? 1.0 : 1e-30; }
+				const double ip = nwt_rcp(piv);
+				if (li == j + p) mypiv = piv;
+				mown[p] = li > j + p ? -ck[p] * ip : 0.0;
+#pragma unroll
+				for (int pp = p + 1; pp < NP; pp++) {   // step j + p applied to the later columns of the group
+					const double mm = -blk[p][pp] * ip;
+#pragma unroll
+					for (int q = pp; q < NP; q++) blk[pp][q] = fma(blk[p][q], mm, blk[pp][q]);
+					ck[pp] = fma(ck[p], mm, ck[pp]);
+#pragma unroll
+					for (int r = 0; r < 4; r++) { c[pp][r] = fma(c[p][r], mm, c[pp][r]); cE[pp][r] = fma(cE[p][r], mm, cE[pp][r]); }
+				}
+			}
+#pragma unroll
+			for (int p = 0; p < NP; p++)
+#pragma unroll
+				for (int r = 0; r < 4; r++) { T00[r] = fma(c[p][r], mown[p], T00[r]); E[r] = fma(cE[p][r], mown[p], E[r]); }
+			nwt_wave_sync();   // the columns are consumed before the next group overwrites them
 		}
 		const double dinv = nwt_rsqrt(mypiv);
 #pragma unroll
