@@ -136,6 +136,17 @@ __device__ __forceinline__ void nwt_to_operand(const nwt_d4 &T, nwt_lds_dp xb, i
 	for (int s = 0; s < 4; s++) op[s] = xb[li * NWT_PSTRIDE + 4 * s + lk];   // X[l%16][4 s + l/16]: A[i][k] as well as B[k][j] = X'[k][j]
 	nwt_wave_sync();
 }
+// two tiles in one LDS round trip (xb: two tiles of 16 x NWT_PSTRIDE)
+__device__ __forceinline__ void nwt_to_operand2(const nwt_d4 &Ta, const nwt_d4 &Tb, nwt_lds_dp xb, int li, int lk, double (&opa)[4], double (&opb)[4])
+{
+	nwt_lds_dp xb2 = xb + 16 * NWT_PSTRIDE;
+#pragma unroll
+	for (int r = 0; r < 4; r++) { xb[(4 * r + lk) * NWT_PSTRIDE + li] = Ta[r]; xb2[(4 * r + lk) * NWT_PSTRIDE + li] = Tb[r]; }
+	nwt_wave_sync();
+#pragma unroll
+	for (int s = 0; s < 4; s++) { opa[s] = xb[li * NWT_PSTRIDE + 4 * s + lk]; opb[s] = xb2[li * NWT_PSTRIDE + 4 * s + lk]; }
+	nwt_wave_sync();
+}
 __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__ Kc, int ng, int hb, nwt_lds_dp panel, int strict)
 {
 	const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
@@ -220,8 +231,7 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 		// sub-diagonal tiles: X = T L00^-T = T E  (E[k][j] in the accumulator layout = operand B[k = 4 s + l/16][j = l%16])
 		{
 			double a1[4], a2[4];
-			nwt_to_operand(T10, xbuf, li, lk, a1);
-			nwt_to_operand(T20, xbuf, li, lk, a2);
+			nwt_to_operand2(T10, T20, xbuf, li, lk, a1, a2);
 			nwt_d4 X1 = {0.0, 0.0, 0.0, 0.0}, X2 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
@@ -245,8 +255,7 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 		// trailing update of the window
 		{
 			double x1[4], x2[4];
-			nwt_to_operand(T10, xbuf, li, lk, x1);
-			nwt_to_operand(T20, xbuf, li, lk, x2);
+			nwt_to_operand2(T10, T20, xbuf, li, lk, x1, x2);
 #pragma unroll
 			for (int s = 0; s < 4; s++) {
 				T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s], x1[s], T11, 0, 0, 0);
