@@ -83,7 +83,10 @@ typedef struct {
 	double ls_mu, ls_eta; /* 1e-4, 0.9 (NPSOL "line search tolerance") */
 	int ls_maxfev;      /* 20 */
 	int hessian;        /* 0 identity cold start (NPSOL), 1 collocation preconditioner (ignored when the cost model is
-	                     * singular on the null space of the equality rows, e.g. a plan without equality rows) */
+	                     * singular on the null space of the equality rows, e.g. a plan without equality rows),
+	                     * 2 structured Newton step for nonlinear trajectory rows: band model of the augmented Lagrangian's Hessian,
+	                     *   assembled and factored on the matrix cores at every major (families with second-order blocks: obstacle,
+	                     *   quadrotor, manipulator; acts as 1 where it does not apply) -- the mode meant for BASELINE's configs D and E */
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
 	int block_threads;  /* 0 = auto (128/256/512) */
 	int qn_memory;      /* quasi-Newton updates kept before the approximation restarts from W0; <= 0: 256 */
