@@ -375,7 +375,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x,
 		L.dfz = p; L.nwt_y = p; p = align16(p + dfz_bytes);
 	}
 	L.fvals = p; p = align16(p + D.P * 8);
-	L.red = p; p = align16(p + 16 * (nthreads / 64 + 1) * 8);
+	L.red = p; p = align16(p + (32 * (nthreads / 64) + 2) * 8);   // two halves of 16 values x waves (block_sum) + the Newton mode's flag words
 	L.dfi = p; p = align16(p + (D.nz + 1) * 8);
 	L.dff = p; p = align16(p + (D.nz + 1) * 8);
 	L.vecs = p; p = align16(p + (nvec * npad + 2 * D.nclin + 2) * 8);

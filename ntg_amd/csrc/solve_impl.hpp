@@ -121,8 +121,11 @@ __device__ __forceinline__ double wave_sum_many(const double *v, int lane)   // 
 	return t;
 }
 
-template <int NT, int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double *red)
+// The cross-wave scratch is double buffered (S.red_sel alternates between two halves): a buffer is rewritten two calls after it was
+// read, and the barrier of the call in between already orders those, so ONE barrier per reduction is enough (a single buffer needs a
+// second one in front of the writes).
+template <int NT, int K, class SM>
+__device__ __forceinline__ void block_sum(double (&v)[K], const SM &S)
 {
 	constexpr int NW = NT / 64;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -131,7 +134,8 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 #pragma unroll
 		for (int k = 0; k < 16; k++) w[k] = k < K ? v[k] : 0.0;
 		const double t = wave_sum_many<K>(w, lane);   // lane L: wave total of value L & 15
-		lds_sync(); // red[] may still be read by the previous call
+		double *red = S.red + (S.red_sel ? 16 * NW : 0);
+		S.red_sel ^= 1;
 		if (lane < K) red[lane * NW + wave] = t;
 		lds_sync();
 #pragma unroll
@@ -146,7 +150,8 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red)
 #pragma unroll
 	for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
 	if (NW == 1) return;
-	lds_sync(); // red[] may still be read by the previous call
+	double *red = S.red + (S.red_sel ? 16 * NW : 0);
+	S.red_sel ^= 1;
 	if (lane == 0) {
 #pragma unroll
 		for (int k = 0; k < K; k++) red[k * NW + wave] = v[k];
@@ -188,6 +193,7 @@ struct Smem {
 	int *oinfo, *tavrow, *tcomp;   // per-output scalars, flag->row map, flag->compact trajectory-constraint index, in LDS
 	short *q_idx; int *q_col; double *q_val;
 	int tav_rows;   // SmemLayout::tav_rows
+	mutable int red_sel;   // which half of the reduction scratch the next block_sum writes (wave uniform)
 	__device__ __forceinline__ Smem(char *base, const SmemLayout &L, const NtgDims &D, const NtgTables &T, int b = 0)
 	{
 		rowv = (double *)(base + L.rowv); colp = (unsigned int *)(base + L.colp);
@@ -209,7 +215,7 @@ struct Smem {
 		}
 		oinfo = (int *)(base + L.oinfo); tavrow = (int *)(base + L.tavrow); tcomp = (int *)(base + L.tcomp);
 		q_idx = (short *)(base + L.q_idx); q_col = (int *)(base + L.q_col); q_val = (double *)(base + L.q_val);
-		tav_rows = L.tav_rows;
+		tav_rows = L.tav_rows; red_sel = 0;
 	}
 };
 
@@ -714,7 +720,7 @@ __device__ __forceinline__ double cost_phase2(const NtgDims &D, const Smem &S, d
 		defer[0] = acc[0]; defer[1] = acc[1]; defer[2] = acc[2]; defer[3] = acc[3];
 		return 0.0;
 	}
-	block_sum<NT, 4>(acc, S.red);
+	block_sum<NT, 4>(acc, S);
 	const double I = D.nicf ? S.dfi[nz] : 0.0, Ff = D.nfcf ? S.dff[nz] : 0.0;
 	*gnorm2 = acc[1];
 	const double Fp = I + acc[0] + Ff;                            // ntg.c:328
@@ -1144,7 +1150,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 #pragma unroll
 					for (int e = 0; e < EPT; e++) { acc[2 * g] += hs[g][e] * vv[e]; acc[2 * g + 1] += hu[g][e] * vv[e]; }
 				}
-				block_sum<NT, 2 * PG>(acc, S.red);
+				block_sum<NT, 2 * PG>(acc, S);
 #pragma unroll
 				for (int g = 0; g < PG; g++) {
 					const bool on = base + g < npairs;
@@ -1193,7 +1199,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 			for (int g = 0; g < G; g++)
 #pragma unroll
 				for (int e = 0; e < EPT; e++) { acc[2 * g] += hs[g][e] * vv[e]; acc[2 * g + 1] += hu[g][e] * vv[e]; }
-			block_sum<NT, 2 * G>(acc, S.red);
+			block_sum<NT, 2 * G>(acc, S);
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				if (g < cnt) {
@@ -1224,7 +1230,7 @@ __device__ __forceinline__ void apply_history(const NtgDims &D, const Smem &S, c
 				}
 			}
 		}
-		block_sum<NT, 8>(acc, S.red);
+		block_sum<NT, 8>(acc, S);
 		for (int c = tid; c < n; c += NT) {
 			double tt = t[c];
 #pragma unroll
@@ -1274,7 +1280,7 @@ __device__ __forceinline__ void apply_dform(const NtgDims &D, const Smem &S, con
 #pragma unroll
 			for (int e = 0; e < EPT; e++) acc[g] += h[g][e] * vv[e];
 		}
-		block_sum<NT, G>(acc, S.red);
+		block_sum<NT, G>(acc, S);
 #pragma unroll
 		for (int g = 0; g < G; g++) {
 			const int i = base - 1 + g;   // link i joins vector i (left) and vector i+1 = base+g (right)
@@ -1373,7 +1379,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	int nwt_bad = 0;              // diagnostic: non-positive pivots replaced in Gauss-Newton factorisations (wave 0's count)
 	int nwt_nfact = 0, nwt_nfail = 0, nwt_napply = 0;   // diagnostic (sp.stamps == 3): factorisations, of which not positive definite, solves
 	bool phase0 = NWT && alprob;  // the pass on the objective alone is still running
-	int *nwt_flag = (int *)(smem_raw + L.red) + 2 * 16 * (NT / 64 + 1) - 2;   // last word pair of the reduction scratch: "not positive definite"
+	int *nwt_flag = (int *)(smem_raw + L.red) + 2 * (32 * (NT / 64) + 2) - 2;   // last word pair of the reduction scratch: "not positive definite"
 	// K = model at the trial point buffer `xs` (must be the iterate x; needs the multiplier estimates al_t of the evaluation
 	// at x), factored; then out = W v.  allow_curv = false: Gauss-Newton terms only.
 	auto nwt_refresh = [&](const double *xs, bool allow_curv) {
@@ -1449,7 +1455,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			const bool ineq = D.nI > 0 && T.linflag[s] != 0;
 			if (ineq ? !(l <= u) : l != u) bad[0] += 1.0;
 		}
-		block_sum<NT, 1>(bad, S.red);
+		block_sum<NT, 1>(bad, S);
 		if (bad[0] != 0.0 || (ncn > 0 && !HASCON) || (D.nI > 0 && !LIN) || (nal > 0 && sp.fixed_iters)) inform = 9;
 	}
 	double F = 0.0, Fp = 0.0, gn2 = 0.0, rv2 = 0.0, alpha = 0.0, pnorm = 0.0;
@@ -1514,10 +1520,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (state != ST_FINAL && state != ST_REEVAL) {
 				project<NT, BIG>(D, S, sg, sgpt, tmp, sd, &part[4]);
 				NTG_STAMP(2);
-				block_sum<NT, 5>(part, S.red);
+				block_sum<NT, 5>(part, S);
 			} else {
 				double p4[4] = {part[0], part[1], part[2], part[3]};
-				block_sum<NT, 4>(p4, S.red);
+				block_sum<NT, 4>(p4, S);
 				part[0] = p4[0]; part[1] = p4[1]; part[2] = p4[2]; part[3] = p4[3];
 			}
 			const double Fpn = (D.nicf ? S.dfi[D.nz] : 0.0) + part[0] + (D.nfcf ? S.dff[D.nz] : 0.0);   // ntg.c:328
@@ -1552,7 +1558,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo);
 				r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
 				for_vec<NT>(n, [&](int c) { r4[0] += sgp[c] * sd[c]; r4[1] += sd[c] * sd[c]; r4[2] += sx[c] * sx[c]; r4[3] += sgp[c] * sgp[c]; });
-				block_sum<NT, 4>(r4, S.red);
+				block_sum<NT, 4>(r4, S);
 				NTG_STAMP(4);
 				new_major = true;
 			} else {
@@ -1582,7 +1588,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo);
 						double r2[2] = {0, 0};
 						for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
-						block_sum<NT, 2>(r2, S.red);
+						block_sum<NT, 2>(r2, S);
 						r4[0] = r2[0]; r4[1] = r2[1];
 						new_major = true;
 					} else {
@@ -1607,7 +1613,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						// 2.7 (config D) refreshes per pass.
 						double r2[2] = {0, 0};
 						for_vec<NT>(n, [&](int c) { const double xn = sx[c], gq = sgpt[c]; r2[0] += xn * xn; r2[1] += gq * gq; });
-						block_sum<NT, 2>(r2, S.red);
+						block_sum<NT, 2>(r2, S);
 						conv_now = alpha * pnorm <= sri * (1.0 + sqrt(r2[0])) && sqrt(r2[1]) <= sri * (1.0 + fmax(1.0 + fabs(Fn), sqrt(gn2n)));
 						if (conv_now) {
 							for_vec<NT>(n, [&](int c) { sgp[c] = sgpt[c]; });
@@ -1635,7 +1641,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						const double s = sg[c], y = sgpt[c] - sgp[c], u = st[c] - sd[c], gpn = sgpt[c];
 						r6[0] += s * y; r6[1] += y * u; r6[2] += s * gpn; r6[3] += u * gpn; r6[4] += s * s; r6[5] += y * y;
 					});
-					block_sum<NT, 6>(r6, S.red);
+					block_sum<NT, 6>(r6, S);
 					const bool upd = !NWT && r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
 					const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
 					r4[0] = r4[1] = r4[2] = r4[3] = 0.0;
@@ -1671,7 +1677,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						__threadfence_block();
 						__syncthreads();   // rho/c2 of the new pair go through HBM/L2: needs the full barrier (vmcnt(0))
 					}
-					block_sum<NT, 4>(r4, S.red);
+					block_sum<NT, 4>(r4, S);
 					F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n;
 					iter++;
 					if (!sp.fixed_iters && alpha * pnorm <= sri * (1.0 + sqrt(r4[2])) &&
@@ -1692,7 +1698,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						project<NT, BIG>(D, S, sd, sg, tmp);
 						double r2[2] = {0, 0};
 						for_vec<NT>(n, [&](int c) { const double dn = sg[c]; sd[c] = dn; r2[0] += sgp[c] * dn; r2[1] += dn * dn; });
-						block_sum<NT, 2>(r2, S.red);
+						block_sum<NT, 2>(r2, S);
 						r4[0] = r2[0]; r4[1] = r2[1];
 					}
 					double dphi0 = -r4[0];
@@ -1706,7 +1712,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 							else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgp, sd, sxt, S.oinfo);
 							double r2[2] = {0, 0};
 							for_vec<NT>(n, [&](int c) { r2[0] += sgp[c] * sd[c]; r2[1] += sd[c] * sd[c]; });
-							block_sum<NT, 2>(r2, S.red);
+							block_sum<NT, 2>(r2, S);
 							r4[0] = r2[0]; r4[1] = r2[1];
 							dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
 						}
