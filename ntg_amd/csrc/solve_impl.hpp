@@ -23,9 +23,6 @@
 #ifndef NTG_HIST_PIPE
 #define NTG_HIST_PIPE 2   // pairs per round of the double-buffered sweep (pair scalars in LDS, 3 coefficients per lane); 0 = off
 #endif
-#ifndef NTG_IEV
-#define NTG_IEV 1
-#endif
 #ifndef NTG_DFORM
 #define NTG_DFORM 1
 #endif
@@ -758,98 +755,6 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	return F;
 }
 
-// The evaluation by knot interval (eval_interval_kernel's formulation, eval_fast.hpp) for the evaluation site INSIDE the solve: one lane
-// per (knot interval, output) of the workgroup's problem -- it reads the interval's K coefficients of its output once,
-// evaluates its <= 6 breakpoints from the channel rows already staged in LDS, keeps its share of the gradient in registers and joins it
-// with the previous interval's by one lane shuffle.  About a third of the wave-instructions of the breakpoint-lane pass plus gather
-// (which the solve kernel, issue bound, feels directly).  For cost-only plans whose cost is a sum over the outputs of one derivative channel
-// (kincar), order K even with multiplicity K / 2: the waves split the outputs (IevSplit), at most 64 / nint outputs each.  Leaves the gradient
-// in sg and the lane partials of the quadrature (part[0]) and of |g|^2 (part[1]).
-// waves that share the evaluation: every wave takes whole outputs (the lane shuffles that join neighbouring intervals stay inside a wave)
-template <int NOUT, int NT>
-struct IevSplit {
-	static constexpr int NW = NT / 64, NO = NOUT > 0 ? NOUT : 1;
-	static constexpr int EW = (NO % NW == 0) ? NW : ((NO % 2 == 0 && NW >= 2) ? 2 : 1);   // evaluating waves
-	static constexpr int OW = NO / EW;                                                      // outputs per wave
-};
-template <int FAM, int NOUT, int K, int CHM, int NT>
-__device__ __forceinline__ bool iev_applies(const NtgDims &D)
-{
-	using Fam = Family<FAM>;
-	if (!(NOUT > 0 && K > 0 && (K & 1) == 0 && CHM != 0 && chm_count(CHM) == 1 && Fam::PER_OUTPUT_COST)) return false;
-	return D.ig_n > 0 && D.ig_n * IevSplit<NOUT, NT>::OW <= 64 && D.uniform && D.mult[0] == K / 2 && D.ncoef[0] == (K / 2) * (D.ig_n + 1) && !D.nicf && !D.nfcf &&
-	       D.nucf && D.ncnln == 0 && D.nI == 0 && D.tcost_mask == chm_full_mask(CHM, NOUT > 0 ? NOUT : 1, Fam::DM);
-}
-template <int FAM, int NOUT, int K, int CHM, int NT>
-__device__ __forceinline__ void eval_cost_intervals(const NtgDims &D, const Smem &S, const double *sx, double *sg, double (&part)[5])
-{
-	using Fam = Family<FAM>;
-	constexpr int DM = Fam::DM, EW = IevSplit<NOUT, NT>::EW, OW = IevSplit<NOUT, NT>::OW, SH = K / 2, SMAX = 6;
-	int rch = 0;
-#pragma unroll
-	for (int r = 0; r < DM; r++) if ((CHM >> r) & 1) rch = r;   // the one derivative channel of the cost
-	const int P = D.P, nint = D.ig_n, nco = SH * nint + SH, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	lds_sync();   // sx complete
-	part[0] = 0.0; part[1] = 0.0; part[2] = 0.0; part[3] = 0.0;
-	if (wave < EW) {
-		const int LP = nint * OW;
-		const bool on = lane < LP;
-		const int rl = on ? lane : 0, t = rl / OW, o = wave * OW + (rl - t * OW);
-		const int i0 = D.igb[t], cnt = on ? D.igb[t + 1] - i0 : 0;
-		const double *brow = S.rowv + S.chrow[rch] + i0;   // basis value of local coefficient q at breakpoint i0 + s2: brow[q P + s2]
-		double xb[K], pg[K];
-#pragma unroll
-		for (int q = 0; q < K; q++) { xb[q] = sx[o * nco + SH * t + q]; pg[q] = 0.0; }
-		auto slot = [&](int s2) -> double {   // one breakpoint: flag, cost functor (this output's share), its share of the gradient; returns the cost value
-			const bool live = s2 < cnt;
-			double bb[K];
-#pragma unroll
-			for (int q = 0; q < K; q++) { const double v = brow[q * P + (live ? s2 : 0)]; bb[q] = live ? v : 0.0; }
-			double z[DM], df[DM], fval = 0.0, acc = 0.0;
-#pragma unroll
-			for (int e = 0; e < DM; e++) z[e] = 0.0;
-#pragma unroll
-			for (int q = 0; q < K; q++) acc += bb[q] * xb[q];
-			z[rch] = acc;
-			Fam::ucf(1, i0 + s2, z, fval, df);
-			const double wd = (live ? S.wts[i0 + s2] : 0.0) * df[rch];
-#pragma unroll
-			for (int q = 0; q < K; q++) pg[q] += wd * bb[q];
-			return live ? fval : 0.0;
-		};
-		auto dt_of = [&](int s2) -> double { const int i = i0 + s2; return (s2 < cnt && i < P - 1) ? S.bps[i + 1] - S.bps[i] : 0.0; };
-		// trapezoid rule (integrator.c:21-24): the term of a breakpoint needs the next cost value; across the interval boundary it comes
-		// from the lane of the next interval
-		double Fp = 0.0;
-		{
-			double fprev = slot(0), dtprev = dt_of(0);
-			double fnext = __shfl_down(fprev, OW, 64);
-			if (t == nint - 1) fnext = 0.0;
-#pragma unroll
-			for (int s2 = 1; s2 < SMAX; s2++) {   // (unrolled: inside the solve there are registers for the basis loads of all six slots in flight)
-				const double fval = slot(s2);
-				Fp += dtprev * ((s2 < cnt ? fval : fnext) + fprev) / 2;
-				fprev = fval; dtprev = dt_of(s2);
-			}
-			Fp += dtprev * (fnext + fprev) / 2;
-		}
-		// gradient: coefficient SH t + j (j < SH) = this interval's pg[j] + the previous interval's pg[SH + j]; the last interval also owns
-		// the coefficients SH t + SH + j
-		double g2 = 0.0;
-#pragma unroll
-		for (int j = 0; j < SH; j++) {
-			double up = __shfl_up(pg[SH + j], OW, 64);
-			if (t == 0) up = 0.0;
-			if (on) {
-				const double gv = pg[j] + up;
-				sg[o * nco + SH * t + j] = gv; g2 += gv * gv;
-				if (t == nint - 1) { const double gl = pg[SH + j]; sg[o * nco + SH * t + SH + j] = gl; g2 += gl * gl; }
-			}
-		}
-		if (on) { part[0] = Fp; part[1] = g2; }
-	}
-}
-
 // NPfuncon (ntg.c:337-371, constraints.c:36-195): residuals and banded Jacobian rows straight
 // to HBM.  Row order [initial; trajectory constraint-major x breakpoint; final].
 template <int FAM, int NOUT, int K, int NT>
@@ -1440,9 +1345,6 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	const double *hrc = L.hrc_n >= sp.memcap ? S.rho : nullptr;
 	// one vector per major (apply_dform): problems without augmented-Lagrangian passes (the direction is never re-projected), a memory that
 	// cannot fill up before the iteration limit, link scalars in LDS
-	// the evaluation by knot interval (eval_cost_intervals) for the plans it applies to
-	constexpr bool IEV_OK = !NWT && !BIG && NOUT > 0 && K > 0 && CHM != 0 && Family<FAM>::PER_OUTPUT_COST && NTG_IEV;
-	const bool iev = IEV_OK && iev_applies<FAM, NOUT, K, CHM, NT>(D);
 	constexpr bool DF_OK = !NWT && !BIG && EPT <= 4 && Family<FAM>::NNLIC + Family<FAM>::NNLTC + Family<FAM>::NNLFC == 0;
 	const bool dform = DF_OK && NTG_DFORM && D.nI == 0 && D.nC <= 3 * NT && hrc != nullptr && sp.memcap >= sp.itlim && L.hrc_n > sp.memcap;   // pair scalars (rho, c2): LDS for memories that fit, else with the pair in HBM
 	stage_tables<NT>(D, T, S, smem_raw, L, b);
@@ -1612,9 +1514,6 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			// The evaluation leaves its four sums (quadrature, |g|^2, penalty, violation) as per-lane partials; the
 			// projection pass adds the slope of the line search, and ONE workgroup reduction serves all five.
 			double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, gdummy;
-			bool ev_done = false;
-			if constexpr (IEV_OK) { if (iev) { eval_cost_intervals<FAM, NOUT, K, CHM, NT>(D, S, sxt, sg, part); ev_done = true; } }
-			if (!ev_done)
 			(void)eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gdummy, cm, al, nullptr, nullptr, (sp.stamps && !NWT) ? tk : nullptr,
 			                                                        LIN ? &lin : nullptr, CHM != 0, part);
 			NTG_STAMP(1);
