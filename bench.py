@@ -348,6 +348,20 @@ def main():
                 entry[mode] = e
                 del wL
             entry["value"] = entry["newton"]["value"]; entry["unit"] = "trajectories/s"; entry["value_mode"] = "newton"
+            # the same solve on the config's WHOLE batch on this one GPU: at 512 / 1024 problems (2 / 4 per CU) the launch ends when the
+            # slowest problems do (majors range from 3 to 41 / 104), a larger batch shows the per-problem cost
+            nbW = 4096
+            loWn, upWn = bnds(nbW)
+            loW = torch.tensor(loWn, device=dev); upW = torch.tensor(upWn, device=dev)
+            oW = api.default_opts(hessian=2)
+            wW = torch.empty(planL.workspace_bytes(nbW, oW), dtype=torch.uint8, device=dev)
+            xW = torch.ones((nbW, specL.nC), dtype=torch.float64, device=dev)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            ooW = planL.solve(loW, upW, xW, oW, work=wW)
+            torch.cuda.synchronize(); dtW = time.perf_counter() - t1
+            entry["newton_batch4096"] = {"value": nbW / dtW, "unit": "trajectories/s", "ms_per_batch": 1e3 * dtW,
+                                         "inform0_frac": float((ooW["inform"] == 0).float().mean().item()), "iters_mean": float(ooW["iters"].float().mean().item())}
+            del wW, xW, loW, upW
             res[key] = entry
             del planL
         # ---- funobj + funcon with banded Jacobian rows (the constraint-Jacobian assembly), configs D and E ----
