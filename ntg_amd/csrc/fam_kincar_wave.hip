@@ -1,0 +1,83 @@
+// fam_kincar_wave.hip -- instances of sqp_wave_kernel (solve_wave.hpp: one wavefront per problem) for the kincar shapes of
+// BASELINE.json: 2, 4 and 6 flat outputs, order 6, 20 knot intervals (configs B / C, two cars, config M).  Own translation unit
+// so that it compiles next to the other families.
+//   FAT   one wave per SIMD (512 registers): the chain of search directions lives in the accumulator registers and LDS; the
+//         instance of long chains -- the identity cold start (NPSOL's mode, the fixed-work benchmark)
+//   LEAN  several waves per SIMD, chain in LDS / HBM: the instance of short solves -- the collocation preconditioner
+//         (3 majors to convergence), receding-horizon re-solves
+#include "solve_wave.hpp"
+#include "plan.hpp"
+#include <cstdlib>
+
+using namespace ntgw;
+
+namespace {
+
+template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS>
+hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
+{
+	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, 20, NWV, MINW, NREG, NLDS, HESS>;
+	WaveArgs A;
+	A.batch = a.batch; A.cap = w.cap; A.lower = a.lo; A.upper = a.up; A.xio = a.x; A.objective = a.obj; A.inform = a.inf; A.iters = a.it;
+	A.nfev = a.nf; A.clambda = a.cl; A.hist = a.hist; A.counter = a.counter; A.hbm_slots = w.hbm_slots;
+	if (w.lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)w.lds);
+	hipError_t e = hipMemsetAsync(a.counter, 0, sizeof(unsigned int), a.st);
+	if (e != hipSuccess) return e;
+	hipLaunchKernelGGL(kfn, dim3(w.grid), dim3(64 * NWV), w.lds, a.st, D, T, sp, A);
+	return hipGetLastError();
+}
+
+// LDS bytes of a workgroup
+size_t wave_lds(const NtgDims &D, int nwv, int cap, int nlds, int epl)
+{
+	const size_t tab = (size_t)wave_tab_doubles<1, 6, 20>() * 8 + (size_t)((D.q_nt * D.q_w + 1) & ~1) * 8 + (size_t)((D.q_nt * D.q_w + 3) & ~3) * 4;
+	return tab + (size_t)nwv * wave_priv_doubles(D.nC, cap, nlds, epl) * 8;
+}
+
+constexpr int FAT_NLDS = 9, LEAN_NLDS = 2;
+
+}   // namespace
+
+// Does the wave kernel take this solve, and with what launch shape / workspace?  (plan.cpp sizes the workspace with it.)
+bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, int batch, int ncu, NtgWavePlan *w)
+{
+	if (getenv("NTG_AMD_NOWAVE")) return false;
+	if (D.family != NTG_FAM_KINCAR || !(D.nout == 2 || D.nout == 4 || D.nout == 6)) return false;
+	const int opl = D.nout == 2 ? 1 : 2;
+	if (!wave_match(D, T, sp, 4, 3, 6, opl, 20)) return false;
+	const int epl = opl * 3;
+	w->cap = std::min(sp.memcap, sp.itlim) + 4;
+	w->fat = (sp.hessian != 1 && !getenv("NTG_AMD_WAVE_LEAN")) ? 1 : 0;
+	w->nwv = 4;
+	if (w->fat) {
+		const int nreg = 252 / (2 * epl);
+		w->lds = wave_lds(D, 4, w->cap, FAT_NLDS, epl);
+		if (w->lds > 160 * 1024) w->fat = 0;
+		else {
+			w->hbm_slots = std::max(0, w->cap - nreg - FAT_NLDS);
+			w->grid = std::max(1, std::min((batch + 3) / 4, ncu));   // one workgroup per CU: four waves, one per SIMD
+		}
+	}
+	if (!w->fat) {
+		w->lds = wave_lds(D, 4, w->cap, LEAN_NLDS, epl);
+		if (w->lds > 160 * 1024) return false;
+		w->hbm_slots = std::max(0, w->cap - LEAN_NLDS);
+		const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / w->lds));
+		w->grid = std::max(1, std::min((batch + 3) / 4, ncu * wg_per_cu));
+	}
+	w->hist_doubles = (size_t)w->grid * w->nwv * w->hbm_slots * epl * 64;
+	return true;
+}
+
+hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
+{
+	if (!a.counter) return hipErrorInvalidValue;
+	if (w.fat) {
+		if (D.nout == 2) return launch_one<2, 1, 4, 1, 42, FAT_NLDS, false>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 4, 1, 21, FAT_NLDS, false>(D, T, sp, a, w);
+		return launch_one<6, 2, 4, 1, 21, FAT_NLDS, false>(D, T, sp, a, w);
+	}
+	if (D.nout == 2) return launch_one<2, 1, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
+	if (D.nout == 4) return launch_one<4, 2, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
+	return launch_one<6, 2, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
+}

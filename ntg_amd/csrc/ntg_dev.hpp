@@ -129,5 +129,6 @@ struct SolveParams {
 struct EvalArgs { int nt, grid, ncu, batch, mode; const double *x; double *f, *g, *c, *jb, *cj; hipStream_t st; };
 struct SqpArgs {
 	int nt, big, batch; const double *lo, *up; double *x, *obj; int *inf, *it, *nf; double *cl, *hist, *alw, *vecw, *nwtw; hipStream_t st;
+	unsigned int *counter;   // problem queue of the wave kernel (4 bytes inside the workspace)
 };
 

@@ -795,6 +795,24 @@ static size_t nwt_doubles(const NtgDims &D, int batch, const SolveParams &sp)
 	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg);
 }
 
+static int plan_ncu(const ntg_plan *p)
+{
+	if (p->ncu <= 0) {
+		hipDeviceProp_t prop;
+		p->ncu = (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+	}
+	return p->ncu;
+}
+
+// which solve kernel takes the batch: the wave kernel (one wavefront per problem) for the plans it covers, else sqp_kernel.
+// The answer depends on the options as ntg_batch_solve will see them (the preconditioner may turn out singular: hessian 1 -> 0).
+static bool wave_takes(const ntg_plan *p, const SolveParams &sp, int batch, NtgWavePlan *w)
+{
+	if (p->grid_batch) return false;
+	if (sp.hessian == 1 && !p->precond_ready) return false;   // decided after the preconditioner exists (its block form is part of the test)
+	return ntg_wave_plan(p->D, p->T, sp, batch, plan_ncu(p), w);
+}
+
 extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, const ntg_solve_opts *o)
 {
 	if (!p) return 0;
@@ -803,7 +821,19 @@ extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, con
 	SmemLayout L; int big;
 	solve_layout(p->D, nt, &L, &big, &sp);
 	const size_t npad = (size_t)((p->D.nC + 1) & ~1);
-	return (long long)((hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0) + nwt_doubles(p->D, batch, sp)) * 8 + 256);
+	size_t dbl = hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0) + nwt_doubles(p->D, batch, sp);
+	// the wave kernel's HBM tier of the direction chains (per resident wave, not per problem); sized for both of its instances
+	for (int h = 0; h < 2; h++) {
+		SolveParams s2 = sp; s2.hessian = h;
+		NtgWavePlan w;
+		if (!p->grid_batch && ntg_wave_plan(p->D, p->T, s2, batch, plan_ncu(p), &w)) dbl = std::max(dbl, w.hist_doubles);
+		else if (h == 1 && !p->grid_batch && !p->precond_ready) {
+			// the preconditioner is not built yet: assume the wave kernel will take the solve (same shape test without the block form)
+			NtgTables T2 = p->T; T2.n0b = (const double *)1; T2.n0b_n = p->D.ncoef[0];
+			if (ntg_wave_plan(p->D, T2, s2, batch, plan_ncu(p), &w)) dbl = std::max(dbl, w.hist_doubles);
+		}
+	}
+	return (long long)(dbl * 8 + 256);
 }
 
 extern "C" int ntg_batch_bounds(const ntg_plan *p, int batch, const double *d_lower, const double *d_upper,
@@ -874,7 +904,13 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	double *vecw = alw + al_doubles(p->D, batch);                     // [batch][5][npad] x, gp, gp+, d, g (BIG only)
 	double *nwtw = vecw + (big ? (size_t)batch * 5 * ((p->D.nC + 1) & ~1) : 0);   // structured Newton mode: bands and blocks
 	SqpArgs sa{nt, big, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev, d_clambda, (double *)d_work, alw,
-	           big ? vecw : nullptr, sp.hessian == 2 ? nwtw : nullptr, (hipStream_t)stream};
+	           big ? vecw : nullptr, sp.hessian == 2 ? nwtw : nullptr, (hipStream_t)stream,
+	           (unsigned int *)((char *)d_work + ((ntg_batch_workspace_bytes(p, batch, o) - 256) & ~(long long)7))};
+	NtgWavePlan wp;
+	if (wave_takes(p, sp, batch, &wp)) {   // one wavefront per problem
+		HIPCHK(ntg_launch_sqp_wave(p->D, p->T, sp, sa, wp));
+		return 0;
+	}
 	HIPCHK(ntg_launch_sqp(p->D, p->T, L, sp, sa));
 	return 0;
 }

@@ -7,6 +7,7 @@
 
 struct ntg_plan {
 	int device = 0;
+	mutable int ncu = 0;                        // compute units of the device (queried on first use)
 	NtgDims D;
 	NtgTables T;
 	bool lin_ok = true;
@@ -39,6 +40,10 @@ void ntg_plan_dense_A(const ntg_plan *p, double *A);
 SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x, int hrc_pairs = 0);
 hipError_t ntg_launch_eval(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a);
 hipError_t ntg_launch_sqp(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a);
+// one wavefront per problem (solve_wave.hpp, fam_kincar_wave.hip): does it take this solve, and its launch shape / HBM workspace
+struct NtgWavePlan { int fat, nwv, grid, cap, hbm_slots; size_t lds, hist_doubles; };
+bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, int batch, int ncu, NtgWavePlan *w);
+hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w);
 hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,
                             long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st);
 hipError_t ntg_launch_interp(const NtgDims &D, int batch, int ntimes, const double *x, const double *tblk, const int *toff,

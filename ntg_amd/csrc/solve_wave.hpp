@@ -1,0 +1,765 @@
+// solve_wave.hpp -- the npsol_ call (ntg.c:250) for the headline problem class with ONE WAVEFRONT PER PROBLEM.
+//
+// Class (same as eval_interval_kernel, eval_fast.hpp): one basis class, order K with multiplicity K/2, a running cost only whose
+// active variables are the derivative channels CHM of every output (kincar: z'', examples/kincar.c:105-117,133-137), linear
+// equality rows kept by projection (constraints.c:198-261), no nonlinear rows.  The iteration is DESIGN.md section 4a word for
+// word (oracle/sqp.c, sqp_kernel): feasibility step, projected gradient, strong-Wolfe line search, inverse BFGS kept as the
+// chain of search directions (section 4a.4 "direction form").
+//
+// Why a second kernel: sqp_kernel spreads one problem over a workgroup, so every dot product of the iteration is a DPP reduction,
+// an LDS hand-over and an s_barrier, and a problem holds 40 KB of LDS for vectors that are read across lanes.  Here a lane owns
+// S = K/2 consecutive coefficients of OPL outputs (lane = (output group, knot interval), nint + 1 lanes per group: 63 of 64 lanes for
+// 6 outputs on 20 intervals) and keeps its share of x, g_p, g_p+, d, t in registers:
+//   * Z = M C and the gradient need the neighbouring lane's coefficients only (an interval's K coefficients belong to lanes t and
+//     t + 1): one DPP wave shift each way, no LDS;
+//   * every reduction is a wave reduction (DPP butterfly + v_readlane): no barrier anywhere in the iteration;
+//   * the quasi-Newton chain d_0 .. d_k -- the bytes that bound sqp_kernel (16 GB per headline launch from HBM) -- stays ON CHIP:
+//     the kernel is compiled for one wave per SIMD and keeps NREG vectors in the accumulator half of the unified register file
+//     (v_accvgpr_write / _read, 252 of the 256 AGPRs), NLDS more in LDS, and only the tail of a long chain in HBM;
+//   * waves are persistent and take problems from an atomic queue (to-convergence batches have ragged iteration counts).
+// The read-only tables (per-interval basis values, trapezoid weights, the projector Q) are shared by the waves of a workgroup.
+#pragma once
+#include "solve_impl.hpp"
+
+namespace ntgw {
+
+template <int J, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+	if constexpr (J < N) { f(std::integral_constant<int, J>{}); static_for<J + 1, N>(f); }
+}
+
+// value of the previous / next lane of the wavefront (DPP wave_shr:1 / wave_shl:1; lane 0 / lane 63 receive 0)
+__device__ __forceinline__ double from_prev(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x138, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x138, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_next(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130, 0xf, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+
+// accumulator registers a[2 IDX], a[2 IDX + 1] as one double.  The kernel lists a0..a251 as clobbers once (which makes the kernel
+// descriptor allocate them); nothing else in the kernel uses AGPRs (no MFMA in the instances that use this tier, and the build
+// audits the ISA for compiler-generated v_accvgpr_* -- ntg_amd/build.py).
+template <int IDX>
+__device__ __forceinline__ void areg_write(double v)
+{
+	asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(__double2loint(v)), "v"(__double2hiint(v)), "i"(2 * IDX), "i"(2 * IDX + 1));
+}
+template <int IDX>
+__device__ __forceinline__ double areg_read()
+{
+	int lo, hi;
+	asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]" : "=v"(lo), "=v"(hi) : "i"(2 * IDX), "i"(2 * IDX + 1));
+	return __hiloint2double(hi, lo);
+}
+#define NTGW_C10(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
+#define NTGW_CLAIM_AGPRS()                                                                                                         \
+	asm volatile("" ::: NTGW_C10(), NTGW_C10(1), NTGW_C10(2), NTGW_C10(3), NTGW_C10(4), NTGW_C10(5), NTGW_C10(6), NTGW_C10(7),     \
+	             NTGW_C10(8), NTGW_C10(9), NTGW_C10(10), NTGW_C10(11), NTGW_C10(12), NTGW_C10(13), NTGW_C10(14), NTGW_C10(15),    \
+	             NTGW_C10(16), NTGW_C10(17), NTGW_C10(18), NTGW_C10(19), NTGW_C10(20), NTGW_C10(21), NTGW_C10(22), NTGW_C10(23),  \
+	             NTGW_C10(24), "a250", "a251")
+
+__device__ __forceinline__ double bcast(double v, int lane)
+{
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+	return __hiloint2double(hi, lo);
+}
+// sums of KV per-lane values over the wavefront, every lane receives all of them
+template <int KV>
+__device__ __forceinline__ void wave_sums(double (&v)[KV], int lane)
+{
+	if constexpr (KV < 4) {
+#pragma unroll
+		for (int k = 0; k < KV; k++) v[k] = wave_sum(v[k]);
+	} else {
+		double w[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) w[k] = k < KV ? v[k] : 0.0;
+		const double t = wave_sum_many<KV>(w, lane);   // lane L: total of value L & 15
+#pragma unroll
+		for (int k = 0; k < KV; k++) v[k] = bcast(t, k);
+	}
+}
+
+struct WaveArgs {
+	int batch, cap;   // problems; slots of the direction chain a wave may hold (registers + LDS + HBM)
+	const double *lower, *upper;
+	double *xio, *objective;
+	int *inform, *iters, *nfev;
+	double *clambda, *hist;   // hist: HBM tier of the chain, [wave][slot - on-chip slots][EPL][64]
+	unsigned int *counter;    // problem queue (zeroed before the launch)
+	int hbm_slots;            // slots per wave in hist
+};
+
+// LDS (doubles) of one workgroup: tables, then per wave [stage | tmp | delta | kappa | links | line search | chain tier]
+template <int NCH, int K, int NINT>
+__host__ __device__ constexpr int wave_tab_doubles() { return NCH * 6 * K * NINT + 2 * 6 * NINT; }
+__host__ __device__ inline int wave_priv_doubles(int nC, int cap, int nlds, int epl)
+{
+	const int capp = (cap + 3) & ~3;
+	return ((nC + 3) & ~3) + 128 + 4 * capp + 48 + nlds * epl * 64;
+}
+
+template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS>
+__global__ void __launch_bounds__(64 * NWV, MINW)
+sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
+{
+	using Fam = Family<FAM>;
+	constexpr int DM = Fam::DM, NCH = chm_count(CHM), SMAX = 6, S = K / 2, NG = NOUT / OPL, EPL = OPL * S, NL = NINT + 1, LP = NL * NG;
+	constexpr int nco = S * NINT + S, nC = NOUT * nco, NZL = OPL * DM;
+	static_assert(LP <= 64 && NREG * 2 * EPL <= 252, "lanes / accumulator registers");
+	static_assert(OPL == NOUT || Fam::PER_OUTPUT_COST, "outputs may be split over lanes only when the cost is a sum over the outputs");
+	if constexpr (NREG > 0) NTGW_CLAIM_AGPRS();
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const int P = D.P, m = D.mE, cap = A.cap, capp = (cap + 3) & ~3, qw = D.q_w;
+	// ---- shared tables ----
+	double *s_bt = (double *)smem_raw;                      // [NCH][SMAX][K][NINT] basis values of the CHM channels per interval slot
+	double *s_wt = s_bt + NCH * SMAX * K * NINT;            // [SMAX][NINT] trapezoid node weights
+	double *s_dt = s_wt + SMAX * NINT;                      // [SMAX][NINT] interval lengths
+	double *s_qv = s_dt + SMAX * NINT;                      // [q_nt][q_w] projector rows (ELL)
+	int *s_qc = (int *)(s_qv + ((D.q_nt * qw + 1) & ~1));   // [q_nt][q_w]
+	double *s_priv0 = (double *)(s_qc + ((D.q_nt * qw + 3) & ~3));
+	for (int e = tid; e < NCH * SMAX * K * NINT; e += 64 * NWV) {
+		const int t = e % NINT, q = (e / NINT) % K, s2 = (e / (NINT * K)) % SMAX, ch = e / (NINT * K * SMAX);
+		int r = 0, seen = -1;
+		for (int rr = 0; rr < DM; rr++) if ((CHM >> rr) & 1) { seen++; if (seen == ch) r = rr; }
+		const int i = D.igb[t] + s2;
+		s_bt[e] = i < D.igb[t + 1] ? T.rowv[D.ch_row0[r] + q * P + i] : 0.0;
+	}
+	for (int e = tid; e < SMAX * NINT; e += 64 * NWV) {
+		const int t = e % NINT, s2 = e / NINT, i = D.igb[t] + s2;
+		double w = 0.0, dt = 0.0;
+		if (i < D.igb[t + 1]) {   // trapezoid weight of node i: integrator.c:21-24 regrouped per node
+			if (i > 0) w += (T.bps[i] - T.bps[i - 1]) / 2;
+			if (i < P - 1) { w += (T.bps[i + 1] - T.bps[i]) / 2; dt = T.bps[i + 1] - T.bps[i]; }
+		}
+		s_wt[e] = w; s_dt[e] = dt;
+	}
+	for (int e = tid; e < D.q_nt * qw; e += 64 * NWV) { s_qv[e] = T.q_val[e]; s_qc[e] = T.q_col[e]; }
+	__syncthreads();   // the only workgroup barrier: from here on the waves are independent
+	// ---- this wave's private LDS ----
+	double *s_st = s_priv0 + (size_t)wave * wave_priv_doubles(nC, cap, NLDS, EPL);   // [nC] staging in the natural layout (output-major)
+	double *s_tmp = s_st + ((nC + 3) & ~3);    // [128]
+	double *s_dl = s_tmp + 128;                // [capp] d_j . v
+	double *s_kp = s_dl + capp;                // [capp] kappa_j
+	double *s_lk = s_kp + capp;                // [capp][2] links (e_i, f_i)
+	LineSearch *lsb = (LineSearch *)(s_lk + 2 * capp);   // 2 copies (48 doubles reserved)
+	double *s_hl = s_lk + 2 * capp + 48;       // [NLDS][EPL][64]
+	// ---- lane roles ----
+	const int og = lane / NL, t = lane - og * NL, o0 = og * OPL;
+	const bool lane_on = lane < LP, has_int = lane_on && t < NINT;
+	const int tt = min(t, NINT - 1);
+	const int cnt = has_int ? D.igb[tt + 1] - D.igb[tt] : 0, i0 = D.igb[tt];
+	const int cbase = lane_on ? o0 * nco + S * t : 0;   // owned coefficient (o, q): cbase + o nco + q
+	int qrow[EPL];                                      // row of the owned coefficient in the compact projector, or -1
+#pragma unroll
+	for (int o = 0; o < OPL; o++)
+#pragma unroll
+		for (int q = 0; q < S; q++) qrow[o * S + q] = (lane_on && m > 0) ? (int)T.q_idx[cbase + o * nco + q] : -1;
+	const int wgid = blockIdx.x * NWV + wave;
+	double *hbm = A.hist + (size_t)wgid * A.hbm_slots * EPL * 64;
+
+	// ================= building blocks (all wave-uniform control flow) =================
+	// NPfunobj (ntg.c:274-335) at xt: gradient into g, returns this lane's shares of the quadrature and of |g|^2
+	auto evaluate = [&](const double (&xt)[EPL], double (&g)[EPL], double &Fq, double &g2) {
+		double xb[OPL][K], pg[OPL][K];
+#pragma unroll
+		for (int o = 0; o < OPL; o++)
+#pragma unroll
+			for (int q = 0; q < S; q++) { xb[o][q] = xt[o * S + q]; xb[o][S + q] = from_next(xt[o * S + q]); pg[o][q] = 0.0; pg[o][S + q] = 0.0; }
+		auto slot = [&](int s2) -> double {
+			double bb[NCH][K];
+#pragma unroll
+			for (int ch = 0; ch < NCH; ch++)
+#pragma unroll
+				for (int q = 0; q < K; q++) bb[ch][q] = s_bt[((ch * SMAX + s2) * K + q) * NINT + tt];
+			double z[NZL], df[NZL], fval = 0.0;
+#pragma unroll
+			for (int o = 0; o < OPL; o++)
+#pragma unroll
+				for (int r = 0; r < DM; r++) {
+					double acc = 0.0;
+					if ((CHM >> r) & 1) {
+#pragma unroll
+						for (int q = 0; q < K; q++) acc += bb[chm_rank(CHM, r)][q] * xb[o][q];
+					}
+					z[DM * o + r] = acc;
+				}
+			Fam::ucf(OPL, i0 + s2, z, fval, df);
+			const double w = has_int ? s_wt[s2 * NINT + tt] : 0.0;   // lanes without an interval (t = nint, idle lanes) contribute nothing
+#pragma unroll
+			for (int o = 0; o < OPL; o++)
+#pragma unroll
+				for (int r = 0; r < DM; r++) {
+					if ((CHM >> r) & 1) {
+						const double wd = w * df[DM * o + r];
+#pragma unroll
+						for (int q = 0; q < K; q++) pg[o][q] += wd * bb[chm_rank(CHM, r)][q];
+					}
+				}
+			return fval;
+		};
+		double Fp = 0.0;
+		{
+			double fprev = slot(0), dtprev = has_int ? s_dt[tt] : 0.0;
+			double fnext = from_next(fprev);
+			if (t >= NINT - 1) fnext = 0.0;
+#pragma unroll 1
+			for (int s2 = 1; s2 < SMAX; s2++) {
+				const double fval = slot(s2);
+				Fp += dtprev * ((s2 < cnt ? fval : fnext) + fprev) / 2;
+				fprev = fval; dtprev = has_int ? s_dt[s2 * NINT + tt] : 0.0;
+			}
+			Fp += dtprev * (fnext + fprev) / 2;
+		}
+		Fq = Fp; g2 = 0.0;
+		// coefficient S t + q: this interval's share + the previous interval's (lane t - 1; the lane before t = 0 is an interval-less lane
+		// of the previous group or nothing: zero either way)
+#pragma unroll
+		for (int o = 0; o < OPL; o++)
+#pragma unroll
+			for (int q = 0; q < S; q++) {
+				const double gv = pg[o][q] + from_prev(pg[o][S + q]);
+				g[o * S + q] = gv; g2 += gv * gv;
+			}
+	};
+	auto stage_put = [&](const double (&v)[EPL]) {
+		if (lane_on) {
+#pragma unroll
+			for (int o = 0; o < OPL; o++)
+#pragma unroll
+				for (int q = 0; q < S; q++) s_st[cbase + o * nco + q] = v[o * S + q];
+		}
+		nwt_wave_sync();
+	};
+	auto stage_get = [&](double (&v)[EPL]) {
+		nwt_wave_sync();
+#pragma unroll
+		for (int o = 0; o < OPL; o++)
+#pragma unroll
+			for (int q = 0; q < S; q++) v[o * S + q] = lane_on ? s_st[cbase + o * nco + q] : 0.0;
+	};
+	// gp = g - Q g, Q = A'(AA')^-1 A as ELL over its non-zero rows (sqp_kernel: project)
+	auto project = [&](const double (&g)[EPL], double (&gp)[EPL]) {
+		if (m == 0) {
+#pragma unroll
+			for (int e = 0; e < EPL; e++) gp[e] = g[e];
+			return;
+		}
+		stage_put(g);
+#pragma unroll
+		for (int e = 0; e < EPL; e++) {
+			double s = 0.0;
+			if (qrow[e] >= 0) {
+				for (int w2 = 0; w2 < qw; w2++) s += s_qv[qrow[e] * qw + w2] * s_st[s_qc[qrow[e] * qw + w2]];
+			}
+			gp[e] = g[e] - s;
+		}
+		nwt_wave_sync();
+	};
+	// out = W0 v: identity (NPSOL cold start) or the collocation preconditioner, block diagonal by output: the one GEMM-shaped piece,
+	// Out(nco x NOUT) = W_b V on v_mfma_f64_16x16x4_f64 (apply_n0_block of sqp_kernel, for one wave)
+	auto apply_w0 = [&](const double (&v)[EPL], double (&out)[EPL]) {
+		if constexpr (!HESS) {
+#pragma unroll
+			for (int e = 0; e < EPL; e++) out[e] = v[e];
+		} else {
+			if (sp.hessian != 1) {
+#pragma unroll
+				for (int e = 0; e < EPL; e++) out[e] = v[e];
+				return;
+			}
+			constexpr int TM = (nco + 15) / 16;
+			stage_put(v);
+			const int li = lane & 15, lk = lane >> 4, spad = T.n0b_sp;
+			const int myblk = li < NOUT ? D.n0_blk[li] : -1;
+			const double *bcol = s_st + (li < NOUT ? li : 0) * nco;
+			ntg_d4 acc[TM];
+#pragma unroll
+			for (int tl = 0; tl < TM; tl++) acc[tl] = ntg_d4{0.0, 0.0, 0.0, 0.0};
+			for (int b = 0; b < T.n0b_nblk; b++) {
+				const double *wbb = T.n0b + (size_t)b * spad * nco + li;
+				const bool mine = myblk == b;
+				for (int k0 = 0; k0 < spad; k0 += 16) {
+					double av[4][TM], bv[4];
+#pragma unroll
+					for (int u = 0; u < 4; u++) {
+						const int k = k0 + 4 * u + lk;
+						bv[u] = mine ? bcol[min(k, nco - 1)] : 0.0;   // k >= nco: W's row is zero padding
+						const double *wk = wbb + (size_t)k * nco;
+#pragma unroll
+						for (int tl = 0; tl < TM; tl++) av[u][tl] = (16 * tl + li < nco) ? wk[16 * tl] : 0.0;
+					}
+#pragma unroll
+					for (int u = 0; u < 4; u++)
+#pragma unroll
+						for (int tl = 0; tl < TM; tl++) acc[tl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][tl], bv[u], acc[tl], 0, 0, 0);
+				}
+			}
+			nwt_wave_sync();   // every read of the staged v is done
+			if (li < NOUT) {
+#pragma unroll
+				for (int tl = 0; tl < TM; tl++)
+#pragma unroll
+					for (int r = 0; r < 4; r++) { const int row = tl * 16 + 4 * r + lk; if (row < nco) s_st[li * nco + row] = acc[tl][r]; }
+			}
+			stage_get(out);
+			nwt_wave_sync();
+		}
+	};
+	// ---- the direction chain: slot j lives in the accumulator registers (j < NREG), in LDS (next NLDS) or in HBM ----
+	auto slot_store = [&](int j, const double (&v)[EPL]) {
+		if (j < NREG) {
+			static_for<0, NREG>([&](auto Jc) {
+				constexpr int J = decltype(Jc)::value;
+				if (j == J) {
+					static_for<0, EPL>([&](auto Ec) { constexpr int E = decltype(Ec)::value; areg_write<J * EPL + E>(v[E]); });
+				}
+			});
+		} else if (j < NREG + NLDS) {
+#pragma unroll
+			for (int e = 0; e < EPL; e++) s_hl[((j - NREG) * EPL + e) * 64 + lane] = v[e];
+		} else {
+#pragma unroll
+			for (int e = 0; e < EPL; e++) hbm[((size_t)(j - NREG - NLDS) * EPL + e) * 64 + lane] = v[e];
+		}
+	};
+	// tv += sum_j kappa_j d_j, kappa = (symmetric tridiagonal of the links) (d_j . v): DESIGN.md 4a.4, apply_dform of sqp_kernel
+	auto sweep = [&](int ns, const double (&v)[EPL], double (&tv)[EPL]) {
+		if (ns < 2) return;   // a chain of one vector carries no update yet
+		double acc[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++) acc[k] = 0.0;
+		auto flush = [&](int base) {   // slots base .. base+15 -> delta
+			const double tot = wave_sum_many<16>(acc, lane);
+			if (lane < 16 && base + lane < ns) s_dl[base + lane] = tot;
+#pragma unroll
+			for (int k = 0; k < 16; k++) acc[k] = 0.0;
+		};
+		// pass 1: delta_j = d_j . v
+		if constexpr (NREG > 0) {
+			static_for<0, NREG>([&](auto Jc) {
+				constexpr int J = decltype(Jc)::value;
+				if (J < ns) {
+					double h[EPL];
+					static_for<0, EPL>([&](auto Ec) { constexpr int E = decltype(Ec)::value; h[E] = areg_read<J * EPL + E>(); });
+					double a = 0.0;
+#pragma unroll
+					for (int e = 0; e < EPL; e++) a += h[e] * v[e];
+					acc[J & 15] = a;
+				}
+				if ((J & 15) == 15 || J == NREG - 1) { if (J - (J & 15) < ns) flush(J - (J & 15)); }
+			});
+		}
+		if constexpr (NLDS > 0) {
+			for (int base = NREG; base < min(ns, NREG + NLDS); base += 16) {
+#pragma unroll
+				for (int u = 0; u < 16; u++) {
+					const int j = base + u;
+					if (u < NLDS && j < min(ns, NREG + NLDS)) {
+						double a = 0.0;
+#pragma unroll
+						for (int e = 0; e < EPL; e++) a += s_hl[((j - NREG) * EPL + e) * 64 + lane] * v[e];
+						acc[u] = a;
+					}
+				}
+				flush(base);
+			}
+		}
+		for (int base = NREG + NLDS; base < ns; base += 16) {
+#pragma unroll
+			for (int u = 0; u < 16; u++) {
+				const int j = min(base + u, ns - 1);   // unconditional loads (a repeat past the end is masked below)
+				double a = 0.0;
+#pragma unroll
+				for (int e = 0; e < EPL; e++) a += hbm[((size_t)(j - NREG - NLDS) * EPL + e) * 64 + lane] * v[e];
+				acc[u] = base + u < ns ? a : 0.0;
+				if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four vectors in flight at a time, not sixteen
+			}
+			flush(base);
+		}
+		nwt_wave_sync();
+		// kappa_j = f_j delta_j + e_j delta_{j+1} + e_{j-1} delta_{j-1}; link i = (e_i, f_i) joins slots i and i + 1
+		double kap0 = 0.0;
+		for (int j = lane; j < ns; j += 64) {
+			const double dj = s_dl[j];
+			double k = 0.0;
+			if (j < ns - 1) k += s_lk[2 * j + 1] * dj + s_lk[2 * j] * s_dl[j + 1];
+			if (j > 0) k += s_lk[2 * j - 2] * s_dl[j - 1];
+			s_kp[j] = k;
+			if (j == lane) kap0 = k;
+		}
+		nwt_wave_sync();
+		// pass 2: tv += kappa_j d_j
+		if constexpr (NREG > 0) {
+			static_for<0, NREG>([&](auto Jc) {
+				constexpr int J = decltype(Jc)::value;
+				if (J < ns) {
+					const double kj = bcast(kap0, J);
+					static_for<0, EPL>([&](auto Ec) { constexpr int E = decltype(Ec)::value; tv[E] += kj * areg_read<J * EPL + E>(); });
+				}
+			});
+		}
+		if constexpr (NLDS > 0) {
+			for (int j = NREG; j < min(ns, NREG + NLDS); j++) {
+				const double kj = s_kp[j];
+#pragma unroll
+				for (int e = 0; e < EPL; e++) tv[e] += kj * s_hl[((j - NREG) * EPL + e) * 64 + lane];
+			}
+		}
+#pragma unroll 4
+		for (int j = NREG + NLDS; j < ns; j++) {
+			const double kj = s_kp[j];
+#pragma unroll
+			for (int e = 0; e < EPL; e++) tv[e] += kj * hbm[((size_t)(j - NREG - NLDS) * EPL + e) * 64 + lane];
+		}
+	};
+
+	// ================= persistent loop over problems =================
+	for (;;) {
+		// (the wave barriers pin the queue pop between the end of one problem and the start of the next: without them the compiler
+		// merged this lane-0 region with the lane-0 stores at the end of the loop body and sent the other 63 lanes round the loop on
+		// their own, past the readfirstlane -- they then re-solved problem 0 for ever)
+		__builtin_amdgcn_wave_barrier();
+		int b = 0;
+		if (lane == 0) b = (int)atomicAdd(A.counter, 1u);
+		__builtin_amdgcn_wave_barrier();
+		b = __builtin_amdgcn_readfirstlane(b);
+		if (b >= A.batch) break;
+		const double *lo = A.lower + (size_t)b * D.nbounds, *up = A.upper + (size_t)b * D.nbounds;
+#ifdef NTGW_DEBUG
+		if (lane == 0) printf("wave %d takes problem %d of %d (cap %d)\n", wgid, b, A.batch, cap);
+#endif
+		double *xrow = A.xio + (size_t)b * nC;
+		double x[EPL], xt[EPL], gp[EPL], gpt[EPL], d[EPL], g[EPL];
+#pragma unroll
+		for (int o = 0; o < OPL; o++)
+#pragma unroll
+			for (int q = 0; q < S; q++) x[o * S + q] = lane_on ? xrow[cbase + o * nco + q] : 0.0;
+#pragma unroll
+		for (int e = 0; e < EPL; e++) { d[e] = 0.0; gp[e] = 0.0; gpt[e] = 0.0; g[e] = 0.0; }
+		enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3 };
+		int inform = 4, iter = 0, nfev = 0, nupd = 0, ns = 0, state = ST_INIT;
+		bool headpair = false;   // the quasi-Newton memory was restarted at an accepted step: its first pair is not in the span of the chain
+		unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define NTGW_STAMP(slot_) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot_] += now_ - tlast; tlast = now_; } } while (0)
+		if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
+		// ---- scope check: every linear row is an equality (lower == upper), see sqp_kernel ----
+		{
+			double bad[1] = {0.0};
+			for (int s = lane; s < D.nlic + D.nltc + D.nlfc; s += 64) if (lo[s] != up[s]) bad[0] += 1.0;
+			wave_sums<1>(bad, lane);
+			if (bad[0] != 0.0) inform = 9;
+		}
+		double F = 0.0, gn2 = 0.0, alpha = 0.0, pnorm = 0.0;
+		int inner_inform = 4;
+		bool weak = false, finished = false;
+		if (inform != 9) {
+			// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
+			if (m > 0) {
+				stage_put(x);
+				for (int r = lane; r < m; r += 64) {
+					double a = 0.0;
+					for (int e = T.csr_ptr[r]; e < T.csr_ptr[r + 1]; e++) a += T.csr_val[e] * s_st[T.csr_col[e]];
+					s_tmp[r] = lo[lin_slot(D, r)] - a;
+				}
+				nwt_wave_sync();
+				for (int r = lane; r < m; r += 64) {
+					double a = 0.0;
+					for (int e = T.sinv_ptr[r]; e < T.sinv_ptr[r + 1]; e++) a += T.sinv_val[e] * s_tmp[T.sinv_col[e]];
+					s_tmp[64 + r] = a;
+				}
+				nwt_wave_sync();
+				if (lane_on) {
+#pragma unroll
+					for (int o = 0; o < OPL; o++)
+#pragma unroll
+						for (int q = 0; q < S; q++) {
+							const int c = cbase + o * nco + q;
+							double s = 0.0;
+							for (int e = T.csc_ptr[c]; e < T.csc_ptr[c + 1]; e++) s += T.csc_val[e] * s_tmp[64 + T.csc_row[e]];
+							x[o * S + q] += s;
+						}
+				}
+				nwt_wave_sync();
+			}
+#pragma unroll
+			for (int e = 0; e < EPL; e++) xt[e] = x[e];
+			NTGW_STAMP(0);
+			int lsi = 0;
+			double ls_a = 0.0;
+			double r4[4] = {0, 0, 0, 0};   // gp.d, d.d, x.x, gp.gp of the current iterate
+			for (;;) {
+				// ================= the one evaluation site =================
+				double part[3] = {0.0, 0.0, 0.0};
+				evaluate(xt, g, part[0], part[1]);
+				NTGW_STAMP(1);
+				if (state != ST_FINAL) {
+					project(g, gpt);
+#pragma unroll
+					for (int e = 0; e < EPL; e++) part[2] += gpt[e] * (-d[e]);
+					NTGW_STAMP(2);
+				}
+				wave_sums<3>(part, lane);
+				const double Fn = part[0], gn2n = part[1];
+#ifdef NTGW_DEBUG
+				if (lane == 0 && nfev < 40) printf("b %d state %d iter %d nfev %d ns %d F %.10g g2 %.6g slope %.6g a %.6g\n", b, state, iter, nfev, ns, Fn, gn2n, part[2], ls_a);
+#endif
+				if (state == ST_FINAL) {
+					// multipliers estimate lam = (AA')^-1 A g at the final point
+					stage_put(g);
+					for (int r = lane; r < m; r += 64) {
+						double a = 0.0;
+						for (int e = T.csr_ptr[r]; e < T.csr_ptr[r + 1]; e++) a += T.csr_val[e] * s_st[T.csr_col[e]];
+						s_tmp[r] = a;
+					}
+					nwt_wave_sync();
+					for (int r = lane; r < m; r += 64) {
+						double a = 0.0;
+						for (int e = T.sinv_ptr[r]; e < T.sinv_ptr[r + 1]; e++) a += T.sinv_val[e] * s_tmp[T.sinv_col[e]];
+						s_tmp[64 + r] = a;
+					}
+					nwt_wave_sync();
+#ifdef NTGW_DEBUG
+					if (lane == 0) printf("b %d multipliers done\n", b);
+#endif
+					break;
+				}
+				nfev++;
+				bool new_major = false;
+				if (state == ST_INIT) {
+					F = Fn; gn2 = gn2n;
+#pragma unroll
+					for (int e = 0; e < EPL; e++) gp[e] = gpt[e];
+					apply_w0(gp, d);
+#pragma unroll
+					for (int k = 0; k < 4; k++) r4[k] = 0.0;
+#pragma unroll
+					for (int e = 0; e < EPL; e++) { r4[0] += gp[e] * d[e]; r4[1] += d[e] * d[e]; r4[2] += x[e] * x[e]; r4[3] += gp[e] * gp[e]; }
+					wave_sums<4>(r4, lane);
+					NTGW_STAMP(4);
+					new_major = true;
+				} else {
+					int rc = 1;
+					if (state == ST_LS) {
+						LineSearch lsr = lsb[lsi];
+						rc = lsr.step(Fn, part[2]);
+						ls_a = lsr.a;
+						if (lane == 0) lsb[lsi ^ 1] = lsr;
+						lsi ^= 1;
+						nwt_wave_sync();
+					}
+					if (rc == 0 || rc == 2) {
+						if (rc == 2) state = ST_FORCE;
+#pragma unroll
+						for (int e = 0; e < EPL; e++) xt[e] = x[e] + ls_a * (-d[e]);
+						NTGW_STAMP(5);
+						continue;
+					}
+					if (rc != 1) {
+						const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+						if (nupd > 0 && sqrt(r4[3]) > tolg) {
+							// line search failed with a non-trivial W: drop the updates and retry from the same point with W0
+							nupd = 0; ns = 0; headpair = false;
+							apply_w0(gp, d);
+							double r2[2] = {0, 0};
+#pragma unroll
+							for (int e = 0; e < EPL; e++) { r2[0] += gp[e] * d[e]; r2[1] += d[e] * d[e]; }
+							wave_sums<2>(r2, lane);
+							r4[0] = r2[0]; r4[1] = r2[1];
+							new_major = true;
+						} else {
+							const double gpn0 = sqrt(r4[3]);
+							if (gpn0 <= tolg) inner_inform = 0;
+							else if (gpn0 <= 1e3 * tolg) { inner_inform = 0; weak = true; }
+							else inner_inform = 6;
+							finished = true;
+						}
+					} else {
+						alpha = ls_a;
+						// accept: s = alpha p, x = xt; t = W gp+ (W0, then the chain), u = t - d, BFGS update on the inverse
+						double sv[EPL], tv[EPL];
+#pragma unroll
+						for (int e = 0; e < EPL; e++) { sv[e] = alpha * (-d[e]); x[e] = xt[e]; }
+						if (nupd == sp.memcap || ns + 3 > cap) {   // memory full: restart the approximation from W0 (oracle/sqp.c does the same at the same count)
+							nupd = 0; ns = 0; headpair = true;
+							apply_w0(gp, d);
+						}
+						if (ns == 0 && !headpair) { slot_store(0, d); ns = 1; }   // a chain starts: d_0 = the direction of this step
+						NTGW_STAMP(5);
+						apply_w0(gpt, tv);
+						NTGW_STAMP(4);
+						sweep(ns, gpt, tv);
+						NTGW_STAMP(3);
+						double r6[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+						for (int e = 0; e < EPL; e++) {
+							const double s = sv[e], y = gpt[e] - gp[e], u = tv[e] - d[e], gq = gpt[e];
+							r6[0] += s * y; r6[1] += y * u; r6[2] += s * gq; r6[3] += u * gq; r6[4] += s * s; r6[5] += y * y;
+						}
+						wave_sums<6>(r6, lane);
+						const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
+						const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
+						double dn[EPL];
+#pragma unroll
+						for (int e = 0; e < EPL; e++) {
+							const double s = sv[e], u = tv[e] - d[e];
+							dn[e] = upd ? tv[e] - rho * (s * r6[3] + u * r6[2]) + c2 * s * r6[2] : tv[e];
+						}
+						if (headpair && upd) {
+							// first update after a restart at an accepted step: s is the step actually taken (along the OLD direction), not
+							// -alpha W0 gp: the pair (s, u) is stored as two slots joined by the link (-rho, c2) -- exactly the pair term
+							// -rho (s u' + u s') + c2 s s' -- followed by a null link to the chain that starts with d+
+							double uv[EPL];
+#pragma unroll
+							for (int e = 0; e < EPL; e++) uv[e] = tv[e] - d[e];
+							slot_store(0, sv); slot_store(1, uv); slot_store(2, dn);
+							if (lane == 0) { s_lk[0] = -rho; s_lk[1] = c2; s_lk[2] = 0.0; s_lk[3] = 0.0; }
+							ns = 3; nupd = 1;
+						} else if (headpair) {
+							slot_store(0, dn); ns = 1;   // no update: W stays W0, a clean chain starts at d+
+						} else {
+							// link of this major: s = -alpha d_k, u = beta d_{k+1} + gamma d_k (omega = -(s.g)/(s.y) > 0 whenever the update is taken)
+							double le = 0.0, lf = 0.0;
+							if (upd) {
+								const double omega = 1.0 - rho * r6[2], theta = rho * r6[2] - alpha * c2 * r6[2] + alpha * rho * r6[3];
+								const double beta = 1.0 / omega, gamma = -theta * beta - 1.0;
+								le = rho * alpha * beta; lf = 2.0 * rho * alpha * gamma + c2 * alpha * alpha;
+								nupd++;
+							}
+							slot_store(ns, dn);
+							if (lane == 0) { s_lk[2 * (ns - 1)] = le; s_lk[2 * (ns - 1) + 1] = lf; }
+							ns++;
+						}
+						headpair = false;
+						nwt_wave_sync();
+#pragma unroll
+						for (int k = 0; k < 4; k++) r4[k] = 0.0;
+#pragma unroll
+						for (int e = 0; e < EPL; e++) {
+							gp[e] = gpt[e]; d[e] = dn[e];
+							r4[0] += gp[e] * d[e]; r4[1] += d[e] * d[e]; r4[2] += x[e] * x[e]; r4[3] += gp[e] * gp[e];
+						}
+						wave_sums<4>(r4, lane);
+						F = Fn; gn2 = gn2n;
+						iter++;
+						if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r4[2])) &&
+						    sqrt(r4[3]) <= sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)))) { inner_inform = 0; finished = true; }
+						else new_major = true;
+					}
+				}
+				if (new_major) {
+					// ---- start of a major iteration at (x, gp, d) ----
+					if (iter >= sp.itlim) { inner_inform = 4; finished = true; }
+					else {
+						double dphi0 = -r4[0];
+						pnorm = sqrt(r4[1]);
+						const double xnorm = sqrt(r4[2]), gpnorm = sqrt(r4[3]);
+						const double tolg = sp.sr * (1.0 + fmax(1.0 + fabs(F), sqrt(gn2)));
+						if (pnorm == 0.0 || !(dphi0 < 0.0)) {
+							if (pnorm != 0.0) {   // W lost definiteness numerically: restart from W0 once
+								nupd = 0; ns = 0; headpair = false;
+								apply_w0(gp, d);
+								double r2[2] = {0, 0};
+#pragma unroll
+								for (int e = 0; e < EPL; e++) { r2[0] += gp[e] * d[e]; r2[1] += d[e] * d[e]; }
+								wave_sums<2>(r2, lane);
+								r4[0] = r2[0]; r4[1] = r2[1];
+								dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
+							}
+							if (pnorm == 0.0 || !(dphi0 < 0.0)) { inner_inform = (gpnorm <= tolg) ? 0 : 6; finished = true; }
+						}
+						if (!finished && !sp.fixed_iters && gpnorm <= 1e-3 * tolg) { inner_inform = 0; finished = true; }
+						if (!finished) {
+							const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
+							const double a = amax < 1.0 ? amax : 1.0;
+							if (lane == 0) lsb[lsi ^ 1].init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
+							lsi ^= 1; ls_a = a;
+							nwt_wave_sync();
+							state = ST_LS;
+#pragma unroll
+							for (int e = 0; e < EPL; e++) xt[e] = x[e] + a * (-d[e]);
+						}
+					}
+				}
+				NTGW_STAMP(5);
+				if (finished) {
+					inform = (inner_inform == 0 && weak) ? 1 : inner_inform;
+					if (A.clambda && m > 0) {   // one more pass at x for the multipliers (the Q form does not produce them)
+						state = ST_FINAL;
+#pragma unroll
+						for (int e = 0; e < EPL; e++) xt[e] = x[e];
+						continue;
+					}
+					break;
+				}
+			}
+		}
+#ifdef NTGW_DEBUG
+		if (lane == 0) printf("b %d left the iteration: inform %d iter %d\n", b, inform, iter);
+#endif
+		if (inform != 9 && lane_on) {
+#pragma unroll
+			for (int o = 0; o < OPL; o++)
+#pragma unroll
+				for (int q = 0; q < S; q++) xrow[cbase + o * nco + q] = x[o * S + q];
+		}
+#ifdef NTGW_DEBUG
+		if (lane == 0) printf("b %d x written\n", b);
+#endif
+		NTGW_STAMP(5);
+		if (A.clambda) {
+			const int ntot = nC + D.nclin;   // NPSOL's layout: coefficients, linear rows (no nonlinear rows in this class)
+			for (int i = lane; i < ntot; i += 64) {
+				double v = 0.0;
+				if (inform != 9 && i >= nC && m > 0) v = s_tmp[64 + (i - nC)];
+				A.clambda[(size_t)b * ntot + i] = v;
+			}
+			if (sp.stamps && lane == 0) for (int i = 0; i < 8; i++) A.clambda[(size_t)b * ntot + i] = (double)tk[i];
+			nwt_wave_sync();
+		}
+#undef NTGW_STAMP
+		if (lane == 0) {
+			if (A.objective) A.objective[b] = F;
+			if (A.inform) A.inform[b] = inform;
+			if (A.iters) A.iters[b] = iter;
+			if (A.nfev) A.nfev[b] = nfev;
+		}
+#ifdef NTGW_DEBUG
+		if (lane == 0) printf("b %d done\n", b);
+#endif
+		__builtin_amdgcn_wave_barrier();
+	}
+#ifdef NTGW_DEBUG
+	if (lane == 0) printf("wave %d exits\n", wgid);
+#endif
+}
+
+// does the plan fit the wave kernel?  (The dispatcher falls back to sqp_kernel otherwise.)
+static inline bool wave_match(const NtgDims &D, const NtgTables &T, const SolveParams &sp, int chm, int dm, int K, int opl, int nint)
+{
+	if (!ntg_chm_match(D, chm, dm) || D.ncnln || !D.uniform || D.nI) return false;
+	if (D.order[0] != K || (K & 1) || D.mult[0] != K / 2 || D.ig_n != nint || D.nout % opl) return false;
+	if (D.ncoef[0] != (K / 2) * D.ig_n + K / 2) return false;
+	if ((D.ig_n + 1) * (D.nout / opl) > 64) return false;
+	if (D.mE != D.nclin || D.mE > 64) return false;
+	if (D.mE > 0 && !D.q_use) return false;
+	if (T.pp_rowv || T.pp_bps || T.pp_q) return false;   // per-problem grids: sqp_kernel
+	if (sp.hessian == 1 && !(T.n0b && T.n0b_n == D.ncoef[0])) return false;
+	if (sp.hessian == 2) return false;
+	return true;
+}
+
+struct WaveLaunch {
+	int nwv, grid, cap, hbm_slots;
+	size_t lds;
+};
+
+}   // namespace ntgw
