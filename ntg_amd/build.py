@@ -47,6 +47,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
             sys.stderr.write(open(obj + ".log").read())
     if failed:
         raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    # the wave kernels address accumulator registers by hand: the compiler's own code must stay below their base
+    from . import isa_audit
+    bad = isa_audit.audit(hipcc, os.path.join(CSRC, "fam_kincar_wave.hip"), os.path.join(HERE, "..", "include"),
+                          os.environ.get("NTG_AMD_CXXFLAGS", "").split(), isa_audit.agpr_base(os.path.join(CSRC, "solve_wave.hpp")))
+    if bad:
+        raise RuntimeError("ISA audit of fam_kincar_wave.hip failed (compiler-generated code in the hand-managed AGPR range, or spills):\n  " + "\n  ".join(bad[:20]))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
     return LIB
 

@@ -30,7 +30,7 @@ hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &s
 // LDS bytes of a workgroup
 size_t wave_lds(const NtgDims &D, int nwv, int cap, int nlds, int epl)
 {
-	const size_t tab = (size_t)wave_tab_doubles<1, 6, 20>() * 8 + (size_t)((D.q_nt * D.q_w + 1) & ~1) * 8 + (size_t)((D.q_nt * D.q_w + 3) & ~3) * 4;
+	const size_t tab = (size_t)wave_tab_doubles<1, 6, 20>() * 8 + (size_t)D.q_nt * 6 * 8 + (size_t)D.q_nt * 8 * 4;
 	return tab + (size_t)nwv * wave_priv_doubles(D.nC, cap, nlds, epl) * 8;
 }
 
@@ -50,7 +50,7 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 	w->fat = (sp.hessian != 1 && !getenv("NTG_AMD_WAVE_LEAN")) ? 1 : 0;
 	w->nwv = 4;
 	if (w->fat) {
-		const int nreg = 252 / (2 * epl);
+		const int nreg = (256 - NTGW_ABASE) / (2 * epl);
 		w->lds = wave_lds(D, 4, w->cap, FAT_NLDS, epl);
 		if (w->lds > 160 * 1024) w->fat = 0;
 		else {
@@ -73,9 +73,9 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 {
 	if (!a.counter) return hipErrorInvalidValue;
 	if (w.fat) {
-		if (D.nout == 2) return launch_one<2, 1, 4, 1, 42, FAT_NLDS, false>(D, T, sp, a, w);
-		if (D.nout == 4) return launch_one<4, 2, 4, 1, 21, FAT_NLDS, false>(D, T, sp, a, w);
-		return launch_one<6, 2, 4, 1, 21, FAT_NLDS, false>(D, T, sp, a, w);
+		if (D.nout == 2) return launch_one<2, 1, 4, 1, (256 - NTGW_ABASE) / 6, FAT_NLDS, false>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 4, 1, (256 - NTGW_ABASE) / 12, FAT_NLDS, false>(D, T, sp, a, w);
+		return launch_one<6, 2, 4, 1, (256 - NTGW_ABASE) / 12, FAT_NLDS, false>(D, T, sp, a, w);
 	}
 	if (D.nout == 2) return launch_one<2, 1, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
 	if (D.nout == 4) return launch_one<4, 2, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);

@@ -21,6 +21,10 @@
 #pragma once
 #include "solve_impl.hpp"
 
+#ifndef NTGW_EVU
+#define NTGW_EVU 1   // unroll factor of the evaluation's loop over an interval's breakpoint slots
+#endif
+
 namespace ntgw {
 
 template <int J, int N, class F>
@@ -43,19 +47,22 @@ __device__ __forceinline__ double from_next(double v)
 	return __hiloint2double(hi, lo);
 }
 
-// accumulator registers a[2 IDX], a[2 IDX + 1] as one double.  The kernel lists a0..a251 as clobbers once (which makes the kernel
-// descriptor allocate them); nothing else in the kernel uses AGPRs (no MFMA in the instances that use this tier, and the build
-// audits the ISA for compiler-generated v_accvgpr_* -- ntg_amd/build.py).
+// The register allocator hands out accumulator registers from a0 upwards when the 256 architectural VGPRs run short (AV-class values:
+// load results, copies).  It cannot be told to keep out, so the chain starts at a[NTGW_ABASE]: a0 .. a[NTGW_ABASE - 1] are the compiler's,
+// and ntg_amd/isa_audit.py fails the build if compiler-generated code touches anything from a[NTGW_ABASE] up.
+#define NTGW_ABASE 32
+// accumulator registers a[ABASE + 2 IDX], a[ABASE + 2 IDX + 1] as one double.  The kernel lists a0..a255 as clobbers once (which makes
+// the kernel descriptor allocate them all).
 template <int IDX>
 __device__ __forceinline__ void areg_write(double v)
 {
-	asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(__double2loint(v)), "v"(__double2hiint(v)), "i"(2 * IDX), "i"(2 * IDX + 1));
+	asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(__double2loint(v)), "v"(__double2hiint(v)), "i"(NTGW_ABASE + 2 * IDX), "i"(NTGW_ABASE + 2 * IDX + 1));
 }
 template <int IDX>
 __device__ __forceinline__ double areg_read()
 {
 	int lo, hi;
-	asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]" : "=v"(lo), "=v"(hi) : "i"(2 * IDX), "i"(2 * IDX + 1));
+	asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]" : "=v"(lo), "=v"(hi) : "i"(NTGW_ABASE + 2 * IDX), "i"(NTGW_ABASE + 2 * IDX + 1));
 	return __hiloint2double(hi, lo);
 }
 #define NTGW_C10(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
@@ -63,7 +70,7 @@ __device__ __forceinline__ double areg_read()
 	asm volatile("" ::: NTGW_C10(), NTGW_C10(1), NTGW_C10(2), NTGW_C10(3), NTGW_C10(4), NTGW_C10(5), NTGW_C10(6), NTGW_C10(7),     \
 	             NTGW_C10(8), NTGW_C10(9), NTGW_C10(10), NTGW_C10(11), NTGW_C10(12), NTGW_C10(13), NTGW_C10(14), NTGW_C10(15),    \
 	             NTGW_C10(16), NTGW_C10(17), NTGW_C10(18), NTGW_C10(19), NTGW_C10(20), NTGW_C10(21), NTGW_C10(22), NTGW_C10(23),  \
-	             NTGW_C10(24), "a250", "a251")
+	             NTGW_C10(24), "a250", "a251", "a252", "a253", "a254", "a255")
 
 __device__ __forceinline__ double bcast(double v, int lane)
 {
@@ -111,11 +118,11 @@ __global__ void __launch_bounds__(64 * NWV, MINW)
 sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 {
 	using Fam = Family<FAM>;
+	if constexpr (NREG > 0) NTGW_CLAIM_AGPRS();
 	constexpr int DM = Fam::DM, NCH = chm_count(CHM), SMAX = 6, S = K / 2, NG = NOUT / OPL, EPL = OPL * S, NL = NINT + 1, LP = NL * NG;
 	constexpr int nco = S * NINT + S, nC = NOUT * nco, NZL = OPL * DM;
-	static_assert(LP <= 64 && NREG * 2 * EPL <= 252, "lanes / accumulator registers");
+	static_assert(LP <= 64 && NTGW_ABASE + NREG * 2 * EPL <= 256, "lanes / accumulator registers");
 	static_assert(OPL == NOUT || Fam::PER_OUTPUT_COST, "outputs may be split over lanes only when the cost is a sum over the outputs");
-	if constexpr (NREG > 0) NTGW_CLAIM_AGPRS();
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int P = D.P, m = D.mE, cap = A.cap, capp = (cap + 3) & ~3, qw = D.q_w;
@@ -124,8 +131,8 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	double *s_wt = s_bt + NCH * SMAX * K * NINT;            // [SMAX][NINT] trapezoid node weights
 	double *s_dt = s_wt + SMAX * NINT;                      // [SMAX][NINT] interval lengths
 	double *s_qv = s_dt + SMAX * NINT;                      // [q_nt][q_w] projector rows (ELL)
-	int *s_qc = (int *)(s_qv + ((D.q_nt * qw + 1) & ~1));   // [q_nt][q_w]
-	double *s_priv0 = (double *)(s_qc + ((D.q_nt * qw + 3) & ~3));
+	int *s_qc = (int *)(s_qv + D.q_nt * 6);                // [q_nt][8]
+	double *s_priv0 = (double *)(s_qc + D.q_nt * 8);
 	for (int e = tid; e < NCH * SMAX * K * NINT; e += 64 * NWV) {
 		const int t = e % NINT, q = (e / NINT) % K, s2 = (e / (NINT * K)) % SMAX, ch = e / (NINT * K * SMAX);
 		int r = 0, seen = -1;
@@ -142,7 +149,8 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		}
 		s_wt[e] = w; s_dt[e] = dt;
 	}
-	for (int e = tid; e < D.q_nt * qw; e += 64 * NWV) { s_qv[e] = T.q_val[e]; s_qc[e] = T.q_col[e]; }
+	for (int e = tid; e < D.q_nt * 6; e += 64 * NWV) { const int r = e / 6, w2 = e - 6 * r; s_qv[e] = w2 < qw ? T.q_val[r * qw + w2] : 0.0; }   // rows padded to 6 entries
+	for (int e = tid; e < D.q_nt * 8; e += 64 * NWV) { const int r = e / 8, w2 = e - 8 * r; s_qc[e] = w2 < qw ? T.q_col[r * qw + w2] : 0; }     // ... and to 8 indices
 	__syncthreads();   // the only workgroup barrier: from here on the waves are independent
 	// ---- this wave's private LDS ----
 	double *s_st = s_priv0 + (size_t)wave * wave_priv_doubles(nC, cap, NLDS, EPL);   // [nC] staging in the natural layout (output-major)
@@ -163,6 +171,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	for (int o = 0; o < OPL; o++)
 #pragma unroll
 		for (int q = 0; q < S; q++) qrow[o * S + q] = (lane_on && m > 0) ? (int)T.q_idx[cbase + o * nco + q] : -1;
+	constexpr int QW = 6;   // entries per projector row this kernel handles (wave_match checks q_w <= 6)
 	const int wgid = blockIdx.x * NWV + wave;
 	double *hbm = A.hist + (size_t)wgid * A.hbm_slots * EPL * 64;
 
@@ -174,7 +183,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		for (int o = 0; o < OPL; o++)
 #pragma unroll
 			for (int q = 0; q < S; q++) { xb[o][q] = xt[o * S + q]; xb[o][S + q] = from_next(xt[o * S + q]); pg[o][q] = 0.0; pg[o][S + q] = 0.0; }
-		auto slot = [&](int s2) -> double {
+		auto slot = [&](int s2) __attribute__((always_inline)) -> double {
 			double bb[NCH][K];
 #pragma unroll
 			for (int ch = 0; ch < NCH; ch++)
@@ -211,7 +220,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			double fprev = slot(0), dtprev = has_int ? s_dt[tt] : 0.0;
 			double fnext = from_next(fprev);
 			if (t >= NINT - 1) fnext = 0.0;
-#pragma unroll 1
+#pragma unroll(NTGW_EVU)
 			for (int s2 = 1; s2 < SMAX; s2++) {
 				const double fval = slot(s2);
 				Fp += dtprev * ((s2 < cnt ? fval : fnext) + fprev) / 2;
@@ -246,7 +255,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 #pragma unroll
 			for (int q = 0; q < S; q++) v[o * S + q] = lane_on ? s_st[cbase + o * nco + q] : 0.0;
 	};
-	// gp = g - Q g, Q = A'(AA')^-1 A as ELL over its non-zero rows (sqp_kernel: project)
+	// gp = g - Q g, Q = A'(AA')^-1 A as ELL over its non-zero rows (sqp_kernel: project).  The column indices of a lane's rows sit in
+	// registers (rows of at most QW entries): the reads of g and of the values are then independent of each other -- one LDS round trip
+	// per projection instead of a dependent chain of 2 q_w EPL of them (measured: 6.2 k -> cycles per projection on one wave per SIMD).
 	auto project = [&](const double (&g)[EPL], double (&gp)[EPL]) {
 		if (m == 0) {
 #pragma unroll
@@ -254,13 +265,22 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			return;
 		}
 		stage_put(g);
+		// every load is unconditional (a lane without a row reads row 0: one broadcast address) and the result is selected afterwards.
+		// Two LDS round trips: the rows' column indices (16-byte reads), then g at those columns and the rows' values.
+		int col[EPL][8];
 #pragma unroll
 		for (int e = 0; e < EPL; e++) {
-			double s = 0.0;
-			if (qrow[e] >= 0) {
-				for (int w2 = 0; w2 < qw; w2++) s += s_qv[qrow[e] * qw + w2] * s_st[s_qc[qrow[e] * qw + w2]];
-			}
-			gp[e] = g[e] - s;
+			const int4 *cp = (const int4 *)(s_qc + (qrow[e] >= 0 ? qrow[e] : 0) * 8);
+			const int4 c0 = cp[0], c1 = cp[1];
+			col[e][0] = c0.x; col[e][1] = c0.y; col[e][2] = c0.z; col[e][3] = c0.w; col[e][4] = c1.x; col[e][5] = c1.y; col[e][6] = 0; col[e][7] = 0;
+		}
+#pragma unroll
+		for (int e = 0; e < EPL; e++) {
+			const double2 *vp = (const double2 *)(s_qv + (qrow[e] >= 0 ? qrow[e] : 0) * 6);
+			const double2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
+			const double s = ((v0.x * s_st[col[e][0]] + v0.y * s_st[col[e][1]]) + (v1.x * s_st[col[e][2]] + v1.y * s_st[col[e][3]])) +
+			                 (v2.x * s_st[col[e][4]] + v2.y * s_st[col[e][5]]);
+			gp[e] = g[e] - (qrow[e] >= 0 ? s : 0.0);
 		}
 		nwt_wave_sync();
 	};
@@ -315,83 +335,99 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		}
 	};
 	// ---- the direction chain: slot j lives in the accumulator registers (j < NREG), in LDS (next NLDS) or in HBM ----
+	// (Tried: the register tier as a plain local array with static indices, left to the register allocator.  It first sank the NREG
+	// conditional stores into one store through a pointer phi -- the whole tier went to scratch -- and, with that prevented, still spilled
+	// 150-390 registers to scratch at 16-21 slots.  Hence the accumulator registers by hand, and an ISA audit in the build.)
 	auto slot_store = [&](int j, const double (&v)[EPL]) {
 		if (j < NREG) {
-			static_for<0, NREG>([&](auto Jc) {
+			static_for<0, NREG>([&](auto Jc) __attribute__((always_inline)) {
 				constexpr int J = decltype(Jc)::value;
 				if (j == J) {
-					static_for<0, EPL>([&](auto Ec) { constexpr int E = decltype(Ec)::value; areg_write<J * EPL + E>(v[E]); });
+					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; areg_write<J * EPL + E>(v[E]); });
 				}
 			});
 		} else if (j < NREG + NLDS) {
 #pragma unroll
-			for (int e = 0; e < EPL; e++) s_hl[((j - NREG) * EPL + e) * 64 + lane] = v[e];
+			for (int e = 0; e < EPL; e++) s_hl[((size_t)(j - NREG) * 64 + lane) * EPL + e] = v[e];
 		} else {
 #pragma unroll
 			for (int e = 0; e < EPL; e++) hbm[((size_t)(j - NREG - NLDS) * EPL + e) * 64 + lane] = v[e];
 		}
 	};
 	// tv += sum_j kappa_j d_j, kappa = (symmetric tridiagonal of the links) (d_j . v): DESIGN.md 4a.4, apply_dform of sqp_kernel
+	// LDS tier: [slot][lane][EPL] -- a lane's EPL doubles are contiguous (16-byte reads, conflict free: lane stride 12 dwords)
+	auto lds_get = [&](int j, double (&h)[EPL]) {
+		const double *p = s_hl + ((size_t)(j - NREG) * 64 + lane) * EPL;
+		if constexpr (EPL % 2 == 0) {
+#pragma unroll
+			for (int e = 0; e < EPL / 2; e++) { const double2 t2 = ((const double2 *)p)[e]; h[2 * e] = t2.x; h[2 * e + 1] = t2.y; }
+		} else {
+#pragma unroll
+			for (int e = 0; e < EPL; e++) h[e] = p[e];
+		}
+	};
+	auto dot = [&](const double (&h)[EPL], const double (&v)[EPL]) -> double {   // two chains: half the dependent latency
+		double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+		for (int e = 0; e < EPL; e++) { if (e & 1) a1 += h[e] * v[e]; else a0 += h[e] * v[e]; }
+		return a0 + a1;
+	};
+	// tv += sum_j kappa_j d_j, kappa = (symmetric tridiagonal of the links) (d_j . v): DESIGN.md 4a.4, apply_dform of sqp_kernel.
+	// On-chip slots: pass 1 (all dot products, 16 per butterfly), the kappa of every slot, pass 2 (axpys).  Slots in HBM are read ONCE:
+	// rounds of HG vectors through two register buffers, link by link (t += d_i (e delta_{i+1} + f delta_i) + d_{i+1} e delta_i), the
+	// first round requested before the on-chip passes start -- its latency hides behind them.
+	constexpr int H0 = NREG + NLDS, HG = 2;
 	auto sweep = [&](int ns, const double (&v)[EPL], double (&tv)[EPL]) {
 		if (ns < 2) return;   // a chain of one vector carries no update yet
+		const int nso = min(ns, H0);   // on-chip slots; the links nso-1 .. ns-2 belong to the HBM rounds
+		double hA[HG][EPL], hB[HG][EPL];
+		auto hload = [&](int base, double (&h)[HG][EPL]) {   // unconditional: past the end the newest vector again (its links are masked)
+#pragma unroll
+			for (int g2 = 0; g2 < HG; g2++) {
+				const double *p = hbm + (size_t)(min(base + g2, ns - 1) - H0) * EPL * 64 + lane;
+#pragma unroll
+				for (int e = 0; e < EPL; e++) h[g2][e] = p[e * 64];
+			}
+		};
+		if (ns > H0) hload(H0, hA);
 		double acc[16];
 #pragma unroll
 		for (int k = 0; k < 16; k++) acc[k] = 0.0;
-		auto flush = [&](int base) {   // slots base .. base+15 -> delta
+		auto flush = [&](int base) __attribute__((always_inline)) {   // slots base .. base+15 -> delta
 			const double tot = wave_sum_many<16>(acc, lane);
-			if (lane < 16 && base + lane < ns) s_dl[base + lane] = tot;
+			if (lane < 16 && base + lane < nso) s_dl[base + lane] = tot;
 #pragma unroll
 			for (int k = 0; k < 16; k++) acc[k] = 0.0;
 		};
 		// pass 1: delta_j = d_j . v
 		if constexpr (NREG > 0) {
-			static_for<0, NREG>([&](auto Jc) {
+			static_for<0, NREG>([&](auto Jc) __attribute__((always_inline)) {
 				constexpr int J = decltype(Jc)::value;
-				if (J < ns) {
+				if (J < nso) {
 					double h[EPL];
-					static_for<0, EPL>([&](auto Ec) { constexpr int E = decltype(Ec)::value; h[E] = areg_read<J * EPL + E>(); });
-					double a = 0.0;
-#pragma unroll
-					for (int e = 0; e < EPL; e++) a += h[e] * v[e];
-					acc[J & 15] = a;
+					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; h[E] = areg_read<J * EPL + E>(); });
+					acc[J & 15] = dot(h, v);
 				}
-				if ((J & 15) == 15 || J == NREG - 1) { if (J - (J & 15) < ns) flush(J - (J & 15)); }
+				if ((J & 15) == 15 || J == NREG - 1) { if (J - (J & 15) < nso) flush(J - (J & 15)); }
 			});
 		}
 		if constexpr (NLDS > 0) {
-			for (int base = NREG; base < min(ns, NREG + NLDS); base += 16) {
+			for (int base = NREG; base < nso; base += 16) {
 #pragma unroll
 				for (int u = 0; u < 16; u++) {
 					const int j = base + u;
-					if (u < NLDS && j < min(ns, NREG + NLDS)) {
-						double a = 0.0;
-#pragma unroll
-						for (int e = 0; e < EPL; e++) a += s_hl[((j - NREG) * EPL + e) * 64 + lane] * v[e];
-						acc[u] = a;
-					}
+					if (u < NLDS && j < nso) { double h[EPL]; lds_get(j, h); acc[u] = dot(h, v); }
 				}
 				flush(base);
 			}
 		}
-		for (int base = NREG + NLDS; base < ns; base += 16) {
-#pragma unroll
-			for (int u = 0; u < 16; u++) {
-				const int j = min(base + u, ns - 1);   // unconditional loads (a repeat past the end is masked below)
-				double a = 0.0;
-#pragma unroll
-				for (int e = 0; e < EPL; e++) a += hbm[((size_t)(j - NREG - NLDS) * EPL + e) * 64 + lane] * v[e];
-				acc[u] = base + u < ns ? a : 0.0;
-				if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four vectors in flight at a time, not sixteen
-			}
-			flush(base);
-		}
 		nwt_wave_sync();
 		// kappa_j = f_j delta_j + e_j delta_{j+1} + e_{j-1} delta_{j-1}; link i = (e_i, f_i) joins slots i and i + 1
 		double kap0 = 0.0;
-		for (int j = lane; j < ns; j += 64) {
+		for (int j = lane; j < nso; j += 64) {
 			const double dj = s_dl[j];
 			double k = 0.0;
-			if (j < ns - 1) k += s_lk[2 * j + 1] * dj + s_lk[2 * j] * s_dl[j + 1];
+			if (j < nso - 1) k += s_lk[2 * j + 1] * dj + s_lk[2 * j] * s_dl[j + 1];
 			if (j > 0) k += s_lk[2 * j - 2] * s_dl[j - 1];
 			s_kp[j] = k;
 			if (j == lane) kap0 = k;
@@ -399,26 +435,59 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		nwt_wave_sync();
 		// pass 2: tv += kappa_j d_j
 		if constexpr (NREG > 0) {
-			static_for<0, NREG>([&](auto Jc) {
+			static_for<0, NREG>([&](auto Jc) __attribute__((always_inline)) {
 				constexpr int J = decltype(Jc)::value;
-				if (J < ns) {
+				if (J < nso) {
 					const double kj = bcast(kap0, J);
-					static_for<0, EPL>([&](auto Ec) { constexpr int E = decltype(Ec)::value; tv[E] += kj * areg_read<J * EPL + E>(); });
+					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; tv[E] += kj * areg_read<J * EPL + E>(); });
 				}
 			});
 		}
 		if constexpr (NLDS > 0) {
-			for (int j = NREG; j < min(ns, NREG + NLDS); j++) {
+			for (int j = NREG; j < nso; j++) {
 				const double kj = s_kp[j];
+				double h[EPL]; lds_get(j, h);
 #pragma unroll
-				for (int e = 0; e < EPL; e++) tv[e] += kj * s_hl[((j - NREG) * EPL + e) * 64 + lane];
+				for (int e = 0; e < EPL; e++) tv[e] += kj * h[e];
 			}
 		}
-#pragma unroll 4
-		for (int j = NREG + NLDS; j < ns; j++) {
-			const double kj = s_kp[j];
+		if (ns > H0) {
+			// the chain's tail in HBM, one pass; carried in: the last on-chip slot and its dot product
+			double dc[EPL], dcl = 0.0;
 #pragma unroll
-			for (int e = 0; e < EPL; e++) tv[e] += kj * hbm[((size_t)(j - NREG - NLDS) * EPL + e) * 64 + lane];
+			for (int e = 0; e < EPL; e++) dc[e] = 0.0;
+			if constexpr (H0 > 0) {
+				if constexpr (NLDS > 0) lds_get(H0 - 1, dc);
+				else static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; dc[E] = areg_read<(NREG > 0 ? NREG - 1 : 0) * EPL + E>(); });
+				dcl = s_dl[H0 - 1];
+			}
+			auto consume = [&](int base, double (&h)[HG][EPL]) {
+				double ac[HG];
+#pragma unroll
+				for (int g2 = 0; g2 < HG; g2++) ac[g2] = dot(h[g2], v);
+				wave_sums<HG>(ac, lane);
+#pragma unroll
+				for (int g2 = 0; g2 < HG; g2++) {
+					const int i = base - 1 + g2;   // link i joins slot i (left) and slot i + 1 = base + g2 (right)
+					const bool on = i >= 0 && i < ns - 1;
+					const int ii = on ? i : 0;
+					const double le = on ? s_lk[2 * ii] : 0.0, lf = on ? s_lk[2 * ii + 1] : 0.0;
+					const double dl = g2 == 0 ? dcl : ac[g2 > 0 ? g2 - 1 : 0], dr = ac[g2];
+					const double ca = le * dr + lf * dl, cb = le * dl;
+#pragma unroll
+					for (int e = 0; e < EPL; e++) tv[e] += (g2 == 0 ? dc[e] : h[g2 > 0 ? g2 - 1 : 0][e]) * ca + h[g2][e] * cb;
+				}
+#pragma unroll
+				for (int e = 0; e < EPL; e++) dc[e] = h[HG - 1][e];
+				dcl = ac[HG - 1];
+			};
+			for (int base = H0; base < ns; base += 2 * HG) {
+				hload(base + HG, hB);
+				consume(base, hA);
+				if (base + HG >= ns) break;
+				hload(base + 2 * HG, hA);
+				consume(base + HG, hB);
+			}
 		}
 	};
 
@@ -449,7 +518,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		int inform = 4, iter = 0, nfev = 0, nupd = 0, ns = 0, state = ST_INIT;
 		bool headpair = false;   // the quasi-Newton memory was restarted at an accepted step: its first pair is not in the span of the chain
 		unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
-#define NTGW_STAMP(slot_) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot_] += now_ - tlast; tlast = now_; } } while (0)
+		// phase clock: the value a phase ends on is made opaque first, so that the phase's arithmetic cannot sink below the clock read
+#define NTGW_STAMPV(slot_, val_) do { if (sp.stamps) { asm volatile("" ::"v"(val_)); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot_] += now_ - tlast; tlast = now_; } } while (0)
+#define NTGW_STAMP(slot_) NTGW_STAMPV(slot_, x[0])
 		if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
 		// ---- scope check: every linear row is an equality (lower == upper), see sqp_kernel ----
 		{
@@ -500,14 +571,15 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				// ================= the one evaluation site =================
 				double part[3] = {0.0, 0.0, 0.0};
 				evaluate(xt, g, part[0], part[1]);
-				NTGW_STAMP(1);
+				NTGW_STAMPV(1, g[0] + part[0] + part[1]);
 				if (state != ST_FINAL) {
 					project(g, gpt);
 #pragma unroll
 					for (int e = 0; e < EPL; e++) part[2] += gpt[e] * (-d[e]);
-					NTGW_STAMP(2);
+					NTGW_STAMPV(2, part[2]);
 				}
 				wave_sums<3>(part, lane);
+				NTGW_STAMPV(6, part[0] + part[1] + part[2]);
 				const double Fn = part[0], gn2n = part[1];
 #ifdef NTGW_DEBUG
 				if (lane == 0 && nfev < 40) printf("b %d state %d iter %d nfev %d ns %d F %.10g g2 %.6g slope %.6g a %.6g\n", b, state, iter, nfev, ns, Fn, gn2n, part[2], ls_a);
@@ -555,6 +627,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						if (lane == 0) lsb[lsi ^ 1] = lsr;
 						lsi ^= 1;
 						nwt_wave_sync();
+						NTGW_STAMPV(7, ls_a);
 					}
 					if (rc == 0 || rc == 2) {
 						if (rc == 2) state = ST_FORCE;
@@ -595,9 +668,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						if (ns == 0 && !headpair) { slot_store(0, d); ns = 1; }   // a chain starts: d_0 = the direction of this step
 						NTGW_STAMP(5);
 						apply_w0(gpt, tv);
-						NTGW_STAMP(4);
+						NTGW_STAMPV(4, tv[0]);
 						sweep(ns, gpt, tv);
-						NTGW_STAMP(3);
+						NTGW_STAMPV(3, tv[0]);
 						double r6[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
 						for (int e = 0; e < EPL; e++) {
@@ -726,6 +799,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			nwt_wave_sync();
 		}
 #undef NTGW_STAMP
+#undef NTGW_STAMPV
 		if (lane == 0) {
 			if (A.objective) A.objective[b] = F;
 			if (A.inform) A.inform[b] = inform;
@@ -750,7 +824,7 @@ static inline bool wave_match(const NtgDims &D, const NtgTables &T, const SolveP
 	if (D.ncoef[0] != (K / 2) * D.ig_n + K / 2) return false;
 	if ((D.ig_n + 1) * (D.nout / opl) > 64) return false;
 	if (D.mE != D.nclin || D.mE > 64) return false;
-	if (D.mE > 0 && !D.q_use) return false;
+	if (D.mE > 0 && (!D.q_use || D.q_w > 6)) return false;
 	if (T.pp_rowv || T.pp_bps || T.pp_q) return false;   // per-problem grids: sqp_kernel
 	if (sp.hessian == 1 && !(T.n0b && T.n0b_n == D.ncoef[0])) return false;
 	if (sp.hessian == 2) return false;

@@ -3,6 +3,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ntg_amd import api, configs as cf
+api.LIB_PATH = os.environ.get("NTG_AMD_LIB", api.LIB_PATH)   # variant builds (tools/mkvariant.sh)
 
 def run(spec, ncars, B, opts, reps=5):
     dev = torch.device("cuda:0")
