@@ -34,7 +34,7 @@ size_t wave_lds(const NtgDims &D, int nwv, int cap, int nlds, int epl)
 	return tab + (size_t)nwv * wave_priv_doubles(D.nC, cap, nlds, epl) * 8;
 }
 
-constexpr int FAT_NLDS = 9, LEAN_NLDS = 2;
+constexpr int FAT_NLDS = 10, FAT_NLDS2 = 6, LEAN_NLDS = 2;   // FAT_NLDS2: the instance for long chains (their scalars take more of the LDS)
 
 }   // namespace
 
@@ -51,14 +51,17 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 	w->nwv = 4;
 	if (w->fat) {
 		const int nreg = (256 - NTGW_ABASE) / (2 * epl);
-		w->lds = wave_lds(D, 4, w->cap, FAT_NLDS, epl);
+		w->nlds = FAT_NLDS;
+		w->lds = wave_lds(D, 4, w->cap, w->nlds, epl);
+		if (w->lds > 160 * 1024) { w->nlds = FAT_NLDS2; w->lds = wave_lds(D, 4, w->cap, w->nlds, epl); }
 		if (w->lds > 160 * 1024) w->fat = 0;
 		else {
-			w->hbm_slots = std::max(0, w->cap - nreg - FAT_NLDS);
+			w->hbm_slots = std::max(0, w->cap - nreg - w->nlds);
 			w->grid = std::max(1, std::min((batch + 3) / 4, ncu));   // one workgroup per CU: four waves, one per SIMD
 		}
 	}
 	if (!w->fat) {
+		w->nlds = LEAN_NLDS;
 		w->lds = wave_lds(D, 4, w->cap, LEAN_NLDS, epl);
 		if (w->lds > 160 * 1024) return false;
 		w->hbm_slots = std::max(0, w->cap - LEAN_NLDS);
@@ -72,10 +75,16 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
 {
 	if (!a.counter) return hipErrorInvalidValue;
+	constexpr int R3 = (256 - NTGW_ABASE) / 6, R6 = (256 - NTGW_ABASE) / 12;
+	if (w.fat && w.nlds == FAT_NLDS) {
+		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, FAT_NLDS, false>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, FAT_NLDS, false>(D, T, sp, a, w);
+		return launch_one<6, 2, 4, 1, R6, FAT_NLDS, false>(D, T, sp, a, w);
+	}
 	if (w.fat) {
-		if (D.nout == 2) return launch_one<2, 1, 4, 1, (256 - NTGW_ABASE) / 6, FAT_NLDS, false>(D, T, sp, a, w);
-		if (D.nout == 4) return launch_one<4, 2, 4, 1, (256 - NTGW_ABASE) / 12, FAT_NLDS, false>(D, T, sp, a, w);
-		return launch_one<6, 2, 4, 1, (256 - NTGW_ABASE) / 12, FAT_NLDS, false>(D, T, sp, a, w);
+		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, FAT_NLDS2, false>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, FAT_NLDS2, false>(D, T, sp, a, w);
+		return launch_one<6, 2, 4, 1, R6, FAT_NLDS2, false>(D, T, sp, a, w);
 	}
 	if (D.nout == 2) return launch_one<2, 1, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
 	if (D.nout == 4) return launch_one<4, 2, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);

@@ -21,10 +21,6 @@
 #pragma once
 #include "solve_impl.hpp"
 
-#ifndef NTGW_EVU
-#define NTGW_EVU 1   // unroll factor of the evaluation's loop over an interval's breakpoint slots
-#endif
-
 namespace ntgw {
 
 template <int J, int N, class F>
@@ -50,7 +46,7 @@ __device__ __forceinline__ double from_next(double v)
 // The register allocator hands out accumulator registers from a0 upwards when the 256 architectural VGPRs run short (AV-class values:
 // load results, copies).  It cannot be told to keep out, so the chain starts at a[NTGW_ABASE]: a0 .. a[NTGW_ABASE - 1] are the compiler's,
 // and ntg_amd/isa_audit.py fails the build if compiler-generated code touches anything from a[NTGW_ABASE] up.
-#define NTGW_ABASE 32
+#define NTGW_ABASE 16
 // accumulator registers a[ABASE + 2 IDX], a[ABASE + 2 IDX + 1] as one double.  The kernel lists a0..a255 as clobbers once (which makes
 // the kernel descriptor allocate them all).
 template <int IDX>
@@ -106,11 +102,11 @@ struct WaveArgs {
 
 // LDS (doubles) of one workgroup: tables, then per wave [stage | tmp | delta | kappa | links | line search | chain tier]
 template <int NCH, int K, int NINT>
-__host__ __device__ constexpr int wave_tab_doubles() { return NCH * 6 * K * NINT + 2 * 6 * NINT; }
+__host__ __device__ constexpr int wave_tab_doubles() { return NCH * 6 * K * (NINT + 1) + 2 * 6 * (NINT + 1); }
 __host__ __device__ inline int wave_priv_doubles(int nC, int cap, int nlds, int epl)
 {
 	const int capp = (cap + 3) & ~3;
-	return ((nC + 3) & ~3) + 128 + 4 * capp + 48 + nlds * epl * 64;
+	return ((nC + 3) & ~3) + (4 * capp > 128 ? 4 * capp : 128) + 48 + nlds * epl * 64;   // (the feasibility / multiplier scratch shares the delta / kappa / link area)
 }
 
 template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS>
@@ -127,23 +123,23 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int P = D.P, m = D.mE, cap = A.cap, capp = (cap + 3) & ~3, qw = D.q_w;
 	// ---- shared tables ----
-	double *s_bt = (double *)smem_raw;                      // [NCH][SMAX][K][NINT] basis values of the CHM channels per interval slot
-	double *s_wt = s_bt + NCH * SMAX * K * NINT;            // [SMAX][NINT] trapezoid node weights
-	double *s_dt = s_wt + SMAX * NINT;                      // [SMAX][NINT] interval lengths
-	double *s_qv = s_dt + SMAX * NINT;                      // [q_nt][q_w] projector rows (ELL)
+	double *s_bt = (double *)smem_raw;                      // [NCH][SMAX][K][NL] basis values of the CHM channels per interval slot; column NINT = 0
+	double *s_wt = s_bt + NCH * SMAX * K * NL;              // [SMAX][NL] trapezoid node weights
+	double *s_dt = s_wt + SMAX * NL;                        // [SMAX][NL] interval lengths
+	double *s_qv = s_dt + SMAX * NL;                        // [q_nt][6] projector rows (ELL)
 	int *s_qc = (int *)(s_qv + D.q_nt * 6);                // [q_nt][8]
 	double *s_priv0 = (double *)(s_qc + D.q_nt * 8);
-	for (int e = tid; e < NCH * SMAX * K * NINT; e += 64 * NWV) {
-		const int t = e % NINT, q = (e / NINT) % K, s2 = (e / (NINT * K)) % SMAX, ch = e / (NINT * K * SMAX);
+	for (int e = tid; e < NCH * SMAX * K * NL; e += 64 * NWV) {
+		const int t = e % NL, q = (e / NL) % K, s2 = (e / (NL * K)) % SMAX, ch = e / (NL * K * SMAX);
 		int r = 0, seen = -1;
 		for (int rr = 0; rr < DM; rr++) if ((CHM >> rr) & 1) { seen++; if (seen == ch) r = rr; }
-		const int i = D.igb[t] + s2;
-		s_bt[e] = i < D.igb[t + 1] ? T.rowv[D.ch_row0[r] + q * P + i] : 0.0;
+		const int i = t < NINT ? D.igb[t] + s2 : P;
+		s_bt[e] = (t < NINT && i < D.igb[t + 1]) ? T.rowv[D.ch_row0[r] + q * P + i] : 0.0;
 	}
-	for (int e = tid; e < SMAX * NINT; e += 64 * NWV) {
-		const int t = e % NINT, s2 = e / NINT, i = D.igb[t] + s2;
+	for (int e = tid; e < SMAX * NL; e += 64 * NWV) {
+		const int t = e % NL, s2 = e / NL, i = t < NINT ? D.igb[t] + s2 : P;
 		double w = 0.0, dt = 0.0;
-		if (i < D.igb[t + 1]) {   // trapezoid weight of node i: integrator.c:21-24 regrouped per node
+		if (t < NINT && i < D.igb[t + 1]) {   // trapezoid weight of node i: integrator.c:21-24 regrouped per node
 			if (i > 0) w += (T.bps[i] - T.bps[i - 1]) / 2;
 			if (i < P - 1) { w += (T.bps[i + 1] - T.bps[i]) / 2; dt = T.bps[i + 1] - T.bps[i]; }
 		}
@@ -154,17 +150,18 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	__syncthreads();   // the only workgroup barrier: from here on the waves are independent
 	// ---- this wave's private LDS ----
 	double *s_st = s_priv0 + (size_t)wave * wave_priv_doubles(nC, cap, NLDS, EPL);   // [nC] staging in the natural layout (output-major)
-	double *s_tmp = s_st + ((nC + 3) & ~3);    // [128]
-	double *s_dl = s_tmp + 128;                // [capp] d_j . v
+	double *s_tmp = s_st + ((nC + 3) & ~3);    // [128] scratch of the feasibility step and of the final multipliers: used before / after the chain exists,
+	double *s_dl = s_tmp;                      // [capp] d_j . v     ... so it shares the chain's scalar area
 	double *s_kp = s_dl + capp;                // [capp] kappa_j
 	double *s_lk = s_kp + capp;                // [capp][2] links (e_i, f_i)
-	LineSearch *lsb = (LineSearch *)(s_lk + 2 * capp);   // 2 copies (48 doubles reserved)
-	double *s_hl = s_lk + 2 * capp + 48;       // [NLDS][EPL][64]
+	const int scal = 4 * capp > 128 ? 4 * capp : 128;
+	LineSearch *lsb = (LineSearch *)(s_tmp + scal);   // 2 copies (48 doubles reserved)
+	double *s_hl = s_tmp + scal + 48;          // [NLDS][lane][EPL]
 	// ---- lane roles ----
 	const int og = lane / NL, t = lane - og * NL, o0 = og * OPL;
 	const bool lane_on = lane < LP, has_int = lane_on && t < NINT;
-	const int tt = min(t, NINT - 1);
-	const int cnt = has_int ? D.igb[tt + 1] - D.igb[tt] : 0, i0 = D.igb[tt];
+	const int tt = has_int ? t : NINT;   // column of the interval tables (NINT: the all-zero column)
+	const int cnt = has_int ? D.igb[t + 1] - D.igb[t] : 0, i0 = has_int ? D.igb[t] : 0;
 	const int cbase = lane_on ? o0 * nco + S * t : 0;   // owned coefficient (o, q): cbase + o nco + q
 	int qrow[EPL];                                      // row of the owned coefficient in the compact projector, or -1
 #pragma unroll
@@ -183,12 +180,18 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		for (int o = 0; o < OPL; o++)
 #pragma unroll
 			for (int q = 0; q < S; q++) { xb[o][q] = xt[o * S + q]; xb[o][S + q] = from_next(xt[o * S + q]); pg[o][q] = 0.0; pg[o][S + q] = 0.0; }
-		auto slot = [&](int s2) __attribute__((always_inline)) -> double {
-			double bb[NCH][K];
+		// One breakpoint slot of the lane's interval: basis values (and weight, interval length) from the shared tables, flag, cost
+		// functor, the slot's share of the gradient.  The loads of slot s + 1 are issued before slot s is computed (two register
+		// buffers, the loop fully unrolled): with one wave per SIMD nothing else hides the LDS latency.  Lanes without an interval read
+		// the tables' all-zero column: no exec masking anywhere.
+		auto slot_load = [&](int s2, double (&bb)[NCH][K], double &w, double &dt) __attribute__((always_inline)) {
 #pragma unroll
 			for (int ch = 0; ch < NCH; ch++)
 #pragma unroll
-				for (int q = 0; q < K; q++) bb[ch][q] = s_bt[((ch * SMAX + s2) * K + q) * NINT + tt];
+				for (int q = 0; q < K; q++) bb[ch][q] = s_bt[((ch * SMAX + s2) * K + q) * NL + tt];
+			w = s_wt[s2 * NL + tt]; dt = s_dt[s2 * NL + tt];
+		};
+		auto slot_compute = [&](int s2, const double (&bb)[NCH][K], double w) __attribute__((always_inline)) -> double {
 			double z[NZL], df[NZL], fval = 0.0;
 #pragma unroll
 			for (int o = 0; o < OPL; o++)
@@ -202,7 +205,6 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 					z[DM * o + r] = acc;
 				}
 			Fam::ucf(OPL, i0 + s2, z, fval, df);
-			const double w = has_int ? s_wt[s2 * NINT + tt] : 0.0;   // lanes without an interval (t = nint, idle lanes) contribute nothing
 #pragma unroll
 			for (int o = 0; o < OPL; o++)
 #pragma unroll
@@ -217,15 +219,25 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		};
 		double Fp = 0.0;
 		{
-			double fprev = slot(0), dtprev = has_int ? s_dt[tt] : 0.0;
+			double bbA[NCH][K], bbB[NCH][K], wA, wB, dtA, dtB;
+			slot_load(0, bbA, wA, dtA);
+			slot_load(1, bbB, wB, dtB);
+			double fprev = slot_compute(0, bbA, wA), dtprev = dtA;
 			double fnext = from_next(fprev);
 			if (t >= NINT - 1) fnext = 0.0;
-#pragma unroll(NTGW_EVU)
-			for (int s2 = 1; s2 < SMAX; s2++) {
-				const double fval = slot(s2);
+			static_for<1, SMAX>([&](auto Sc) __attribute__((always_inline)) {
+				constexpr int s2 = decltype(Sc)::value;
+				double fval;
+				if constexpr (s2 & 1) {
+					if constexpr (s2 + 1 < SMAX) slot_load(s2 + 1, bbA, wA, dtA);
+					fval = slot_compute(s2, bbB, wB);
+				} else {
+					if constexpr (s2 + 1 < SMAX) slot_load(s2 + 1, bbB, wB, dtB);
+					fval = slot_compute(s2, bbA, wA);
+				}
 				Fp += dtprev * ((s2 < cnt ? fval : fnext) + fprev) / 2;
-				fprev = fval; dtprev = has_int ? s_dt[s2 * NINT + tt] : 0.0;
-			}
+				fprev = fval; dtprev = (s2 & 1) ? dtB : dtA;
+			});
 			Fp += dtprev * (fnext + fprev) / 2;
 		}
 		Fq = Fp; g2 = 0.0;
