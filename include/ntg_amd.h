@@ -86,7 +86,8 @@ typedef struct {
 	                     * singular on the null space of the equality rows, e.g. a plan without equality rows),
 	                     * 2 structured Newton step for nonlinear trajectory rows: band model of the augmented Lagrangian's Hessian,
 	                     *   assembled and factored on the matrix cores at every major (families with second-order blocks: obstacle,
-	                     *   quadrotor, manipulator; acts as 1 where it does not apply) -- the mode meant for BASELINE's configs D and E */
+	                     *   quadrotor, manipulator; acts as 1 where it does not apply, e.g. more coupling groups than a
+	                     *   workgroup has wavefronts) -- the robust mode for BASELINE's configs D and E (for E the quasi-Newton mode 1 can be the faster one) */
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
 	int block_threads;  /* 0 = auto (128/256/512) */
 	int qn_memory;      /* quasi-Newton updates kept before the approximation restarts from W0; <= 0: 256 */
@@ -151,8 +152,8 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
  * structure must be the plan's: one basis class, and every breakpoint in the same knot interval as in the plan's grid (checked;
  * NTG_E_BADARG otherwise) -- the index tables stay shared, the VALUES (basis blocks, trapezoid weights, linear-constraint rows,
  * (A A')^-1, projector, with_precond != 0: the preconditioner blocks) become per problem.  Plans with linear equality rows only.
- * Afterwards ntg_batch_eval / ntg_batch_solve of exactly `batch` problems use these grids (hessian = 2 acts as 1; ntg_batch_interp and
- * ntg_batch_mpc_run refuse) until ntg_plan_clear_grids(). */
+ * Afterwards ntg_batch_eval / ntg_batch_solve of exactly `batch` problems use these grids (hessian = 2 acts as 1; ntg_batch_interp,
+ * ntg_batch_mpc_shift and ntg_batch_mpc_run refuse with NTG_E_UNSUPPORTED: they work on the plan's shared grid) until ntg_plan_clear_grids(). */
 int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream);
 void ntg_plan_clear_grids(ntg_plan *p);
 
@@ -172,7 +173,8 @@ int ntg_batch_kincar_reverse(const ntg_plan *p, int batch, int ntimes, const dou
 /* Receding-horizon step (the warm-start use NPSOL's istate/clambda/R were meant for, ntg.h:64-68):
  * re-pin the linear initial-constraint bounds of every problem to the flat flag of its current
  * solution at breakpoint shift_bp, and shift the coefficients by shift_knots knot intervals
- * (tail = last coefficient) as the next initial guess.  d_x, d_lower, d_upper are updated in place. */
+ * (tail = last coefficient) as the next initial guess.  d_x, d_lower, d_upper are updated in place.  Shared grid only
+ * (NTG_E_UNSUPPORTED after ntg_plan_set_grids). */
 int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, int shift_knots, double *d_x,
                         double *d_lower, double *d_upper, void *stream);
 

@@ -34,7 +34,13 @@ size_t wave_lds(const NtgDims &D, int nwv, int cap, int nlds, int epl)
 	return tab + (size_t)nwv * wave_priv_doubles(D.nC, cap, nlds, epl) * 8;
 }
 
-constexpr int FAT_NLDS = 10, FAT_NLDS2 = 6, LEAN_NLDS = 2;   // FAT_NLDS2: the instance for long chains (their scalars take more of the LDS)
+#ifndef NTGW_LEAN_NLDS
+#define NTGW_LEAN_NLDS 2
+#endif
+#ifndef NTGW_LEAN_MINW
+#define NTGW_LEAN_MINW 2
+#endif
+constexpr int FAT_NLDS = 10, FAT_NLDS2 = 6, LEAN_NLDS = NTGW_LEAN_NLDS, LEAN_MINW = NTGW_LEAN_MINW;   // FAT_NLDS2: the instance for long chains (their scalars take more of the LDS)
 
 }   // namespace
 
@@ -65,7 +71,7 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 		w->lds = wave_lds(D, 4, w->cap, LEAN_NLDS, epl);
 		if (w->lds > 160 * 1024) return false;
 		w->hbm_slots = std::max(0, w->cap - LEAN_NLDS);
-		const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / w->lds));
+		const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(LEAN_MINW, (160 * 1024) / w->lds));
 		w->grid = std::max(1, std::min((batch + 3) / 4, ncu * wg_per_cu));
 	}
 	w->hist_doubles = (size_t)w->grid * w->nwv * w->hbm_slots * epl * 64;
@@ -86,7 +92,7 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, FAT_NLDS2, false>(D, T, sp, a, w);
 		return launch_one<6, 2, 4, 1, R6, FAT_NLDS2, false>(D, T, sp, a, w);
 	}
-	if (D.nout == 2) return launch_one<2, 1, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
-	if (D.nout == 4) return launch_one<4, 2, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
-	return launch_one<6, 2, 4, 2, 0, LEAN_NLDS, true>(D, T, sp, a, w);
+	if (D.nout == 2) return launch_one<2, 1, 4, LEAN_MINW, 0, LEAN_NLDS, true>(D, T, sp, a, w);
+	if (D.nout == 4) return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true>(D, T, sp, a, w);
+	return launch_one<6, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true>(D, T, sp, a, w);
 }

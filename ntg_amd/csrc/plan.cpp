@@ -763,6 +763,13 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	sp->ls_mu = o->ls_mu > 0 ? o->ls_mu : 1e-4; sp->ls_eta = o->ls_eta > 0 ? o->ls_eta : 0.9;
 	int t = o->block_threads;
 	if (t != 128 && t != 256 && t != 512) t = auto_threads(D);
+	// the structured Newton mode runs one wavefront per coupling group: a workgroup too small for the plan's groups grows to hold them, and a
+	// plan with more groups than the largest workgroup has waves takes the collocation preconditioner (decided here, once: workspace, layout
+	// and launch all see the same mode)
+	if (sp->hessian == 2) {
+		while (t < 512 && D.nwt_ngrp * 64 > t) t *= 2;
+		if (D.nwt_ngrp * 64 > t) sp->hessian = 1;
+	}
 	*nt = t;
 	return 0;
 }
@@ -1127,11 +1134,21 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 				std::vector<char> seen((size_t)m * n, 0);
 				for (int i = 0; i < m; i++) for (int eidx = p->h_csr_ptr[i]; eidx < p->h_csr_ptr[i + 1]; eidx++) { cr[eidx] = AE[(size_t)i * n + p->h_csr_col[eidx]]; seen[(size_t)i * n + p->h_csr_col[eidx]] = 1; }
 				for (int c = 0; c < n; c++) for (int eidx = p->h_csc_ptr[c]; eidx < p->h_csc_ptr[c + 1]; eidx++) cc[eidx] = AE[(size_t)p->h_csc_row[eidx] * n + c];
-				for (size_t t = 0; t < (size_t)m * n; t++) if (!seen[t] && std::fabs(AE[t]) > 1e-300) { err.store(1); break; }
+				// ... up to rounding: a final breakpoint one ulp past the last knot (cumulative-add linspace, ntg.c:385-388) leaves ~1e-16
+				// basis values where the plan has exact zeros -- the same relative threshold as build_newton_tables() (the solve re-projects)
+				{
+					bool outside = false;
+					for (int i = 0; i < m && !outside; i++) {
+						double rmax = 0.0;
+						for (int c = 0; c < n; c++) rmax = std::max(rmax, std::fabs(AE[(size_t)i * n + c]));
+						for (int c = 0; c < n; c++) if (!seen[(size_t)i * n + c] && std::fabs(AE[(size_t)i * n + c]) > 1e-10 * rmax) { outside = true; break; }
+					}
+					if (outside) { err.store(1); continue; }   // (the loop head sees err and stops this worker)
+				}
 				// (A A')^-1
 				S.assign((size_t)m * m, 0.0);
 				for (int i = 0; i < m; i++) for (int j = 0; j <= i; j++) { double a = 0.0; for (int c = 0; c < n; c++) a += AE[(size_t)i * n + c] * AE[(size_t)j * n + c]; S[(size_t)i * m + j] = a; S[(size_t)j * m + i] = a; }
-				if (!chol_lower(S, m)) { err.store(2); break; }
+				if (!chol_lower(S, m)) { err.store(2); continue; }
 				Sinv.assign((size_t)m * m, 0.0);
 				for (int j = 0; j < m; j++) { std::fill(col.begin(), col.end(), 0.0); col[j] = 1.0; chol_solve(S, m, col.data()); for (int i = 0; i < m; i++) Sinv[(size_t)i * m + j] = col[i]; }
 				for (int i = 0; i < m; i++) for (int j = 0; j < i; j++) { const double a = 0.5 * (Sinv[(size_t)i * m + j] + Sinv[(size_t)j * m + i]); Sinv[(size_t)i * m + j] = a; Sinv[(size_t)j * m + i] = a; }
@@ -1241,6 +1258,9 @@ extern "C" int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, i
 	if (batch <= 0) return 0;
 	if (!d_x || !d_lower || !d_upper) return fail(NTG_E_BADARG, "null argument");
 	if (shift_bp < 0 || shift_bp >= p->D.P || shift_knots < 0) return fail(NTG_E_BADARG, "shift out of range");
+	// the shift re-pins the initial bounds with the basis blocks of the plan's SHARED grid (T.blk / T.off): with per-problem grids that would
+	// be the wrong grid's values, silently
+	if (p->grid_batch) return fail(NTG_E_UNSUPPORTED, "the receding-horizon shift works on the plan's shared grid: clear the per-problem grids first");
 	HIPCHK(hipSetDevice(p->device));
 	HIPCHK(ntg_launch_mpc_shift(p->D, p->T, batch, shift_bp, shift_knots, p->d_lic, d_x, d_lower, d_upper, (hipStream_t)stream));
 	return 0;

@@ -120,3 +120,23 @@ def test_grid_structure_mismatch_is_refused():
     kq, bq = grids_for(sq, 2)
     with pytest.raises(api.NtgError, match="linear equality"):
         q.set_grids(dev(kq), dev(bq))
+
+
+def test_mpc_shift_refuses_per_problem_grids():
+    """The receding-horizon shift re-pins the initial bounds with the basis blocks of the plan's shared grid: after
+    ntg_plan_set_grids it must refuse (like ntg_batch_interp and ntg_batch_mpc_run), not use the wrong grid silently."""
+    spec = cf.config_B()
+    nb = 4
+    knots, bps = grids_for(spec, nb)
+    p = api.Plan(spec, 0)
+    lo, up = cf.kincar_random_bounds(1, nb)
+    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    lo_d, up_d = dev(lo), dev(up)
+    p.mpc_shift(x, lo_d, up_d, 5, 1)                       # shared grid: fine
+    p.set_grids(dev(knots), dev(bps), with_precond=False)
+    x0, lo0 = x.clone(), lo_d.clone()
+    with pytest.raises(api.NtgError, match="shared grid"):
+        p.mpc_shift(x, lo_d, up_d, 5, 1)
+    assert torch.equal(x, x0) and torch.equal(lo_d, lo0)   # nothing was touched
+    p.clear_grids()
+    p.mpc_shift(x, lo_d, up_d, 5, 1)

@@ -57,11 +57,14 @@ def test_newton_solve_matches_oracle(name, nb):
     torch.cuda.synchronize()
     ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(hessian=2), nthreads=8)
     inf = out["inform"].cpu().numpy(); it = out["iters"].cpu().numpy(); obj = out["objective"].cpu().numpy()
-    # inform 1 ("optimal, not to the requested accuracy": the line search ran out of representable decrease) may hit either
-    # side at a different rounding; the comparison is over the problems both call optimal
-    assert np.isin(inf, (0, 1)).all() and np.isin(ref["inform"], (0, 1)).all()
+    # The device calls every problem of these batches optimal (inform 0).  The oracle ends one E2 problem with inform 1 ("optimal, not
+    # to the requested accuracy": its last line search ran out of representable decrease at a different rounding) -- the counts are
+    # explicit, and EVERY problem both sides call optimal is compared (round 2 allowed 10 % to drop out).
+    ref_inform1 = {"O": 0, "D2": 0, "E2": 1}[name]
+    assert (inf == 0).all(), inf
+    assert np.isin(ref["inform"], (0, 1)).all() and int((ref["inform"] == 1).sum()) == ref_inform1, ref["inform"]
     ok = (inf == 0) & (ref["inform"] == 0)
-    assert ok.mean() >= 0.9
+    assert int(ok.sum()) == nb - ref_inform1
     assert np.abs(it - ref["iters"])[ok].max() <= 3, (it, ref["iters"])
     assert (np.abs(obj - ref["objective"]) <= 1e-9 * np.abs(ref["objective"]))[ok].all()
     assert np.abs(x.cpu().numpy() - ref["x"])[ok].max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
