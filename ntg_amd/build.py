@@ -33,6 +33,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             continue
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", path, "-o", obj,
                "-I", os.path.join(HERE, "..", "include"), "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
+        if src.endswith(".hip"):
+            cmd += ["-save-temps=obj", "-Wno-unused-command-line-argument"]   # keeps the device assembly next to the object: audited below
         if verbose:
             cmd += ["-Rpass-analysis=kernel-resource-usage"]
         cmd += os.environ.get("NTG_AMD_CXXFLAGS", "").split()   # e.g. -DNTG_HIST_G=8 for tuning experiments
@@ -47,10 +49,27 @@ def build(force: bool = False, verbose: bool = False) -> str:
             sys.stderr.write(open(obj + ".log").read())
     if failed:
         raise RuntimeError("hipcc failed for " + ", ".join(failed))
+    # call boundaries of the device code (no generic pointers into the private segment, no FLAT in out-of-line functions, no dynamic
+    # stack: ntg_amd/call_audit.py says why); the other intermediate files of -save-temps are removed
+    from . import call_audit
+    bad = []
+    for src in SOURCES:
+        stem = os.path.splitext(src)[0]
+        asm = os.path.join(CSRC, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")
+        if os.path.exists(asm):
+            bad += call_audit.audit(asm)
+        for f in os.listdir(CSRC):
+            if f.startswith(stem + "-hip-") or f.startswith(stem + "-host-") or f.startswith(stem + ".hip-"):
+                if not f.endswith("gfx950.s"):
+                    os.remove(os.path.join(CSRC, f))
+    if bad:
+        raise RuntimeError("call-boundary audit failed:\n  " + "\n  ".join(bad[:20]))
     # the wave kernels address accumulator registers by hand: the compiler's own code must stay below their base
     from . import isa_audit
+    wave_asm = os.path.join(CSRC, "fam_kincar_wave-hip-amdgcn-amd-amdhsa-gfx950.s")
     bad = isa_audit.audit(hipcc, os.path.join(CSRC, "fam_kincar_wave.hip"), os.path.join(HERE, "..", "include"),
-                          os.environ.get("NTG_AMD_CXXFLAGS", "").split(), isa_audit.agpr_base(os.path.join(CSRC, "solve_wave.hpp")))
+                          os.environ.get("NTG_AMD_CXXFLAGS", "").split(), isa_audit.agpr_base(os.path.join(CSRC, "solve_wave.hpp")),
+                          asm_path=wave_asm if os.path.exists(wave_asm) else None)
     if bad:
         raise RuntimeError("ISA audit of fam_kincar_wave.hip failed (compiler-generated code in the hand-managed AGPR range, or spills):\n  " + "\n  ".join(bad[:20]))
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)

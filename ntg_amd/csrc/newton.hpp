@@ -35,10 +35,22 @@ typedef __attribute__((address_space(3))) double *nwt_lds_dp;
 // (s_waitcnt lgkmcnt(0)) waited for the band rows prefetched for the next block column.
 typedef __attribute__((address_space(1))) double *nwt_glb_dp;
 typedef const __attribute__((address_space(1))) double *nwt_glb_cdp;
-// The factorisation and the assembly are inlined into the solve kernel; only the triangular solves are kept out of line.
-// (With all three out of line the tuned quadrotor instance faulted on the GPU -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION
-// on a flat access -- although every index checked out; inlined, the same code runs clean.  Treated as a code-generation
-// hazard of calls under this register pressure)
+// The assembly is inlined into the solve kernel; the factorisation (nwt_factor_wave) and the triangular solves (nwt_solve_wave) are out
+// of line (own register allocation) and take every pointer with its address space in the type.
+// Round 2 met HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in a build with all three routines out of line.  That build, reconstructed
+// (commit 24d0f74 with NWT_FN = noinline, compiled for gfx950 and read statically, round 3): nwt_assemble took `const NtgDims &` /
+// `const NtgTables &`; the kernel's by-value arguments live in a PRIVATE (scratch) copy once their address escapes, so the call passed
+// a generic pointer into the private segment (`v_mov v0, 0xa0; v1 = src_private_base.hi` at the call site) and the callee read the
+// dimensions with 31 FLAT loads through the private aperture -- under a 2 336 + 332 byte scratch frame, 297 VGPR and 359 SGPR spills
+// around the calls, band and LDS scratch as generic pointers too (171 + 114 FLAT loads in the factorisation and the solves).  The
+// descriptor was consistent (private segment 2 668 B = frame + largest callee frame, no dynamic stack, no AGPRs): nothing the compiler
+// emitted was wrong on paper, and the fault itself cannot be replayed statically.  What can be said: the ONLY class of access the
+// faulting build had and every clean build lacks is FLAT through the private aperture to a kernel-argument copy, reached through
+// SGPR-spilled aperture bases.  The shipped code excludes the whole class by construction, and ntg_amd/call_audit.py checks the
+// assembly of every translation unit for it at build time:
+//   R1 no generic pointer into the private segment is ever formed (no src_private_base anywhere);
+//   R2 out-of-line device functions contain no FLAT instruction (address-space-typed parameters, structs by value in registers);
+//   R3 no dynamic stack.
 #define NWT_FN __device__ __forceinline__
 #ifdef NWT_CHECK   // debugging aid: report an out-of-range band index instead of touching memory
 #define NWT_IDX(i, lim, tag) (((long long)(i) >= 0 && (long long)(i) < (long long)(lim)) ? (size_t)(i) : (printf("NWT index %s: %lld of %lld (blk %d thr %d)\n", tag, (long long)(i), (long long)(lim), (int)blockIdx.x, (int)threadIdx.x), (size_t)0))

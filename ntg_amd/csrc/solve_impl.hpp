@@ -999,11 +999,20 @@ __device__ __forceinline__ void project(const NtgDims &D, const Smem &S, const d
 	if (!dneg) lds_sync();
 }
 
+typedef const __attribute__((address_space(3))) double *lds_cdp;
+typedef const __attribute__((address_space(3))) int *lds_cip;
+typedef __attribute__((address_space(3))) double *lds_dp;
+typedef const __attribute__((address_space(1))) double *glb_cdp;
+typedef __attribute__((address_space(1))) double *glb_dp;
+typedef const __attribute__((address_space(1))) unsigned short *glb_cusp;
+// a coefficient vector of the solve lives in LDS, or (BIG layouts) in the per-problem HBM workspace: the out-of-line routines below take
+// it with its address space in the type (template flag G = "global"), so that they contain no FLAT instruction (ntg_amd/call_audit.py R2)
+template <bool G> struct VecPtr { typedef lds_dp rw; typedef lds_cdp ro; };
+template <> struct VecPtr<true> { typedef glb_dp rw; typedef glb_cdp ro; };
 // out = W0 v for the collocation preconditioner (ELL, rows streamed from L2).  Kept out of line:
 // it runs a handful of times per solve and must not add to the register pressure of the main loop.
-template <int NT>
-__device__ __attribute__((noinline)) void apply_n0(int n, int w, const double *__restrict__ n0,
-                                                   const unsigned short *__restrict__ n0c, const double *v, double *out)
+template <int NT, bool VG, bool OG>
+__device__ __attribute__((noinline)) void apply_n0(int n, int w, glb_cdp n0, glb_cusp n0c, typename VecPtr<VG>::ro v, typename VecPtr<OG>::rw out)
 {
 	for (int c = threadIdx.x; c < n; c += NT) {
 		double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -1029,12 +1038,10 @@ __device__ __attribute__((noinline)) void apply_n0(int n, int w, const double *_
 //   B = V:   staged in LDS laid out like v ([output][coefficient]); column j >= nout or of another block is 0.
 // Rows of W_b beyond nco are zero padding (spad rows, a multiple of 16); `out` may alias `stage`: the result tiles
 // stay in registers until every wave has finished reading.
-typedef const __attribute__((address_space(3))) double *lds_cdp;
-typedef const __attribute__((address_space(3))) int *lds_cip;
 typedef double ntg_d4 __attribute__((ext_vector_type(4)));
-template <int NT>
-__device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int nco, int spad, int nblk, const double *__restrict__ wb,
-                                                         lds_cip oinfo, const double *v, double *stage_w, double *out)
+template <int NT, bool VG, bool OG>
+__device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int nco, int spad, int nblk, glb_cdp wb,
+                                                         lds_cip oinfo, typename VecPtr<VG>::ro v, lds_dp stage_w, typename VecPtr<OG>::rw out)
 {
 	constexpr int NW = NT / 64, TMAX = 4, U = 4;   // nco <= NT (checked by the caller): at most NT/16 = 4 NW row tiles
 	lds_sync();   // previous readers of stage are done
@@ -1049,7 +1056,7 @@ __device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int n
 #pragma unroll
 	for (int t = 0; t < TMAX; t++) acc[t] = ntg_d4{0.0, 0.0, 0.0, 0.0};
 	for (int b = 0; b < nblk; b++) {
-		const double *wbb = wb + (size_t)b * spad * nco + li;
+		glb_cdp wbb = wb + (size_t)b * spad * nco + li;
 		const bool mine = myblk == b;
 		for (int k0 = 0; k0 < spad; k0 += 4 * U) {   // spad is a multiple of 16 = 4 U
 			// U k-steps of loads first (L2 latency overlaps), then their matrix instructions
@@ -1058,7 +1065,7 @@ __device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int n
 			for (int u = 0; u < U; u++) {
 				const int k = k0 + 4 * u + lk;
 				bv[u] = mine ? bcol[min(k, nco - 1)] : 0.0;   // k >= nco: W's row is zero padding
-				const double *wk = wbb + (size_t)k * nco;
+				glb_cdp wk = wbb + (size_t)k * nco;
 #pragma unroll
 				for (int t = 0; t < TMAX; t++) av[u][t] = (wave + t * NW < ntile) ? wk[(wave + t * NW) * 16] : 0.0;
 			}
@@ -1086,9 +1093,11 @@ __device__ __attribute__((noinline)) void apply_n0_block(int nC, int nout, int n
 // nC doubles that is free at every call site (the trial point: it is rebuilt from x and d afterwards).
 // HESS = false: the instance is only ever launched with the identity cold start (NPSOL's mode, the fixed-work
 // benchmark): no preconditioner code, in particular no out-of-line calls, in its main loop.
-template <int NT, bool BIG, bool HESS>
+// OLDS: `out` is an LDS vector even in the BIG layout (t = W gp+ lives in the trial-point buffer)
+template <int NT, bool BIG, bool HESS, bool OLDS = false>
 __device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, int hessian, const double *v, double *out, double *stage, const int *oinfo)
 {
+	constexpr bool VG = BIG, OG = BIG && !OLDS;
 	if (!HESS) {
 		lds_sync();
 		for_vec<NT>(D.nC, [&](int c) { out[c] = v[c]; });
@@ -1096,14 +1105,14 @@ __device__ __forceinline__ void apply_w0(const NtgDims &D, const NtgTables &T, i
 		return;
 	}
 	if (hessian == 1 && T.n0b && T.n0b_n <= NT) {
-		apply_n0_block<NT>(D.nC, D.nout, T.n0b_n, T.n0b_sp, T.n0b_nblk, T.n0b, (lds_cip)oinfo, v, stage, out);
+		apply_n0_block<NT, VG, OG>(D.nC, D.nout, T.n0b_n, T.n0b_sp, T.n0b_nblk, (glb_cdp)T.n0b, (lds_cip)oinfo, (typename VecPtr<VG>::ro)v, (lds_dp)stage, (typename VecPtr<OG>::rw)out);
 		if (BIG) __syncthreads();   // out may live in HBM and was written by row, not by owner lane
 		else lds_sync();
 		return;
 	}
 	if (BIG) __syncthreads();   // v lives in HBM/L2 and apply_n0 reads it across lanes
 	else lds_sync();
-	if (hessian == 1 && T.n0) apply_n0<NT>(D.nC, T.n0_w, T.n0, T.n0c, v, out);
+	if (hessian == 1 && T.n0) apply_n0<NT, VG, OG>(D.nC, T.n0_w, (glb_cdp)T.n0, (glb_cusp)T.n0c, (typename VecPtr<VG>::ro)v, (typename VecPtr<OG>::rw)out);
 	else for_vec<NT>(D.nC, [&](int c) { out[c] = v[c]; });
 	lds_sync();
 }
@@ -1626,7 +1635,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					}
 					if (!conv_now) {
 					if (NWT) { nwt_refresh(sxt, true); nwt_apply(sgpt, st); }   // sxt still holds the accepted point; st (= sxt) is written last
-					else apply_w0<NT, BIG, HESS>(D, Tw, sp.hessian, sgpt, st, sxt, S.oinfo);
+					else apply_w0<NT, BIG, HESS, true>(D, Tw, sp.hessian, sgpt, st, sxt, S.oinfo);
 					NTG_STAMP(4);
 					// register-resident pairs: 3 coefficients per lane, 6 pairs per round; the 5-coefficient instances (config E)
 					// take 3 pairs per round

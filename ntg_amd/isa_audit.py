@@ -12,8 +12,8 @@ maxidx: dict = {}
 warnings: list = []   # spills in kernels that do not address AGPRs by hand: slow, not wrong
 
 
-def audit(hipcc: str, src: str, include: str, flags: list[str], reserve_from: int = 0) -> list[str]:
-    asm = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only", src, "-o", "-",
+def audit(hipcc: str, src: str, include: str, flags: list[str], reserve_from: int = 0, asm_path: str | None = None) -> list[str]:
+    asm = open(asm_path, errors="replace").read() if asm_path else subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-x", "hip", "-S", "--cuda-device-only", src, "-o", "-",
                           "-I", include, "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unused-command-line-argument"] + flags,
                          check=True, capture_output=True, text=True).stdout
     problems, cur, inasm, uses_manual, meta_name = [], None, False, {}, None
