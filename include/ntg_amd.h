@@ -136,8 +136,10 @@ int ntg_batch_solve(const ntg_plan *p, int batch, const double *d_lower, const d
                     double *d_x, const ntg_solve_opts *o,
                     double *d_objective, int *d_inform, int *d_iters, int *d_nfev,
                     double *d_clambda, void *d_work, long long work_bytes, void *stream);
-/* name and average-per-launch facts of the solve kernel, for bench/roofline bookkeeping */
+/* name of the solve kernel, for bench/roofline bookkeeping: the general one, and the one ntg_batch_solve launches for (plan, batch,
+ * options) -- "sqp_wave_kernel" (one wavefront per problem: the kincar class of BASELINE's configs B, C, M) or "sqp_kernel" */
 const char *ntg_solve_kernel_name(void);
+const char *ntg_batch_solve_kernel(const ntg_plan *p, int batch, const ntg_solve_opts *o);
 
 /* bsplvd at every collocation point for `ngrids` different grids of one spline spec
  * (per-problem horizons): d_knots [ngrids][ninterv+1], d_bps [ngrids][nbps] ->

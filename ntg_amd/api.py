@@ -56,6 +56,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.ntg_last_error.restype = C.c_char_p
         L.ntg_solve_kernel_name.restype = C.c_char_p
+        L.ntg_batch_solve_kernel.restype = C.c_char_p
+        L.ntg_batch_solve_kernel.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ntg_batch_workspace_bytes.restype = C.c_longlong
         L.ntg_batch_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.ntg_plan_create.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
@@ -262,6 +264,10 @@ class Plan:
         _check(lib().ntg_batch_mpc_run(self.h, batch, nsteps, shift_bp, shift_knots, _ptr(x), _ptr(lower), _ptr(upper), C.byref(o),
                                        _ptr(inform), _ptr(bad), _ptr(work), work.numel() * work.element_size(), self._stream()))
         return inform, bad
+
+    def solve_kernel(self, batch: int, opts: Optional[SolveOpts] = None) -> str:
+        """name of the kernel solve() launches for this batch and these options"""
+        return lib().ntg_batch_solve_kernel(self.h, batch, C.byref(opts) if opts is not None else None).decode()
 
     def workspace_bytes(self, batch: int, opts: Optional[SolveOpts] = None) -> int:
         return int(lib().ntg_batch_workspace_bytes(self.h, batch, C.byref(opts) if opts is not None else None))

@@ -40,6 +40,7 @@ extern "C" void ntg_default_opts(ntg_solve_opts *o)
 	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->block_threads = 0; o->qn_memory = 0;
 }
 extern "C" const char *ntg_solve_kernel_name(void) { return "sqp_kernel"; }
+extern "C" const char *ntg_batch_solve_kernel(const ntg_plan *p, int batch, const ntg_solve_opts *o);
 // diagnostic: LDS bytes and block size the solve / eval launches of this plan use
 extern "C" int ntg_debug_layout(const ntg_plan *p, const ntg_solve_opts *o, int *lds_solve, int *lds_eval, int *nt_solve);
 
@@ -818,6 +819,21 @@ static bool wave_takes(const ntg_plan *p, const SolveParams &sp, int batch, NtgW
 	if (p->grid_batch) return false;
 	if (sp.hessian == 1 && !p->precond_ready) return false;   // decided after the preconditioner exists (its block form is part of the test)
 	return ntg_wave_plan(p->D, p->T, sp, batch, plan_ncu(p), w);
+}
+
+// name of the kernel ntg_batch_solve will launch for (plan, batch, options): "sqp_wave_kernel" (one wavefront per problem) or "sqp_kernel"
+extern "C" const char *ntg_batch_solve_kernel(const ntg_plan *p, int batch, const ntg_solve_opts *o)
+{
+	if (!p) return "";
+	SolveParams sp; int nt;
+	resolve_params(p, o, &sp, &nt);
+	if (p->grid_batch && sp.hessian == 2) sp.hessian = 1;
+	if (sp.hessian == 1 && p->precond_ready && p->precond_singular) sp.hessian = 0;
+	NtgWavePlan w;
+	if (p->grid_batch) return "sqp_kernel";
+	NtgTables T2 = p->T;
+	if (sp.hessian == 1 && !p->precond_ready) { T2.n0b = (const double *)1; T2.n0b_n = p->D.ncoef[0]; }   // not built yet: assume the block form
+	return ntg_wave_plan(p->D, T2, sp, batch, plan_ncu(p), &w) ? "sqp_wave_kernel" : "sqp_kernel";
 }
 
 extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, const ntg_solve_opts *o)
