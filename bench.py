@@ -507,17 +507,12 @@ def main():
         # ---- CPU baseline: the oracle on a bounded sample of the same workload, on the host cores of this box.  Two flavours
         #      (SURVEY 8d): "ref" = the reference's loops and dense temporaries (cost.c:117-134), "opt" = banded, allocation-free
         #      evaluation.  One pinned thread per PHYSICAL core (OMP_PLACES=cores, OMP_PROC_BIND=spread), >= 32 problems per thread;
-        #      glibc keeps the per-call dense temporaries (calloc of 0.3 - 21 MB) on the thread's heap instead of mmap/munmap per call
-        #      (M_MMAP_THRESHOLD / M_TRIM_THRESHOLD raised): the loops are the reference's, the kernel's mmap lock is not measured ----
-        import ctypes
-        try:
-            libc = ctypes.CDLL("libc.so.6")
-            libc.mallopt(-3, 1 << 30)   # M_MMAP_THRESHOLD
-            libc.mallopt(-1, 1 << 30)   # M_TRIM_THRESHOLD
-        except OSError:
-            pass
+        #      the per-call dense temporaries (calloc of 0.3 - 100 MB in the reference's loops) are served from a reused per-thread
+        #      buffer (orc_set_scratch_reuse): the loops and zero-fills are the reference's, the C library's mmap / page-fault
+        #      traffic under 128 threads (one address-space lock per process) is not measured ----
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import orc
+        orc.set_scratch_reuse(True)
         nthreads_hw = os.cpu_count() or 1
         ncore = min(physical_cores(), nthreads_hw)
         ns = args.cpu_sample if args.cpu_sample > 0 else 32 * ncore
@@ -552,7 +547,7 @@ def main():
                                "sample": f"first {ns} problems of the same batch ({ns / ncore:.1f} per pinned thread, one thread per physical core), same solve mode, oracle/sqp.c with the "
                                          f"reference-faithful dense assembly, OpenMP, {flav['ref']['all_cores_wall_s']:.2f} s wall",
                                "flavours": flav, "cpu_model": model, "compiler": cflags,
-                               "malloc": "M_MMAP_THRESHOLD and M_TRIM_THRESHOLD raised to 1 GiB: dense temporaries stay on the thread heap"}
+                               "malloc": "per-call dense temporaries from a reused per-thread buffer (orc_set_scratch_reuse): no mmap / munmap / page faults per call"}
         # same inputs -> same answers (oracle is the checker here, never the thing shipped)
         nchk = min(ns, B)
         gobj = out["objective"][:nchk].cpu().numpy()

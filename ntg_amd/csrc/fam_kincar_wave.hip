@@ -13,10 +13,10 @@ using namespace ntgw;
 
 namespace {
 
-template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS>
+template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false>
 hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
 {
-	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, 20, NWV, MINW, NREG, NLDS, HESS>;
+	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, 20, NWV, MINW, NREG, NLDS, HESS, XLDS>;
 	WaveArgs A;
 	A.batch = a.batch; A.cap = w.cap; A.lower = a.lo; A.upper = a.up; A.xio = a.x; A.objective = a.obj; A.inform = a.inf; A.iters = a.it;
 	A.nfev = a.nf; A.clambda = a.cl; A.hist = a.hist; A.counter = a.counter; A.hbm_slots = w.hbm_slots;
@@ -27,10 +27,14 @@ hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &s
 	return hipGetLastError();
 }
 
-// LDS bytes of a workgroup
-size_t wave_lds(const NtgDims &D, int nwv, int cap, int nlds, int epl)
+// LDS bytes of a workgroup (xlds: with the preconditioner blocks and the sparse linear operator staged)
+size_t wave_lds(const NtgDims &D, const NtgTables &T, int hessian, int nwv, int cap, int nlds, int epl, bool xlds = false)
 {
-	const size_t tab = (size_t)wave_tab_doubles<1, 6, 20>() * 8 + (size_t)D.q_nt * 6 * 8 + (size_t)D.q_nt * 8 * 4;
+	size_t tab = (size_t)wave_tab_doubles<1, 6, 20>() * 8 + (size_t)D.q_nt * 6 * 8 + (size_t)D.q_nt * 8 * 4;
+	if (xlds) {
+		const int lnz = std::max(D.lin_nnz, 1), snz = std::max(D.sinv_nnz, 1);
+		tab += (size_t)(hessian == 1 ? T.n0b_nblk * 64 * 64 : 0) * 8 + (size_t)(2 * lnz + snz) * 8 + (size_t)((2 * (D.mE + 1) + (D.nC + 1) + 2 * lnz + snz + 3) & ~3) * 4;
+	}
 	return tab + (size_t)nwv * wave_priv_doubles(D.nC, cap, nlds, epl) * 8;
 }
 
@@ -58,8 +62,8 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 	if (w->fat) {
 		const int nreg = (256 - NTGW_ABASE) / (2 * epl);
 		w->nlds = FAT_NLDS;
-		w->lds = wave_lds(D, 4, w->cap, w->nlds, epl);
-		if (w->lds > 160 * 1024) { w->nlds = FAT_NLDS2; w->lds = wave_lds(D, 4, w->cap, w->nlds, epl); }
+		w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl);
+		if (w->lds > 160 * 1024) { w->nlds = FAT_NLDS2; w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl); }
 		if (w->lds > 160 * 1024) w->fat = 0;
 		else {
 			w->hbm_slots = std::max(0, w->cap - nreg - w->nlds);
@@ -67,12 +71,15 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 		}
 	}
 	if (!w->fat) {
-		w->nlds = LEAN_NLDS;
-		w->lds = wave_lds(D, 4, w->cap, LEAN_NLDS, epl);
+		// eight waves sharing one copy of the tables, the preconditioner block and the linear operator in LDS; four when the scalars of
+		// a long quasi-Newton memory leave no room for eight
+		w->nlds = LEAN_NLDS; w->nwv = 8;
+		w->lds = wave_lds(D, T, sp.hessian, 8, w->cap, LEAN_NLDS, epl, true);
+		if (w->lds > 160 * 1024 || (sp.hessian == 1 && T.n0b_sp > 64)) { w->nwv = 4; w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, LEAN_NLDS, epl, sp.hessian != 1 || T.n0b_sp <= 64); }
 		if (w->lds > 160 * 1024) return false;
 		w->hbm_slots = std::max(0, w->cap - LEAN_NLDS);
-		const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(LEAN_MINW, (160 * 1024) / w->lds));
-		w->grid = std::max(1, std::min((batch + 3) / 4, ncu * wg_per_cu));
+		const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>((4 * LEAN_MINW) / w->nwv, (160 * 1024) / w->lds));
+		w->grid = std::max(1, std::min((batch + w->nwv - 1) / w->nwv, ncu * wg_per_cu));
 	}
 	w->hist_doubles = (size_t)w->grid * w->nwv * w->hbm_slots * epl * 64;
 	return true;
@@ -91,6 +98,17 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, FAT_NLDS2, false>(D, T, sp, a, w);
 		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, FAT_NLDS2, false>(D, T, sp, a, w);
 		return launch_one<6, 2, 4, 1, R6, FAT_NLDS2, false>(D, T, sp, a, w);
+	}
+	const bool xl = sp.hessian != 1 || T.n0b_sp <= 64;
+	if (w.nwv == 8 && xl) {
+		if (D.nout == 2) return launch_one<2, 1, 8, LEAN_MINW, 0, LEAN_NLDS, true, true>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 8, LEAN_MINW, 0, LEAN_NLDS, true, true>(D, T, sp, a, w);
+		return launch_one<6, 2, 8, LEAN_MINW, 0, LEAN_NLDS, true, true>(D, T, sp, a, w);
+	}
+	if (xl) {
+		if (D.nout == 2) return launch_one<2, 1, 4, LEAN_MINW, 0, LEAN_NLDS, true, true>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, true>(D, T, sp, a, w);
+		return launch_one<6, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, true>(D, T, sp, a, w);
 	}
 	if (D.nout == 2) return launch_one<2, 1, 4, LEAN_MINW, 0, LEAN_NLDS, true>(D, T, sp, a, w);
 	if (D.nout == 4) return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true>(D, T, sp, a, w);

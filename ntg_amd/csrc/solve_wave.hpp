@@ -109,7 +109,9 @@ __host__ __device__ inline int wave_priv_doubles(int nC, int cap, int nlds, int 
 	return ((nC + 3) & ~3) + (4 * capp > 128 ? 4 * capp : 128) + 48 + nlds * epl * 64;   // (the feasibility / multiplier scratch shares the delta / kappa / link area)
 }
 
-template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS>
+// XLDS: the preconditioner blocks W_b (zero padded to 64 x 64) and the sparse operator of the linear rows (A as CSR and CSC, (A A')^-1 as
+// CSR) are staged in the workgroup's LDS: the instance of short solves, where their L2 latency is a visible share of a problem
+template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false>
 __global__ void __launch_bounds__(64 * NWV, MINW)
 sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 {
@@ -128,7 +130,30 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	double *s_dt = s_wt + SMAX * NL;                        // [SMAX][NL] interval lengths
 	double *s_qv = s_dt + SMAX * NL;                        // [q_nt][6] projector rows (ELL)
 	int *s_qc = (int *)(s_qv + D.q_nt * 6);                // [q_nt][8]
-	double *s_priv0 = (double *)(s_qc + D.q_nt * 8);
+	// XLDS extras: [nblk][64][64] preconditioner blocks; csr_ptr[m+1] csr_col[nnz] csc_ptr[nC+1] csc_row[nnz] sinv_ptr[m+1] sinv_col[snz] (ints),
+	// csr_val[nnz] csc_val[nnz] sinv_val[snz] (doubles)
+	double *s_w0 = (double *)(s_qc + D.q_nt * 8);
+	const int w0n = (XLDS && HESS && sp.hessian == 1) ? T.n0b_nblk * 64 * 64 : 0, lnz = D.lin_nnz > 0 ? D.lin_nnz : 1, snz = D.sinv_nnz > 0 ? D.sinv_nnz : 1;
+	double *s_lv = s_w0 + w0n;                                     // csr_val | csc_val | sinv_val
+	int *s_li = (int *)(s_lv + (XLDS ? 2 * lnz + snz : 0));          // csr_ptr | csr_col | csc_ptr | csc_row | sinv_ptr | sinv_col
+	const int lin_ints = XLDS ? ((2 * (m + 1) + (nC + 1) + 2 * lnz + snz + 3) & ~3) : 0;
+	double *s_priv0 = (double *)(s_li + lin_ints);
+	const double *l_csr_val = XLDS ? s_lv : T.csr_val, *l_csc_val = XLDS ? s_lv + lnz : T.csc_val, *l_sinv_val = XLDS ? s_lv + 2 * lnz : T.sinv_val;
+	const int *l_csr_ptr = XLDS ? s_li : T.csr_ptr, *l_csr_col = XLDS ? s_li + (m + 1) : T.csr_col;
+	const int *l_csc_ptr = XLDS ? s_li + (m + 1) + lnz : T.csc_ptr, *l_csc_row = XLDS ? s_li + (m + 1) + lnz + (nC + 1) : T.csc_row;
+	const int *l_sinv_ptr = XLDS ? s_li + (m + 1) + 2 * lnz + (nC + 1) : T.sinv_ptr, *l_sinv_col = XLDS ? s_li + 2 * (m + 1) + 2 * lnz + (nC + 1) : T.sinv_col;
+	if (XLDS) {
+		for (int e = tid; e < w0n; e += 64 * NWV) {
+			const int row = e & 63, k = (e >> 6) & 63, b2 = e >> 12;
+			s_w0[e] = (k < T.n0b_sp && row < nco) ? T.n0b[((size_t)b2 * T.n0b_sp + k) * nco + row] : 0.0;
+		}
+		if (m > 0) {
+			for (int e = tid; e < lnz; e += 64 * NWV) { s_lv[e] = T.csr_val[e]; s_lv[lnz + e] = T.csc_val[e]; s_li[(m + 1) + e] = T.csr_col[e]; s_li[(m + 1) + lnz + (nC + 1) + e] = T.csc_row[e]; }
+			for (int e = tid; e < snz; e += 64 * NWV) { s_lv[2 * lnz + e] = T.sinv_val[e]; s_li[2 * (m + 1) + 2 * lnz + (nC + 1) + e] = T.sinv_col[e]; }
+			for (int e = tid; e <= m; e += 64 * NWV) { s_li[e] = T.csr_ptr[e]; s_li[(m + 1) + 2 * lnz + (nC + 1) + e] = T.sinv_ptr[e]; }
+			for (int e = tid; e <= nC; e += 64 * NWV) s_li[(m + 1) + lnz + e] = T.csc_ptr[e];
+		}
+	}
 	for (int e = tid; e < NCH * SMAX * K * NL; e += 64 * NWV) {
 		const int t = e % NL, q = (e / NL) % K, s2 = (e / (NL * K)) % SMAX, ch = e / (NL * K * SMAX);
 		int r = 0, seen = -1;
@@ -318,6 +343,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			for (int tl = 0; tl < TM; tl++) acc[tl] = ntg_d4{0.0, 0.0, 0.0, 0.0};
 			for (int b = 0; b < T.n0b_nblk; b++) {
 				const double *wbb = T.n0b + (size_t)b * spad * nco + li;
+				const double *wlb = s_w0 + (size_t)b * 64 * 64 + li;   // staged copy: rows and columns zero padded to 64
 				const bool mine = myblk == b;
 				for (int k0 = 0; k0 < spad; k0 += 16) {
 					double av[4][TM], bv[4];
@@ -327,7 +353,10 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						bv[u] = mine ? bcol[min(k, nco - 1)] : 0.0;   // k >= nco: W's row is zero padding
 						const double *wk = wbb + (size_t)k * nco;
 #pragma unroll
-						for (int tl = 0; tl < TM; tl++) av[u][tl] = (16 * tl + li < nco) ? wk[16 * tl] : 0.0;
+						for (int tl = 0; tl < TM; tl++) {
+							if constexpr (XLDS) av[u][tl] = wlb[k * 64 + 16 * tl];
+							else av[u][tl] = (16 * tl + li < nco) ? wk[16 * tl] : 0.0;
+						}
 					}
 #pragma unroll
 					for (int u = 0; u < 4; u++)
@@ -550,13 +579,13 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				stage_put(x);
 				for (int r = lane; r < m; r += 64) {
 					double a = 0.0;
-					for (int e = T.csr_ptr[r]; e < T.csr_ptr[r + 1]; e++) a += T.csr_val[e] * s_st[T.csr_col[e]];
+					for (int e = l_csr_ptr[r]; e < l_csr_ptr[r + 1]; e++) a += l_csr_val[e] * s_st[l_csr_col[e]];
 					s_tmp[r] = lo[lin_slot(D, r)] - a;
 				}
 				nwt_wave_sync();
 				for (int r = lane; r < m; r += 64) {
 					double a = 0.0;
-					for (int e = T.sinv_ptr[r]; e < T.sinv_ptr[r + 1]; e++) a += T.sinv_val[e] * s_tmp[T.sinv_col[e]];
+					for (int e = l_sinv_ptr[r]; e < l_sinv_ptr[r + 1]; e++) a += l_sinv_val[e] * s_tmp[l_sinv_col[e]];
 					s_tmp[64 + r] = a;
 				}
 				nwt_wave_sync();
@@ -567,7 +596,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						for (int q = 0; q < S; q++) {
 							const int c = cbase + o * nco + q;
 							double s = 0.0;
-							for (int e = T.csc_ptr[c]; e < T.csc_ptr[c + 1]; e++) s += T.csc_val[e] * s_tmp[64 + T.csc_row[e]];
+							for (int e = l_csc_ptr[c]; e < l_csc_ptr[c + 1]; e++) s += l_csc_val[e] * s_tmp[64 + l_csc_row[e]];
 							x[o * S + q] += s;
 						}
 				}
@@ -601,13 +630,13 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 					stage_put(g);
 					for (int r = lane; r < m; r += 64) {
 						double a = 0.0;
-						for (int e = T.csr_ptr[r]; e < T.csr_ptr[r + 1]; e++) a += T.csr_val[e] * s_st[T.csr_col[e]];
+						for (int e = l_csr_ptr[r]; e < l_csr_ptr[r + 1]; e++) a += l_csr_val[e] * s_st[l_csr_col[e]];
 						s_tmp[r] = a;
 					}
 					nwt_wave_sync();
 					for (int r = lane; r < m; r += 64) {
 						double a = 0.0;
-						for (int e = T.sinv_ptr[r]; e < T.sinv_ptr[r + 1]; e++) a += T.sinv_val[e] * s_tmp[T.sinv_col[e]];
+						for (int e = l_sinv_ptr[r]; e < l_sinv_ptr[r + 1]; e++) a += l_sinv_val[e] * s_tmp[l_sinv_col[e]];
 						s_tmp[64 + r] = a;
 					}
 					nwt_wave_sync();

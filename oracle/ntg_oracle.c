@@ -248,68 +248,98 @@ void orc_integrate_cols(double *I, const double *f, int rows, int cols, const do
 }
 
 /* cost.c:4-36 */
+/* ---- scratch of one evaluation ----
+ * The reference allocates its dense temporaries per call (calloc / free in cost.c:117-134, constraints.c:147 ...) and so does this
+ * restatement.  For the TIMED multi-threaded CPU baseline (bench.py cpu_baseline) the allocations can be served from a per-thread
+ * buffer that is reused from call to call (orc_set_scratch_reuse(1)): the loops and the zero-fills stay the reference's, but 128
+ * threads no longer queue on the kernel's address-space lock for mmap / munmap / page faults of 0.3 - 100 MB per call -- that
+ * lock is a property of the C library under threads, not of the reference (which is single-threaded).  Off by default: the
+ * parity tests run the plain calloc / free path. */
+static int orc_scratch_reuse = 0;
+static __thread struct { char *base; size_t cap, top; } orc_arena;
+void orc_set_scratch_reuse(int on) { orc_scratch_reuse = on; }
+static void orc_tmp_reset(void) { orc_arena.top = 0; }
+static void *orc_tmp_malloc(size_t bytes)
+{
+	if (!orc_scratch_reuse) return malloc(bytes);
+	bytes = (bytes + 63) & ~(size_t)63;
+	if (!orc_arena.base) { orc_arena.cap = (size_t)768 << 20; orc_arena.base = malloc(orc_arena.cap); orc_arena.top = 0; }   /* virtual: pages are touched as used, once */
+	if (!orc_arena.base || orc_arena.top + bytes > orc_arena.cap) return malloc(bytes);
+	{ void *q = orc_arena.base + orc_arena.top; orc_arena.top += bytes; return q; }
+}
+static void *orc_tmp_calloc(size_t n, size_t sz)
+{
+	if (!orc_scratch_reuse) return calloc(n, sz);
+	{ void *q = orc_tmp_malloc(n * sz); if (q) memset(q, 0, n * sz); return q; }
+}
+static void orc_tmp_free(void *q)
+{
+	if (orc_arena.base && (char *)q >= orc_arena.base && (char *)q < orc_arena.base + orc_arena.cap) return;   /* released by the next reset */
+	free(q);
+}
+
 static void cost_I(int *mode, int *nstate, double *I, double *dI, orc_icf_t func, const orc_colloc *cc, double *Z)
 {
-	double **zp = malloc(cc->nout * sizeof(double *));
+	double **zp = orc_tmp_malloc(cc->nout * sizeof(double *));
 	zp_I(zp, Z, cc);
 	if (*mode == 0) {
 		func(mode, nstate, I, NULL, zp);
 	} else if (*mode == 1 || *mode == 2) {
-		double *dIdz = calloc(cc->nz, sizeof(double));
-		double *dIdZ = calloc(cc->nZ, sizeof(double));
-		double *dIdC = calloc(cc->nC, sizeof(double));
+		double *dIdz = orc_tmp_calloc(cc->nz, sizeof(double));
+		double *dIdZ = orc_tmp_calloc(cc->nZ, sizeof(double));
+		double *dIdC = orc_tmp_calloc(cc->nC, sizeof(double));
 		const double *rowp[1];
 		func(mode, nstate, I, dIdz, zp);
 		rowp[0] = dIdz;
 		scat_I(dIdZ, 1, 1, rowp, cc);
 		mult_I(dIdC, 1, dIdZ, 1, 1, cc);
 		memcpy(dI, dIdC, cc->nC * sizeof(double));
-		free(dIdz); free(dIdZ); free(dIdC);
+		orc_tmp_free(dIdz); orc_tmp_free(dIdZ); orc_tmp_free(dIdC);
 	}
-	free(zp);
+	orc_tmp_free(zp);
 }
 /* cost.c:141-174 */
 static void cost_F(int *mode, int *nstate, double *I, double *dI, orc_icf_t func, const orc_colloc *cc, double *Z)
 {
-	double **zp = malloc(cc->nout * sizeof(double *));
+	double **zp = orc_tmp_malloc(cc->nout * sizeof(double *));
 	zp_F(zp, Z, cc);
 	if (*mode == 0) {
 		func(mode, nstate, I, NULL, zp);
 	} else if (*mode == 1 || *mode == 2) {
-		double *dIdz = calloc(cc->nz, sizeof(double));
-		double *dIdZ = calloc(cc->nZ, sizeof(double));
-		double *dIdC = calloc(cc->nC, sizeof(double));
+		double *dIdz = orc_tmp_calloc(cc->nz, sizeof(double));
+		double *dIdZ = orc_tmp_calloc(cc->nZ, sizeof(double));
+		double *dIdC = orc_tmp_calloc(cc->nC, sizeof(double));
 		const double *rowp[1];
 		func(mode, nstate, I, dIdz, zp);
 		rowp[0] = dIdz;
 		scat_F(dIdZ, 1, 1, rowp, cc);
 		mult_F(dIdC, 1, dIdZ, 1, 1, cc);
 		memcpy(dI, dIdC, cc->nC * sizeof(double));
-		free(dIdz); free(dIdZ); free(dIdC);
+		orc_tmp_free(dIdz); orc_tmp_free(dIdZ); orc_tmp_free(dIdC);
 	}
-	free(zp);
+	orc_tmp_free(zp);
 }
 /* cost.c:38-139 -- keeps the dense nbps x nC temporary and the full-column trapezoid */
 static void cost_T(int *mode, int *nstate, double *I, double *dI, const double *bps,
                    orc_ucf_t func, const orc_colloc *cc, double *Z)
 {
-	double **zp = malloc(cc->nout * sizeof(double *));
+	double **zp = orc_tmp_malloc(cc->nout * sizeof(double *));
 	int P = cc->nbps, i, j, k, l, offset;
 	double *f = NULL, *d1 = NULL, *dIdz = NULL, *dIdC = NULL;
-	if (*mode == 0 || *mode == 2) f = malloc(P * sizeof(double));
+	if (*mode == 0 || *mode == 2) f = orc_tmp_malloc(P * sizeof(double));
 	if (*mode == 1 || *mode == 2) {
-		d1 = malloc(cc->nz * sizeof(double));
-		dIdz = calloc((size_t)P * cc->nz, sizeof(double)); /* FMatrix(nbps rows, nz cols) */
+		d1 = orc_tmp_malloc(cc->nz * sizeof(double));
+		dIdz = orc_tmp_calloc((size_t)P * cc->nz, sizeof(double)); /* FMatrix(nbps rows, nz cols) */
 	}
 	for (i = 0; i < P; i++) {
 		zp_T(zp, Z, cc, i);
 		func(mode, nstate, &i, f ? f + i : NULL, d1, zp);
 		if (d1) for (j = 0; j < cc->nz; j++) FM(dIdz, P, i, j) = d1[j];
 	}
-	if (f) { orc_integrate_vector(I, f, bps, P); free(f); }
+	if (f) { orc_integrate_vector(I, f, bps, P); orc_tmp_free(f); }
 	if (d1) {
-		free(d1);
-		dIdC = calloc((size_t)P * cc->nC, sizeof(double));
+		orc_tmp_free(d1);
+		dIdC = orc_tmp_calloc((size_t)P * cc->nC, sizeof(double));
 		for (i = 0; i < cc->nout; i++)
 			for (j = 0; j < P; j++) {
 				offset = cc->off[i][j];
@@ -321,11 +351,11 @@ static void cost_T(int *mode, int *nstate, double *I, double *dI, const double *
 				}
 				for (; k < cc->ncoef[i]; k++) FM(dIdC, P, j, cc->iC[i] + k) = 0;
 			}
-		free(dIdz);
+		orc_tmp_free(dIdz);
 		orc_integrate_cols(dI, dIdC, P, cc->nC, bps);
-		free(dIdC);
+		orc_tmp_free(dIdC);
 	}
-	free(zp);
+	orc_tmp_free(zp);
 }
 
 /* constraints.c:5-33 */
@@ -346,38 +376,38 @@ void orc_bounds(double *bbar, const double *b, int nc, int nlic, int nltc, int n
 /* user Jacobian storage: DoubleFMatrix(nz rows, ncon cols) => dc[con][var], contiguous */
 static double **make_dc(int nz, int ncon)
 {
-	double **d = malloc((ncon > 0 ? ncon : 1) * sizeof(double *));
+	double **d = orc_tmp_malloc((ncon > 0 ? ncon : 1) * sizeof(double *));
 	int c;
-	d[0] = calloc((size_t)nz * (ncon > 0 ? ncon : 1), sizeof(double));
+	d[0] = orc_tmp_calloc((size_t)nz * (ncon > 0 ? ncon : 1), sizeof(double));
 	for (c = 1; c < ncon; c++) d[c] = d[0] + (size_t)c * nz;
 	return d;
 }
-static void free_dc(double **d) { free(d[0]); free(d); }
+static void free_dc(double **d) { orc_tmp_free(d[0]); orc_tmp_free(d); }
 
 /* constraints.c:88-117 / :165-195.  dIdC points at row `row0` of the (ldJ x nC) Jacobian */
 static void nl_IF(int final, int *mode, int *nstate, int ncon, double *c, double *dIdC, int ldJ,
                   orc_nlic_t func, const orc_colloc *cc, double *Z)
 {
-	double **zp = malloc(cc->nout * sizeof(double *));
+	double **zp = orc_tmp_malloc(cc->nout * sizeof(double *));
 	if (final) zp_F(zp, Z, cc); else zp_I(zp, Z, cc);
 	if (*mode == 0) {
 		func(mode, nstate, c, NULL, zp);
 	} else if (*mode == 1 || *mode == 2) {
 		double **dIdz = make_dc(cc->nz, ncon);
-		double *dIdZ = calloc((size_t)ncon * cc->nZ, sizeof(double));
+		double *dIdZ = orc_tmp_calloc((size_t)ncon * cc->nZ, sizeof(double));
 		func(mode, nstate, c, dIdz, zp);
 		if (final) { scat_F(dIdZ, ncon, ncon, (const double *const *)dIdz, cc); mult_F(dIdC, ldJ, dIdZ, ncon, ncon, cc); }
 		else       { scat_I(dIdZ, ncon, ncon, (const double *const *)dIdz, cc); mult_I(dIdC, ldJ, dIdZ, ncon, ncon, cc); }
-		free_dc(dIdz); free(dIdZ);
+		free_dc(dIdz); orc_tmp_free(dIdZ);
 	}
-	free(zp);
+	orc_tmp_free(zp);
 }
 /* constraints.c:120-162 -- keeps the dense (nbps*ncon x nZ) temporary, calloc'd per call */
 static void nl_T(int *mode, int *nstate, int ncon, double *c, double *dIdC, int ldJ,
                  orc_nltc_t func, const orc_colloc *cc, double *Z)
 {
-	double **zp = malloc(cc->nout * sizeof(double *));
-	double *tmp = malloc(ncon * sizeof(double));
+	double **zp = orc_tmp_malloc(cc->nout * sizeof(double *));
+	double *tmp = orc_tmp_malloc(ncon * sizeof(double));
 	int P = cc->nbps, i, j;
 	if (*mode == 0) {
 		for (i = 0; i < P; i++) {
@@ -388,7 +418,7 @@ static void nl_T(int *mode, int *nstate, int ncon, double *c, double *dIdC, int 
 	} else if (*mode == 1 || *mode == 2) {
 		double **dIdz = make_dc(cc->nz, ncon);
 		int rows = P * ncon;
-		double *dIdZ = calloc((size_t)rows * cc->nZ, sizeof(double));
+		double *dIdZ = orc_tmp_calloc((size_t)rows * cc->nZ, sizeof(double));
 		for (i = 0; i < P; i++) {
 			zp_T(zp, Z, cc, i);
 			func(mode, nstate, &i, tmp, dIdz, zp);
@@ -396,9 +426,9 @@ static void nl_T(int *mode, int *nstate, int ncon, double *c, double *dIdC, int 
 			scat_T(dIdZ, rows, ncon, (const double *const *)dIdz, cc, i);
 		}
 		mult_T(dIdC, ldJ, dIdZ, rows, rows, cc);
-		free_dc(dIdz); free(dIdZ);
+		free_dc(dIdz); orc_tmp_free(dIdZ);
 	}
-	free(tmp); free(zp);
+	orc_tmp_free(tmp); orc_tmp_free(zp);
 }
 
 /* constraints.c:198-261: A = [lic; ltc (constraint-major x bp); lfc], col-major ld = nclin */
@@ -510,6 +540,7 @@ void orc_funobj(orc_problem *p, int *mode, const double *x, double *y, double *y
 	const orc_colloc *cc = p->cc;
 	double I = 0.0, In = 0.0, F = 0.0, *dI, *dIn, *dF;
 	int i;
+	orc_tmp_reset();
 	if (p->banded && *mode == 2 && p->nicf == 0 && p->nfcf == 0 && p->nucf != 0 && cc->nz <= 64 && cc->nout <= 16) { cost_T_banded(y, yprime, p, x); return; }
 	if (p->nicf != 0) orc_updateZ(p->Z, cc, x, p->icostav, p->nicostav, ORC_AVINITIAL);
 	if (p->nucf != 0) orc_updateZ(p->Z, cc, x, p->tcostav, p->ntcostav, ORC_AVTRAJECTORY);
@@ -523,13 +554,13 @@ void orc_funobj(orc_problem *p, int *mode, const double *x, double *y, double *y
 		break;
 	case 1:
 	case 2:
-		dI = calloc(cc->nC, sizeof(double)); dIn = calloc(cc->nC, sizeof(double)); dF = calloc(cc->nC, sizeof(double));
+		dI = orc_tmp_calloc(cc->nC, sizeof(double)); dIn = orc_tmp_calloc(cc->nC, sizeof(double)); dF = orc_tmp_calloc(cc->nC, sizeof(double));
 		if (p->nicf != 0) cost_I(mode, nstate, &I, dI, p->icf, cc, p->Z);
 		if (p->nucf != 0) cost_T(mode, nstate, &In, dIn, cc->bps, p->ucf, cc, p->Z);
 		if (p->nfcf != 0) cost_F(mode, nstate, &F, dF, p->fcf, cc, p->Z);
 		if (*mode == 2) *y = I + In + F;
 		for (i = 0; i < cc->nC; i++) yprime[i] = dI[i] + dIn[i] + dF[i];   /* Vector3Add matrix.c:177 */
-		free(dI); free(dIn); free(dF);
+		orc_tmp_free(dI); orc_tmp_free(dIn); orc_tmp_free(dF);
 		break;
 	default:
 		*nstate = -1;
@@ -542,6 +573,7 @@ void orc_funcon(orc_problem *p, int *mode, const double *x, double *c, double *c
 	const orc_colloc *cc = p->cc;
 	int i1 = 0, ldJ = p->ncnln ? p->ncnln : 1;
 	double *J = cJac ? cJac : p->cJac;
+	orc_tmp_reset();
 	if (p->nnlic != 0) orc_updateZ(p->Z, cc, x, p->icav, p->nicav, ORC_AVINITIAL);
 	if (p->nnltc != 0) orc_updateZ(p->Z, cc, x, p->tcav, p->ntcav, ORC_AVTRAJECTORY);
 	if (p->nnlfc != 0) orc_updateZ(p->Z, cc, x, p->fcav, p->nfcav, ORC_AVFINAL);

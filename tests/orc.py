@@ -151,6 +151,11 @@ def eval_batch(spec, x, mode=2, nthreads=1):
     return out
 
 
+def set_scratch_reuse(on: bool):
+    """timed CPU baseline only (bench.py): per-thread reuse of the evaluation's dense temporaries instead of calloc / free per call"""
+    lib().orc_set_scratch_reuse(1 if on else 0)
+
+
 def solve_batch(spec, lowerb, upperb, x0, opts=None, nthreads=1):
     cs = CSpec(spec)
     o = opts or default_opts()
