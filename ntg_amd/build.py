@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libntg_amd.so")
-SOURCES = ["kernels.hip", "fam_kincar.hip", "fam_kincar_chm.hip", "fam_kincar_wave.hip", "fam_vanderpol.hip", "fam_testfam.hip", "fam_obstacle.hip", "fam_quadrotor.hip",
+SOURCES = ["kernels.hip", "grids.hip", "fam_kincar.hip", "fam_kincar_chm.hip", "fam_kincar_wave.hip", "fam_vanderpol.hip", "fam_testfam.hip", "fam_obstacle.hip", "fam_quadrotor.hip",
            "fam_manip.hip", "plan.cpp", "ntg_host.cpp"]
 HEADERS = ["ntg_dev.hpp", "solve_impl.hpp", "newton.hpp", "eval_fast.hpp", "solve_wave.hpp", "families.hpp", "linesearch.hpp", "plan.hpp", "../../include/ntg_amd.h", "../../include/ntg.h"]
 

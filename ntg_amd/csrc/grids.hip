@@ -1,0 +1,182 @@
+// grids.hip -- per-problem grids on the device: the setup phase of ntg() (ntg.c:114-229) for every problem of a batch.
+//
+// ntg() builds its collocation per call (CollocMatrix per output, colloc.c:57-117; LinearConstraintsMatrix, constraints.c:198-261).
+// With per-problem grids the plan's combinatorial structure is shared and the VALUES are per problem (ntg_plan_set_grids, plan.cpp):
+// basis_kernel evaluates the basis blocks of every grid; the two kernels here derive everything else from them without leaving the
+// device (round 2 did this algebra on host threads: 0.2 - 1.5 s for 16 384 grids):
+//   grid_rows_kernel  channel rows rowv[chrow[r] + q P + i] = D^r B_{off+q}(bps_i) (the layout eval_kernel / sqp_kernel stage), and
+//                     the check that every breakpoint lies in the plan's knot interval (block[i].offset, colloc.c:104-111)
+//   grid_lin_kernel   one wavefront per problem: the rows of A_E (LinearConstraintsMatrix: the user's lic / ltc / lfc rows through
+//                     the basis blocks of their breakpoint, constraints.c:225-261) as values of the plan's CSR / CSC patterns, a test
+//                     that nothing of weight falls outside the pattern, S = A A' in LDS, its Cholesky factor, (A A')^-1 on the plan's
+//                     pattern, and the projector Q = A'(A A')^-1 A on the plan's ELL pattern.
+// A row of A_E has support nout * k (the k basis functions of its breakpoint, for every output): the kernel keeps the m supports in
+// LDS and never forms the dense m x nC matrix.
+#include <hip/hip_runtime.h>
+#include "ntg_dev.hpp"
+#include "plan.hpp"
+
+// lanes of one wave hand data over through LDS: the LDS queue of a wave is processed in order, the compiler must not reorder or forward
+__device__ __forceinline__ void nwt_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__global__ void grid_rows_kernel(NtgDims D, int batch, const double *__restrict__ blk, const int *__restrict__ off, const int *__restrict__ plan_off,
+                                 double *__restrict__ rowv, int *__restrict__ err)
+{
+	const int b = blockIdx.x, P = D.P, k = D.cls_k[0], d = D.cls_d[0];
+	if (b >= batch) return;
+	const double *bk = blk + (size_t)b * P * k * d;
+	double *rv = rowv + (size_t)b * D.row_total;
+	for (int idx = threadIdx.x; idx < d * k * P; idx += blockDim.x) {
+		const int i = idx % P, q = (idx / P) % k, r = idx / (P * k);
+		const int ch = D.ch_row0[r];
+		if (ch >= 0) rv[ch + q * P + i] = bk[((size_t)i * k + q) * d + r];   // (the one trailing zero per channel stays from the memset)
+	}
+	for (int i = threadIdx.x; i < P; i += blockDim.x)
+		if (off[(size_t)b * P + i] != plan_off[i]) { if (atomicCAS(&err[0], 0, 1) == 0) { err[1] = b; err[2] = i; } }
+}
+
+struct GridLinArgs {
+	const double *blk;        // [batch][P][k][d]
+	const double *linrows;    // [nclin][nz] the user's lic / ltc / lfc rows, stacked
+	const int *plan_off;      // [P]
+	const int *erow, *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col, *q_col, *q_row2coef;
+	const unsigned char *q_pad;   // [q_nt][q_w] 1: padding entry of the ELL pattern (stays 0)
+	double *csr_val, *csc_val, *sinv_val, *q_val;   // per problem, strides lin_nnz / lin_nnz / sinv_nnz / q_nt q_w
+	int *err;
+};
+
+// value of A_E(i, c) from the row supports in LDS: c = o nco + cl, the row's block starts at offe[i]
+__device__ __forceinline__ double grid_getA(const double *sup, const int *offe, int sw, int k, int nco, int i, int c)
+{
+	const int o = c / nco, q = c - o * nco - offe[i];
+	return (q >= 0 && q < k) ? sup[i * sw + o * k + q] : 0.0;
+}
+
+__global__ void __launch_bounds__(64)
+grid_lin_kernel(NtgDims D, int batch, GridLinArgs A)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	const int b = blockIdx.x, lane = threadIdx.x, m = D.mE, P = D.P, k = D.cls_k[0], d = D.cls_d[0], nout = D.nout, nco = D.ncoef[0], nz = D.nz;
+	if (b >= batch) return;
+	const int sw = nout * k, mp = m + 1;
+	double *sup = (double *)smem_raw;          // [m][sw] supports of the rows
+	double *S = sup + (size_t)m * sw;           // [m][m+1] A A', then its Cholesky factor (lower)
+	double *Si = S + (size_t)m * mp;            // [m][m+1] (A A')^-1
+	int *offe = (int *)(Si + (size_t)m * mp);   // [m] block offset of the row's breakpoint
+	const double *bk = A.blk + (size_t)b * P * k * d;
+	const int lnz = D.lin_nnz > 0 ? D.lin_nnz : 1, snz = D.sinv_nnz > 0 ? D.sinv_nnz : 1, qn = D.q_use ? D.q_nt * D.q_w : 0;
+	// 1. supports: sup[e][o k + q] = sum_l row_e[iz[o] + l] * D^l B_{off+q}(bp_e)     (dIdz2dIdZ* + CollocConcatMult*, constraints.c:225-261)
+	for (int idx = lane; idx < m * sw; idx += 64) {
+		const int e = idx / sw, oq = idx - e * sw, o = oq / k, q = oq - o * k;
+		const int r = A.erow[e];
+		const double *row; int bp;
+		if (r < D.nlic) { row = A.linrows + (size_t)r * nz; bp = 0; }
+		else if (r < D.nlic + D.nltc * P) { const int rr = r - D.nlic; row = A.linrows + (size_t)(D.nlic + rr / P) * nz; bp = rr % P; }
+		else { row = A.linrows + (size_t)(D.nlic + D.nltc + (r - D.nlic - D.nltc * P)) * nz; bp = P - 1; }
+		double acc = 0.0;
+		for (int l = 0; l < d; l++) acc += row[D.iz[o] + l] * bk[((size_t)bp * k + q) * d + l];
+		sup[idx] = acc;
+		if (oq == 0) offe[e] = A.plan_off[bp];
+	}
+	nwt_wave_sync();
+	// 2. values on the plan's patterns; nothing of weight outside them (relative threshold as in build_newton_tables(): a final breakpoint
+	//    one ulp past the last knot leaves ~1e-16 basis values where the plan has exact zeros)
+	for (int i = lane; i < m; i += 64) {
+		double rmax = 0.0;
+		for (int oq = 0; oq < sw; oq++) rmax = fmax(rmax, fabs(sup[i * sw + oq]));
+		for (int oq = 0; oq < sw; oq++) {
+			const int o = oq / k, c = o * nco + offe[i] + (oq - o * k);
+			bool in = false;
+			for (int e = A.csr_ptr[i]; e < A.csr_ptr[i + 1]; e++) if (A.csr_col[e] == c) { in = true; break; }
+			if (!in && fabs(sup[i * sw + oq]) > 1e-10 * rmax) { if (atomicCAS(&A.err[0], 0, 2) == 0) { A.err[1] = b; A.err[2] = i; } }
+		}
+		for (int e = A.csr_ptr[i]; e < A.csr_ptr[i + 1]; e++) A.csr_val[(size_t)b * lnz + e] = grid_getA(sup, offe, sw, k, nco, i, A.csr_col[e]);
+	}
+	for (int c = lane; c < D.nC; c += 64)
+		for (int e = A.csc_ptr[c]; e < A.csc_ptr[c + 1]; e++) A.csc_val[(size_t)b * lnz + e] = grid_getA(sup, offe, sw, k, nco, A.csc_row[e], c);
+	// 3. S = A A'
+	for (int idx = lane; idx < m * m; idx += 64) {
+		const int i = idx / m, j = idx - i * m;
+		if (j > i) continue;
+		const int sh = offe[i] - offe[j];
+		double acc = 0.0;
+		for (int o = 0; o < nout; o++)
+			for (int q = 0; q < k; q++) { const int qj = q + sh; if (qj >= 0 && qj < k) acc += sup[i * sw + o * k + q] * sup[j * sw + o * k + qj]; }
+		S[i * mp + j] = acc; S[j * mp + i] = acc;
+	}
+	nwt_wave_sync();
+	// 4. Cholesky S = L L' in place (lane = row), right-looking
+	bool bad = false;
+	for (int j = 0; j < m; j++) {
+		const double dj = S[j * mp + j];
+		if (!(dj > 0.0)) { bad = true; break; }
+		const double ld = sqrt(dj);
+		nwt_wave_sync();
+		for (int i = lane; i < m; i += 64) {
+			if (i == j) S[i * mp + j] = ld;
+			else if (i > j) S[i * mp + j] = S[i * mp + j] / ld;
+		}
+		nwt_wave_sync();
+		for (int i = lane; i < m; i += 64)
+			if (i > j) { const double lij = S[i * mp + j]; for (int k2 = j + 1; k2 <= i; k2++) S[i * mp + k2] -= lij * S[k2 * mp + j]; }
+		nwt_wave_sync();
+	}
+	if (bad) { if (lane == 0 && atomicCAS(&A.err[0], 0, 3) == 0) { A.err[1] = b; A.err[2] = 0; } return; }
+	// 5. (A A')^-1 column by column (lane = column): L y = e_c, L' x = y
+	for (int c = lane; c < m; c += 64) {
+		for (int i = 0; i < m; i++) {
+			double s = (i == c) ? 1.0 : 0.0;
+			for (int k2 = 0; k2 < i; k2++) s -= S[i * mp + k2] * Si[k2 * mp + c];
+			Si[i * mp + c] = s / S[i * mp + i];
+		}
+		for (int i = m - 1; i >= 0; i--) {
+			double s = Si[i * mp + c];
+			for (int k2 = i + 1; k2 < m; k2++) s -= S[k2 * mp + i] * Si[k2 * mp + c];
+			Si[i * mp + c] = s / S[i * mp + i];
+		}
+	}
+	nwt_wave_sync();
+	for (int idx = lane; idx < m * m; idx += 64) {   // symmetrise (as the host setup does)
+		const int i = idx / m, j = idx - i * m;
+		if (j < i) { const double a = 0.5 * (Si[i * mp + j] + Si[j * mp + i]); S[i * mp + j] = a; S[j * mp + i] = a; }
+		else if (j == i) S[i * mp + i] = Si[i * mp + i];
+	}
+	nwt_wave_sync();   // S now holds the symmetrised inverse
+	for (int i = lane; i < m; i += 64)
+		for (int e = A.sinv_ptr[i]; e < A.sinv_ptr[i + 1]; e++) A.sinv_val[(size_t)b * snz + e] = S[i * mp + A.sinv_col[e]];
+	// 6. projector Q = A'(A A')^-1 A on the plan's ELL pattern (its padding entries stay 0)
+	for (int idx = lane; idx < qn; idx += 64) {
+		double acc = 0.0;
+		if (!A.q_pad[idx]) {
+			const int t = idx / D.q_w, a = A.q_row2coef[t], c = A.q_col[idx];
+			for (int i = 0; i < m; i++) {
+				const double aia = grid_getA(sup, offe, sw, k, nco, i, a);
+				if (aia == 0.0) continue;
+				double yj = 0.0;
+				for (int j = 0; j < m; j++) yj += S[i * mp + j] * grid_getA(sup, offe, sw, k, nco, j, c);
+				acc += aia * yj;
+			}
+		}
+		A.q_val[(size_t)b * qn + idx] = acc;
+	}
+}
+
+hipError_t ntg_launch_grid_rows(const NtgDims &D, int batch, const double *blk, const int *off, const int *plan_off, double *rowv, int *err, hipStream_t st)
+{
+	hipLaunchKernelGGL(grid_rows_kernel, dim3(batch), dim3(256), 0, st, D, batch, blk, off, plan_off, rowv, err);
+	return hipGetLastError();
+}
+
+hipError_t ntg_launch_grid_lin(const NtgDims &D, int batch, const NtgGridLin &g, hipStream_t st)
+{
+	GridLinArgs A;
+	A.blk = g.blk; A.linrows = g.linrows; A.plan_off = g.plan_off; A.erow = g.erow; A.csr_ptr = g.csr_ptr; A.csr_col = g.csr_col;
+	A.csc_ptr = g.csc_ptr; A.csc_row = g.csc_row; A.sinv_ptr = g.sinv_ptr; A.sinv_col = g.sinv_col; A.q_col = g.q_col; A.q_row2coef = g.q_row2coef;
+	A.q_pad = g.q_pad; A.csr_val = g.csr_val; A.csc_val = g.csc_val; A.sinv_val = g.sinv_val; A.q_val = g.q_val; A.err = g.err;
+	const int m = D.mE, sw = D.nout * D.cls_k[0];
+	const size_t lds = ((size_t)m * sw + 2 * (size_t)m * (m + 1)) * 8 + (size_t)((m + 3) & ~3) * 4;
+	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)grid_lin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(grid_lin_kernel, dim3(batch), dim3(64), lds, st, D, batch, A);
+	return hipGetLastError();
+}

@@ -417,7 +417,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 				    dev_upload(&d_qv, qval.data(), qval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 				T.q_idx = d_qi; T.q_col = d_qc; T.q_val = d_qv;
 				D.q_use = 1; D.q_nt = nt; D.q_w = w;
-				p->h_qidx = qidx; p->h_qcol = qcol;
+				p->h_qidx = qidx; p->h_qcol = qcol; p->h_qval = qval;
 			}
 		}
 		// the general three-step operator (A g, (AA')^-1, A' lam) is staged in LDS only when Q is not used
@@ -1107,112 +1107,91 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 		if (p->precond_singular || !p->T.n0b) return fail(NTG_E_UNSUPPORTED, "per-problem grids with the preconditioner need its block form (one dense block per output)");
 	}
 	hipStream_t st = (hipStream_t)stream;
-	const int P = D.P, k = D.cls_k[0], d = D.cls_d[0], l = D.cls_l[0], n = D.nC, m = D.mE;
+	const int P = D.P, k = D.cls_k[0], d = D.cls_d[0], l = D.cls_l[0], n = D.nC, m = D.mE, nz = D.nz;
 	const size_t nblk = (size_t)P * k * d;
-	// 1. basis blocks and offsets of every problem: one launch of basis_kernel (bsplvd at every collocation point, colloc.c:95-111)
-	double *d_blk = nullptr; int *d_off = nullptr;
-	HIPCHK(hipMalloc((void **)&d_blk, (size_t)batch * nblk * 8));
-	if (hipMalloc((void **)&d_off, (size_t)batch * P * 4) != hipSuccess) { hipFree(d_blk); return fail(NTG_E_HIP, "hipMalloc"); }
-	hipError_t e = ntg_launch_basis(batch, l, k, D.cls_m[0], d, P, d_knots, d_bps, l + 1, P, d_blk, d_off, st);
-	std::vector<double> hblk((size_t)batch * nblk), hbps((size_t)batch * P); std::vector<int> hoff((size_t)batch * P);
-	if (e == hipSuccess) e = hipStreamSynchronize(st);
-	if (e == hipSuccess) e = hipMemcpy(hblk.data(), d_blk, hblk.size() * 8, hipMemcpyDeviceToHost);
-	if (e == hipSuccess) e = hipMemcpy(hoff.data(), d_off, hoff.size() * 4, hipMemcpyDeviceToHost);
-	if (e == hipSuccess) e = hipMemcpy(hbps.data(), d_bps, hbps.size() * 8, hipMemcpyDeviceToHost);
-	hipFree(d_blk); hipFree(d_off);
-	if (e != hipSuccess) return fail(NTG_E_HIP, hipGetErrorString(e));
-	// 2. same combinatorial structure as the plan's grid: every breakpoint in the same knot interval
-	for (int b = 0; b < batch; b++) for (int i = 0; i < P; i++)
-		if (hoff[(size_t)b * P + i] != p->h_off[i]) return fail(NTG_E_BADARG, "per-problem grid: a breakpoint lies in another knot interval than in the plan's grid (problem " + std::to_string(b) + ", breakpoint " + std::to_string(i) + ")");
-	// 3. per-problem values behind the shared index tables
 	const int row_total = D.row_total, lin_nnz = std::max(D.lin_nnz, 1), sinv_nnz = std::max(D.sinv_nnz, 1), qn = D.q_use ? D.q_nt * D.q_w : 0;
-	const size_t n0b_sz = with_precond ? (size_t)p->T.n0b_nblk * p->T.n0b_sp * p->T.n0b_n + 16 : 0;
-	std::vector<double> rowv((size_t)batch * row_total, 0.0), csrv((size_t)batch * lin_nnz, 0.0), cscv((size_t)batch * lin_nnz, 0.0),
-		sinvv((size_t)batch * sinv_nnz, 0.0), qv((size_t)batch * std::max(qn, 1), 0.0), n0bv((size_t)batch * n0b_sz, 0.0);
-	std::atomic<int> next(0), err(0);
-	auto worker = [&]() {
-		std::vector<double> AE, S, Sinv, col(std::max(m, 1));
-		for (;;) {
-			const int b = next.fetch_add(1);
-			if (b >= batch || err.load()) break;
-			const double *blk = hblk.data() + (size_t)b * nblk;
-			// channel rows: rowv[chrow[r] + q P + i] = D^r B_{off+q}(bps[i]); one trailing zero per channel (see ntg_plan_create)
-			double *rv = rowv.data() + (size_t)b * row_total;
-			for (int r = 0; r < d; r++) {
-				const int ch = p->h_chrow[r];
-				if (ch < 0) continue;
-				for (int q = 0; q < k; q++) for (int i = 0; i < P; i++) rv[ch + q * P + i] = blk[((size_t)i * k + q) * d + r];
-			}
-			if (m > 0) {
-				dense_AE_pp(p, blk, AE);
-				// values of A_E in the plan's CSR / CSC patterns; an entry outside the pattern must vanish
-				double *cr = csrv.data() + (size_t)b * lin_nnz, *cc = cscv.data() + (size_t)b * lin_nnz;
-				std::vector<char> seen((size_t)m * n, 0);
-				for (int i = 0; i < m; i++) for (int eidx = p->h_csr_ptr[i]; eidx < p->h_csr_ptr[i + 1]; eidx++) { cr[eidx] = AE[(size_t)i * n + p->h_csr_col[eidx]]; seen[(size_t)i * n + p->h_csr_col[eidx]] = 1; }
-				for (int c = 0; c < n; c++) for (int eidx = p->h_csc_ptr[c]; eidx < p->h_csc_ptr[c + 1]; eidx++) cc[eidx] = AE[(size_t)p->h_csc_row[eidx] * n + c];
-				// ... up to rounding: a final breakpoint one ulp past the last knot (cumulative-add linspace, ntg.c:385-388) leaves ~1e-16
-				// basis values where the plan has exact zeros -- the same relative threshold as build_newton_tables() (the solve re-projects)
-				{
-					bool outside = false;
-					for (int i = 0; i < m && !outside; i++) {
-						double rmax = 0.0;
-						for (int c = 0; c < n; c++) rmax = std::max(rmax, std::fabs(AE[(size_t)i * n + c]));
-						for (int c = 0; c < n; c++) if (!seen[(size_t)i * n + c] && std::fabs(AE[(size_t)i * n + c]) > 1e-10 * rmax) { outside = true; break; }
-					}
-					if (outside) { err.store(1); continue; }   // (the loop head sees err and stops this worker)
-				}
-				// (A A')^-1
-				S.assign((size_t)m * m, 0.0);
-				for (int i = 0; i < m; i++) for (int j = 0; j <= i; j++) { double a = 0.0; for (int c = 0; c < n; c++) a += AE[(size_t)i * n + c] * AE[(size_t)j * n + c]; S[(size_t)i * m + j] = a; S[(size_t)j * m + i] = a; }
-				if (!chol_lower(S, m)) { err.store(2); continue; }
-				Sinv.assign((size_t)m * m, 0.0);
-				for (int j = 0; j < m; j++) { std::fill(col.begin(), col.end(), 0.0); col[j] = 1.0; chol_solve(S, m, col.data()); for (int i = 0; i < m; i++) Sinv[(size_t)i * m + j] = col[i]; }
-				for (int i = 0; i < m; i++) for (int j = 0; j < i; j++) { const double a = 0.5 * (Sinv[(size_t)i * m + j] + Sinv[(size_t)j * m + i]); Sinv[(size_t)i * m + j] = a; Sinv[(size_t)j * m + i] = a; }
-				double *sv = sinvv.data() + (size_t)b * sinv_nnz;
-				for (int i = 0; i < m; i++) for (int eidx = p->h_sinv_ptr[i]; eidx < p->h_sinv_ptr[i + 1]; eidx++) sv[eidx] = Sinv[(size_t)i * m + p->h_sinv_col[eidx]];
-				// projector Q = A'(AA')^-1 A on the plan's ELL pattern
-				if (D.q_use) {
-					double *qq = qv.data() + (size_t)b * qn;
-					for (int a = 0; a < n; a++) {
-						const int t = p->h_qidx[a];
-						if (t < 0) continue;
-						for (int w2 = 0; w2 < D.q_w; w2++) {
-							const int c = p->h_qcol[(size_t)t * D.q_w + w2];
-							double acc = 0.0;
-							for (int i = 0; i < m; i++) { const double aia = AE[(size_t)i * n + a]; if (aia == 0.0) continue; for (int j = 0; j < m; j++) acc += aia * Sinv[(size_t)i * m + j] * AE[(size_t)j * n + c]; }
-							qq[(size_t)t * D.q_w + w2] = acc;   // padded entries repeat column 0 with value... the pattern's padding has value 0 in the plan
-						}
-					}
-				}
-				if (with_precond && precond_blocks_pp(p, blk, hbps.data() + (size_t)b * P, AE, n0bv.data() + (size_t)b * n0b_sz)) { err.store(3); break; }
-			}
+	// batch-shared inputs of the device algebra, uploaded once per plan
+	if (!p->d_planoff) {
+		if (dev_upload(&p->d_planoff, p->h_off.data(), (size_t)P, p->owned)) return NTG_E_HIP;
+		std::vector<double> rows((size_t)std::max(D.nclin, 1) * nz, 0.0);
+		if (D.nlic) std::copy(p->h_lic.begin(), p->h_lic.end(), rows.begin());
+		if (D.nltc) std::copy(p->h_ltc.begin(), p->h_ltc.end(), rows.begin() + (size_t)D.nlic * nz);
+		if (D.nlfc) std::copy(p->h_lfc.begin(), p->h_lfc.end(), rows.begin() + (size_t)(D.nlic + D.nltc) * nz);
+		if (dev_upload(&p->d_linrows, rows.data(), rows.size(), p->owned)) return NTG_E_HIP;
+		std::vector<int> er(std::max(m, 1), 0);
+		for (int e2 = 0; e2 < m; e2++) er[e2] = p->h_erow[e2];
+		if (dev_upload(&p->d_erow, er.data(), er.size(), p->owned)) return NTG_E_HIP;
+		std::vector<int> r2c(std::max(D.q_nt, 1), 0);
+		std::vector<unsigned char> pad((size_t)std::max(qn, 1), 0);
+		if (D.q_use) {
+			for (int a = 0; a < n; a++) if (p->h_qidx[a] >= 0) r2c[p->h_qidx[a]] = a;
+			// ELL padding: entries whose plan value is exactly 0 and that repeat column 0 behind the row's real entries
+			for (int t = 0; t < D.q_nt; t++) for (int w2 = 1; w2 < D.q_w; w2++)
+				if (p->h_qval[(size_t)t * D.q_w + w2] == 0.0 && p->h_qcol[(size_t)t * D.q_w + w2] == 0) pad[(size_t)t * D.q_w + w2] = 1;
 		}
+		if (dev_upload(&p->d_qrow2coef, r2c.data(), r2c.size(), p->owned) || dev_upload(&p->d_qpad, pad.data(), pad.size(), p->owned)) return NTG_E_HIP;
+	}
+	// 1. basis blocks and offsets of every problem: one launch of basis_kernel (bsplvd at every collocation point, colloc.c:95-111)
+	double *d_blk = nullptr; int *d_off = nullptr, *d_err = nullptr;
+	double *d_rowv = nullptr, *d_bpsc = nullptr, *d_csr = nullptr, *d_csc = nullptr, *d_sinv = nullptr, *d_q = nullptr, *d_n0b = nullptr;
+	auto fail_free = [&](int code, const std::string &msg) {
+		for (void *q : {(void *)d_blk, (void *)d_off, (void *)d_err, (void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b}) if (q) hipFree(q);
+		return fail(code, msg);
 	};
-	{
+	const size_t n0b_sz = with_precond ? (size_t)p->T.n0b_nblk * p->T.n0b_sp * p->T.n0b_n + 16 : 0;
+	if (hipMalloc((void **)&d_blk, (size_t)batch * nblk * 8) != hipSuccess || hipMalloc((void **)&d_off, (size_t)batch * P * 4) != hipSuccess ||
+	    hipMalloc((void **)&d_err, 16) != hipSuccess || hipMalloc((void **)&d_rowv, (size_t)batch * row_total * 8) != hipSuccess ||
+	    hipMalloc((void **)&d_bpsc, (size_t)batch * P * 8) != hipSuccess || hipMalloc((void **)&d_csr, (size_t)batch * lin_nnz * 8) != hipSuccess ||
+	    hipMalloc((void **)&d_csc, (size_t)batch * lin_nnz * 8) != hipSuccess || hipMalloc((void **)&d_sinv, (size_t)batch * sinv_nnz * 8) != hipSuccess ||
+	    hipMalloc((void **)&d_q, (size_t)batch * std::max(qn, 1) * 8) != hipSuccess ||
+	    (with_precond && hipMalloc((void **)&d_n0b, (size_t)batch * n0b_sz * 8) != hipSuccess)) return fail_free(NTG_E_HIP, "hipMalloc (per-problem grids)");
+	hipError_t e = hipMemsetAsync(d_err, 0, 16, st);
+	if (e == hipSuccess) e = hipMemsetAsync(d_rowv, 0, (size_t)batch * row_total * 8, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_bpsc, d_bps, (size_t)batch * P * 8, hipMemcpyDeviceToDevice, st);
+	if (e == hipSuccess) e = ntg_launch_basis(batch, l, k, D.cls_m[0], d, P, d_knots, d_bps, l + 1, P, d_blk, d_off, st);
+	// 2. channel rows in the kernels' layout + the structure check (every breakpoint in the plan's knot interval); 3. the algebra of the
+	//    linear rows -- A_E on the plan's patterns, (A A')^-1, Q -- one wavefront per problem, all on the device (grids.hip)
+	if (e == hipSuccess) e = ntg_launch_grid_rows(D, batch, d_blk, d_off, p->d_planoff, d_rowv, d_err, st);
+	if (e == hipSuccess && m > 0) {
+		NtgGridLin g{d_blk, p->d_linrows, p->d_planoff, p->d_erow, p->T.csr_ptr, p->T.csr_col, p->T.csc_ptr, p->T.csc_row, p->T.sinv_ptr, p->T.sinv_col,
+		             p->T.q_col, p->d_qrow2coef, p->d_qpad, d_csr, d_csc, d_sinv, d_q, d_err};
+		e = ntg_launch_grid_lin(D, batch, g, st);
+	}
+	int herr[4] = {0, 0, 0, 0};
+	if (e == hipSuccess) e = hipMemcpyAsync(herr, d_err, 12, hipMemcpyDeviceToHost, st);
+	if (e == hipSuccess) e = hipStreamSynchronize(st);
+	if (e != hipSuccess) return fail_free(NTG_E_HIP, hipGetErrorString(e));
+	if (herr[0] == 1) return fail_free(NTG_E_BADARG, "per-problem grid: a breakpoint lies in another knot interval than in the plan's grid (problem " + std::to_string(herr[1]) + ", breakpoint " + std::to_string(herr[2]) + ")");
+	if (herr[0] == 2) return fail_free(NTG_E_UNSUPPORTED, "per-problem grid: a linear-constraint entry outside the plan's sparsity pattern (problem " + std::to_string(herr[1]) + ", row " + std::to_string(herr[2]) + ")");
+	if (herr[0] == 3) return fail_free(NTG_E_BADARG, "per-problem grid: linear constraint rows are rank deficient (problem " + std::to_string(herr[1]) + ")");
+	// 4. the preconditioner blocks of every grid (hessian = 1): dense n_o x n_o algebra per problem, still on host threads
+	if (with_precond) {
+		std::vector<double> hblk((size_t)batch * nblk), hbps((size_t)batch * P), n0bv((size_t)batch * n0b_sz, 0.0);
+		if (hipMemcpy(hblk.data(), d_blk, hblk.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
+		    hipMemcpy(hbps.data(), d_bps, hbps.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail_free(NTG_E_HIP, "reading the basis blocks back failed");
+		std::atomic<int> next(0), err(0);
+		auto worker = [&]() {
+			std::vector<double> AE;
+			for (;;) {
+				const int b = next.fetch_add(1);
+				if (b >= batch || err.load()) break;
+				const double *blk = hblk.data() + (size_t)b * nblk;
+				dense_AE_pp(p, blk, AE);
+				if (precond_blocks_pp(p, blk, hbps.data() + (size_t)b * P, AE, n0bv.data() + (size_t)b * n0b_sz)) { err.store(3); break; }
+			}
+		};
 		const unsigned nthr = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
 		std::vector<std::thread> pool;
 		for (unsigned t = 0; t + 1 < nthr; t++) pool.emplace_back(worker);
 		worker();
 		for (auto &th : pool) th.join();
+		if (err.load()) return fail_free(NTG_E_UNSUPPORTED, "per-problem grid: preconditioner block not positive definite");
+		if (hipMemcpy(d_n0b, n0bv.data(), n0bv.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail_free(NTG_E_HIP, "uploading the preconditioner blocks failed");
 	}
-	if (err.load() == 1) return fail(NTG_E_UNSUPPORTED, "per-problem grid: a linear-constraint entry outside the plan's sparsity pattern");
-	if (err.load() == 2) return fail(NTG_E_BADARG, "per-problem grid: linear constraint rows are rank deficient");
-	if (err.load() == 3) return fail(NTG_E_UNSUPPORTED, "per-problem grid: preconditioner block not positive definite");
-	// the ELL padding of Q (column 0, value 0 in the plan) must stay zero: entries whose plan value is exactly 0 and that repeat an earlier column
-	if (D.q_use) {
-		std::vector<double> q0((size_t)qn);
-		if (hipMemcpy(q0.data(), p->T.q_val, (size_t)qn * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(NTG_E_HIP, "reading the projector back failed");
-		for (int t = 0; t < D.q_nt; t++) for (int w2 = 1; w2 < D.q_w; w2++)
-			if (q0[(size_t)t * D.q_w + w2] == 0.0 && p->h_qcol[(size_t)t * D.q_w + w2] == 0)
-				for (int b = 0; b < batch; b++) qv[(size_t)b * qn + (size_t)t * D.q_w + w2] = 0.0;
-	}
-	// 4. upload; the kernels add b * stride to the value pointers (NtgTables::pp_*)
+	hipFree(d_blk); hipFree(d_off); hipFree(d_err);
+	// 5. the kernels add b * stride to the value pointers (NtgTables::pp_*)
 	p->T_shared = p->T;
-	double *d_rowv = nullptr, *d_bpsc = nullptr, *d_csr = nullptr, *d_csc = nullptr, *d_sinv = nullptr, *d_q = nullptr, *d_n0b = nullptr;
-	if (dev_upload(&d_rowv, rowv.data(), rowv.size(), p->grid_owned) || dev_upload(&d_bpsc, hbps.data(), hbps.size(), p->grid_owned) ||
-	    dev_upload(&d_csr, csrv.data(), csrv.size(), p->grid_owned) || dev_upload(&d_csc, cscv.data(), cscv.size(), p->grid_owned) ||
-	    dev_upload(&d_sinv, sinvv.data(), sinvv.size(), p->grid_owned) || dev_upload(&d_q, qv.data(), qv.size(), p->grid_owned) ||
-	    dev_upload(&d_n0b, n0bv.data(), n0bv.size(), p->grid_owned)) { ntg_plan_clear_grids(p); for (void *q : p->grid_owned) hipFree(q); p->grid_owned.clear(); return NTG_E_HIP; }
+	for (void *q : {(void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b}) if (q) p->grid_owned.push_back(q);
 	NtgTables &T = p->T;
 	T.rowv = d_rowv; T.pp_rowv = row_total;
 	T.bps = d_bpsc; T.pp_bps = P;

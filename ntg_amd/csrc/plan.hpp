@@ -28,6 +28,10 @@ struct ntg_plan {
 	std::vector<void *> grid_owned;
 	NtgTables T_shared;                         // the tables of the shared grid, restored by ntg_plan_clear_grids
 	double *d_lic = nullptr;                    // [nlic][nz] kept for the receding-horizon shift
+	// per-problem grids on the device (grids.hip): the user's linear rows stacked [nclin][nz], row -> coefficient map and padding mask of
+	// the projector's ELL pattern, the plan's block offsets; the plan's own projector values (host) to tell padding from pattern
+	double *d_linrows = nullptr; int *d_qrow2coef = nullptr, *d_planoff = nullptr, *d_erow = nullptr; unsigned char *d_qpad = nullptr;
+	std::vector<double> h_qval;
 	std::vector<double *> d_knots;              // break sequence of every basis class (ntg_batch_interp)
 };
 
@@ -61,5 +65,12 @@ hipError_t ntg_launch_hostcost(const NtgDims &D, const NtgTables &T, const SmemL
                                hipStream_t st);
 hipError_t ntg_launch_hostcon(const NtgDims &D, const NtgTables &T, const double *dc, double *jband, double *cjac,
                               hipStream_t st);
+// per-problem grids: device-side setup algebra (grids.hip)
+struct NtgGridLin {
+	const double *blk, *linrows; const int *plan_off, *erow, *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col, *q_col, *q_row2coef;
+	const unsigned char *q_pad; double *csr_val, *csc_val, *sinv_val, *q_val; int *err;
+};
+hipError_t ntg_launch_grid_rows(const NtgDims &D, int batch, const double *blk, const int *off, const int *plan_off, double *rowv, int *err, hipStream_t st);
+hipError_t ntg_launch_grid_lin(const NtgDims &D, int batch, const NtgGridLin &g, hipStream_t st);
 hipError_t ntg_launch_mpc_shift(const NtgDims &D, const NtgTables &T, int batch, int sbp, int sknot, const double *lic,
                                 double *x, double *lower, double *upper, hipStream_t st);
