@@ -472,7 +472,7 @@ def main():
         res["eval_kernel"].update({"device_copy_same_bytes_ms": cms, "device_copy_same_bytes_GBps": cgb, "frac_of_device_copy": res["eval_kernel"]["achieved"] / cgb})
         del xe, ca, cb_
         # ---- per-problem grids (free final time): every problem on its own horizon; the basis rows and weights are then per-problem
-        #      input (counted in the algorithmic bytes) and eval_kernel stages them per problem ----
+        #      input (counted in the algorithmic bytes) and the interval kernel stages them per problem and wave; setup on the device ----
         nbg = 16384
         k0 = np.asarray(spec.knots[0]); rngg = np.random.default_rng(3)
         scale = rngg.uniform(0.6, 1.6, nbg)[:, None]
@@ -497,7 +497,7 @@ def main():
         gms = g0.elapsed_time(g1) / 10
         row_bytes = 8 * (sum(1 for r in range(spec.maxderiv[0]) if any(a[1] == r for a in list(spec.tcostav) + list(spec.icostav) + list(spec.fcostav) + list(spec.tcav) + list(spec.icav) + list(spec.fcav))) * spec.order[0] * spec.nbps + spec.nbps)
         gb = nbg * (spec.eval_bytes() + row_bytes)
-        res["per_problem_grids"] = {"workload": spec.name + ", %d horizons in [0.6, 1.6] x the plan's" % nbg, "kernel": "eval_kernel (general instance, value tables staged per problem)",
+        res["per_problem_grids"] = {"workload": spec.name + ", %d horizons in [0.6, 1.6] x the plan's" % nbg, "kernel": "eval_interval_kernel with wave-private interval tables restaged per problem (round 2: the general eval_kernel)",
                                     "batch": nbg, "ms": gms, "alg_bytes_per_eval": spec.eval_bytes() + row_bytes, "achieved": gb / (gms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": gb / (gms * 1e-3) / 1e9 / HBM_PEAK_GBS, "evals_per_s": nbg / (gms * 1e-3),
                                     "set_grids_host_s": setup_s}

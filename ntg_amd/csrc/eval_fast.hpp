@@ -234,7 +234,9 @@ struct IntervalEvalDims {
 
 // NINT: the number of knot intervals as a compile-time constant (every LDS offset of the loop then folds into the instruction).
 // WANT_G: the instance stores gradients (modes 1, 2); a values-only instance has no store in its loop.
-template <int FAM, int NOUT, int OPL, int K, int CHM, int NT, int MINW, int NINT, bool WANT_G>
+// PPG: per-problem grids (ntg_plan_set_grids): the interval tables are wave private and restaged for every problem from the problem's own
+// channel rows and breakpoints (T.rowv + b pp_rowv, T.bps + b pp_bps); one problem per wave at a time (the host checks LP > 32)
+template <int FAM, int NOUT, int OPL, int K, int CHM, int NT, int MINW, int NINT, bool WANT_G, bool PPG = false>
 __global__ void __launch_bounds__(NT, MINW)
 eval_interval_kernel(IntervalEvalDims D, NtgTables T, int batch, int mode, const double *__restrict__ x, double *__restrict__ f,
                      double *__restrict__ g)
@@ -247,27 +249,33 @@ eval_interval_kernel(IntervalEvalDims D, NtgTables T, int batch, int mode, const
 	constexpr int LP = nint * NG, PW = 64 / LP;                     // lanes per problem, problems a wavefront takes at a time
 	// LDS: tables [NCH][SMAX][K][nint] basis values, [SMAX][nint] trapezoid node weights and interval lengths; per wave: coefficient /
 	// gradient staging [PW][nC] and one partial cost per lane
-	double *s_bt = (double *)smem_raw;
+	constexpr int TABD = NCH * SMAX * K * nint + 2 * SMAX * nint;   // doubles of one set of interval tables
+	double *s_bt = (double *)smem_raw + (PPG ? (size_t)wave * TABD : 0);
 	double *s_wt = s_bt + NCH * SMAX * K * nint;
 	double *s_dt = s_wt + SMAX * nint;
-	double *s_xs = s_dt + SMAX * nint + (size_t)wave * (PW * nC + 64);
+	double *s_xs = (double *)smem_raw + (PPG ? (size_t)NW * TABD : TABD) + (size_t)wave * (PW * nC + 64);
 	double *s_fs = s_xs + PW * nC;
-	for (int e = tid; e < NCH * SMAX * K * nint; e += NT) {
-		const int t = e % nint, q = (e / nint) % K, s2 = (e / (nint * K)) % SMAX, ch = e / (nint * K * SMAX);
-		int r = 0, seen = -1;
-		for (int rr = 0; rr < DM; rr++) if ((CHM >> rr) & 1) { seen++; if (seen == ch) r = rr; }
-		const int i = D.igb[t] + s2;
-		s_bt[e] = i < D.igb[t + 1] ? T.rowv[D.chrow[r] + q * P + i] : 0.0;
-	}
-	for (int e = tid; e < SMAX * nint; e += NT) {
-		const int t = e % nint, s2 = e / nint, i = D.igb[t] + s2;
-		double w = 0.0, dt = 0.0;
-		if (i < D.igb[t + 1]) {
-			if (i > 0) w += (T.bps[i] - T.bps[i - 1]) / 2;
-			if (i < P - 1) { w += (T.bps[i + 1] - T.bps[i]) / 2; dt = T.bps[i + 1] - T.bps[i]; }
+	// tables of grid `gb` into (s_bt, s_wt, s_dt): by the whole workgroup (shared grid) or by one wave (its problem's grid)
+	auto stage = [&](int gb, int t0, int tstep) {
+		const double *rowv = T.rowv + (size_t)gb * T.pp_rowv, *bps = T.bps + (size_t)gb * T.pp_bps;
+		for (int e = t0; e < NCH * SMAX * K * nint; e += tstep) {
+			const int t = e % nint, q = (e / nint) % K, s2 = (e / (nint * K)) % SMAX, ch = e / (nint * K * SMAX);
+			int r = 0, seen = -1;
+			for (int rr = 0; rr < DM; rr++) if ((CHM >> rr) & 1) { seen++; if (seen == ch) r = rr; }
+			const int i = D.igb[t] + s2;
+			s_bt[e] = i < D.igb[t + 1] ? rowv[D.chrow[r] + q * P + i] : 0.0;
 		}
-		s_wt[e] = w; s_dt[e] = dt;
-	}
+		for (int e = t0; e < SMAX * nint; e += tstep) {
+			const int t = e % nint, s2 = e / nint, i = D.igb[t] + s2;
+			double w = 0.0, dt = 0.0;
+			if (i < D.igb[t + 1]) {
+				if (i > 0) w += (bps[i] - bps[i - 1]) / 2;
+				if (i < P - 1) { w += (bps[i + 1] - bps[i]) / 2; dt = bps[i + 1] - bps[i]; }
+			}
+			s_wt[e] = w; s_dt[e] = dt;
+		}
+	};
+	if (!PPG) stage(0, tid, NT);
 	__syncthreads();
 	const int pl = lane / LP, rl = lane - pl * LP, t = rl / NG, og = rl - t * NG, o0 = og * OPL;
 	const bool lane_on = pl < PW;
@@ -295,6 +303,7 @@ eval_interval_kernel(IntervalEvalDims D, NtgTables T, int batch, int mode, const
 	for (int e = 0; e < XE; e++) xn[e] = x[(size_t)min(wid * PW + nwaves * PW + spl[e], batch - 1) * nC + sof[e]];
 	for (int b0 = wid * PW; b0 < batch; b0 += nwaves * PW) {
 		nwt_wave_sync();
+		if (PPG) { stage(b0, lane, 64); nwt_wave_sync(); }   // this problem's grid (PW == 1)
 		const bool on = lane_on && b0 + pl < batch;
 		// the interval's K coefficients of this lane's outputs
 		double xb[OPL][K];
@@ -420,10 +429,18 @@ static hipError_t launch_eval_interval(const NtgTables &T, const IntervalEvalDim
 #endif
 	constexpr int NT = NTG_EVI_NT, NW = NT / 64, NCH = chm_count(CHM);
 	const int ncu = a.ncu > 0 ? a.ncu : 256, PW = 64 / (F.nint * (NOUT / OPL));
-	const size_t lds = ((size_t)NCH * 6 * K * F.nint + 2 * 6 * F.nint + (size_t)NW * (PW * F.nC + 64)) * 8;
+	const bool ppg = T.pp_rowv != 0;
+	if (ppg && PW != 1) return hipErrorInvalidValue;   // (the caller checks: wave-private tables hold one grid)
+	const size_t lds = ((size_t)(ppg ? NW : 1) * (NCH * 6 * K * F.nint + 2 * 6 * F.nint) + (size_t)NW * (PW * F.nC + 64)) * 8;
 	const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(MINW * 4 / NW, (160 * 1024) / lds));   // MINW waves per SIMD = 4 MINW waves per CU
 	const int need = (a.batch + NW * PW - 1) / (NW * PW);
 	const int grid = std::max(1, std::min(need, ncu * wg_per_cu));
+	if (ppg) {
+		auto kfn = eval_interval_kernel<FAM, NOUT, OPL, K, CHM, NT, MINW, NINT, true, true>;
+		if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(kfn, dim3(grid), dim3(NT), lds, a.st, F, T, a.batch, a.mode, a.x, a.f, a.g);
+		return hipGetLastError();
+	}
 	if (a.g && a.mode != 0) {
 		auto kfn = eval_interval_kernel<FAM, NOUT, OPL, K, CHM, NT, MINW, NINT, true>;
 		if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

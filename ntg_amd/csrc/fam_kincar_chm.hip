@@ -11,6 +11,12 @@ hipError_t ntg_launch_eval_kincar_chm(const NtgDims &D, const NtgTables &T, cons
 	// values and gradient only (no Jacobian outputs: the family has no constraints): the lean kernel
 	IntervalEvalDims FI;
 	const bool shared_grid = T.pp_rowv == 0;   // the lean kernels stage one grid per workgroup: per-problem grids take eval_kernel
+	// per-problem grids: the interval kernel with wave-private tables restaged per problem (shapes that fill more than half a wave: one
+	// problem per wave at a time); needs the gradient output (its store slots are unconditional)
+	if (!shared_grid && !a.c && !a.jb && !a.cj && a.g && a.mode != 0 && !getenv("NTG_AMD_EVAL_V1")) {
+		if (D.nout == 4 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 4, 2, 6, 4, 4, 20>(T, FI, a);
+		if (D.nout == 6 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 6, 2, 6, 4, 4, 20>(T, FI, a);
+	}
 	if (shared_grid && !a.c && !a.jb && !a.cj && !getenv("NTG_AMD_EVAL_V1")) {   // one lane per (knot interval, pair of outputs)
 		// (instances for 20 knot intervals: BASELINE's kincar configs; other grids take the breakpoint-lane kernel below)
 		if (D.nout == 2 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 2, 2, 6, 4, 4, 20>(T, FI, a);

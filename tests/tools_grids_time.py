@@ -21,3 +21,14 @@ for rep in range(3):
     torch.cuda.synchronize(); print(f"set_grids({nbg}, no preconditioner): {1e3 * (time.perf_counter() - t):.2f} ms", flush=True)
 t = time.perf_counter(); pg.set_grids(knd[:2048], bpd[:2048], with_precond=True); torch.cuda.synchronize()
 print(f"set_grids(2048, with preconditioner blocks on host threads): {1e3 * (time.perf_counter() - t):.1f} ms", flush=True)
+pg.set_grids(knd, bpd, with_precond=False)
+xg = torch.randn((nbg, spec.nC), dtype=torch.float64, device=dev)
+og = pg.eval(xg, 2); pg.eval(xg, 2, out=og); torch.cuda.synchronize()
+g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+g0.record()
+for _ in range(10):
+    pg.eval(xg, 2, out=og)
+g1.record(); torch.cuda.synchronize()
+gms = g0.elapsed_time(g1) / 10
+gb = nbg * 11712
+print(f"per-problem-grid evaluation: {gms:.4f} ms per {nbg}: {gb / (gms * 1e-3) / 1e9:.0f} GB/s = {gb / (gms * 1e-3) / 1e9 / 8000:.3f} of the HBM spec", flush=True)
