@@ -368,6 +368,33 @@ def main():
                                        "inform_counts": {str(k): int((infO == k).sum()) for k in np.unique(infO)},
                                        "iters_mean": float(ooO["iters"].float().mean().item()), "iters_max": int(ooO["iters"].max().item())}
         del wO
+        # ---- receding horizon WITH a nonlinear inequality row (obstacle family): multiplier estimates carried over and shifted with the
+        #      horizon (ntg_solve_opts.warm_start, ntg_batch_mpc_shift_multipliers) against re-solving every step from lambda = 0 ----
+        nbM, nresM = 1024, 20
+        loM, upM = cf.obstacle_bounds(nbM)
+        mo = {}
+        for tag, ws in (("cold_every_step", 0), ("multipliers_carried_over", 1)):
+            oM = api.default_opts(hessian=1, warm_start=ws)
+            wM = torch.empty(planO.workspace_bytes(nbM, oM), dtype=torch.uint8, device=dev)
+            loM1 = torch.tensor(loM, device=dev); upM1 = torch.tensor(upM, device=dev)
+            xM = torch.ones((nbM, specO.nC), dtype=torch.float64, device=dev)
+            o_first = api.default_opts(hessian=1)
+            planO.solve(loM1, upM1, xM, o_first, work=wM); planO.mpc_shift(xM, loM1, upM1, 5, 1)
+            if ws:
+                planO.mpc_shift_multipliers(nbM, 5, oM, wM)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            maj = 0; notc = 0
+            for _ in range(nresM):
+                ooM = planO.solve(loM1, upM1, xM, oM, work=wM)
+                planO.mpc_shift(xM, loM1, upM1, 5, 1)
+                if ws:
+                    planO.mpc_shift_multipliers(nbM, 5, oM, wM)
+                maj += float(ooM["iters"].float().mean().item()); notc += int((ooM["inform"] != 0).sum().item())
+            torch.cuda.synchronize(); dtM = time.perf_counter() - t1
+            mo[tag] = {"value": nbM * nresM / dtM, "unit": "re-solves/s", "ms_per_resolve_batch": 1e3 * dtM / nresM, "majors_per_resolve": maj / nresM, "not_converged": notc}
+            del wM
+        mo["workload"] = specO.name + f": {nresM} re-solves x {nbM}, advance one knot interval per re-solve (host loop: solve, shift, multiplier shift)"
+        res["mpc_obstacle"] = mo
         # ---- BASELINE configs D and E at their full sizes, to convergence (per-GPU share of the 8-GPU batch): the structured
         #      Newton mode (hessian = 2) and, beside it, the quasi-Newton mode of round 1.  (`bench.py --config D|E
         #      --gpus N` times the same solve as the headline of its own line, sharded over N GPUs.) ----

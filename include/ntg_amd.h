@@ -91,6 +91,10 @@ typedef struct {
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
 	int block_threads;  /* 0 = auto (128/256/512) */
 	int qn_memory;      /* quasi-Newton updates kept before the approximation restarts from W0; <= 0: 256 */
+	int warm_start;     /* plans with nonlinear / inequality rows: 1 = start the augmented-Lagrangian loop from the multiplier estimates the
+	                     * previous ntg_batch_solve of the same batch left in d_work (the use NPSOL's clambda was meant for, ntg.h:64-68:
+	                     * receding-horizon re-solves; ntg_batch_mpc_run shifts them with the horizon), 0 = multipliers start at 0.
+	                     * The structured Newton mode then skips its pass on the objective alone. */
 } ntg_solve_opts;
 
 typedef struct ntg_plan ntg_plan;
@@ -184,6 +188,13 @@ int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, int shift_kn
  * first step the (solve, shift) pair is replayed as a hipGraph.  d_inform [batch] receives the last step's inform,
  * d_notconv [1] (may be NULL; zero it first) accumulates the number of problems whose re-solve did not end with inform 0.
  * With stream == NULL the run uses a private stream and returns when it has finished. */
+/* The multiplier part of the receding-horizon step: the estimates of the trajectory rows kept in d_work move shift_bp breakpoints towards the
+ * start of the horizon (row (j, i) <- row (j, i + shift_bp), the tail starts at 0), ready for a solve with warm_start = 1.
+ * ntg_batch_mpc_run does this itself when the options ask for a warm start; callers that run their own loop call it after
+ * ntg_batch_mpc_shift.  No-op for plans without such rows. */
+int ntg_batch_mpc_shift_multipliers(const ntg_plan *p, int batch, int shift_bp, const ntg_solve_opts *o, void *d_work, long long work_bytes,
+                                    void *stream);
+
 int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int shift_bp, int shift_knots, double *d_x,
                       double *d_lower, double *d_upper, const ntg_solve_opts *o, int *d_inform, int *d_notconv,
                       void *d_work, long long work_bytes, void *stream);

@@ -41,7 +41,7 @@ class _Spec(C.Structure):
 class SolveOpts(C.Structure):
     _fields_ = [("itlim", C.c_int), ("opttol", C.c_double), ("steplimit", C.c_double),
                 ("ls_mu", C.c_double), ("ls_eta", C.c_double), ("ls_maxfev", C.c_int),
-                ("hessian", C.c_int), ("fixed_iters", C.c_int), ("block_threads", C.c_int), ("qn_memory", C.c_int)]
+                ("hessian", C.c_int), ("fixed_iters", C.c_int), ("block_threads", C.c_int), ("qn_memory", C.c_int), ("warm_start", C.c_int)]
 
 
 _lib = None
@@ -71,6 +71,7 @@ def lib():
                                       C.c_longlong, C.c_void_p]
         L.ntg_basis_batch.argtypes = [C.c_int] * 6 + [C.c_void_p] * 5
         L.ntg_batch_mpc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_longlong, C.c_void_p]
+        L.ntg_batch_mpc_shift_multipliers.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
         L.ntg_batch_interp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ntg_plan_set_grids.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ntg_plan_clear_grids.argtypes = [C.c_void_p]
@@ -249,6 +250,10 @@ class Plan:
         """Receding-horizon step in place: re-pin initial bounds to the solution's flag at breakpoint
         shift_bp, shift the coefficients by shift_knots knot intervals."""
         _check(lib().ntg_batch_mpc_shift(self.h, x.shape[0], shift_bp, shift_knots, _ptr(x), _ptr(lower), _ptr(upper), self._stream()))
+
+    def mpc_shift_multipliers(self, batch: int, shift_bp: int, opts: SolveOpts, work):
+        """The multipliers' share of the receding-horizon step: estimates in `work` move shift_bp breakpoints towards the start of the horizon."""
+        _check(lib().ntg_batch_mpc_shift_multipliers(self.h, batch, shift_bp, C.byref(opts), _ptr(work), work.numel() * work.element_size(), self._stream()))
 
     def mpc_run(self, x, lower, upper, nsteps: int, shift_bp: int, shift_knots: int, opts: Optional[SolveOpts] = None, work=None):
         """nsteps x (solve, shift) inside the library (hipGraph replay).  Returns (inform of the last step, #not converged)."""

@@ -453,6 +453,26 @@ hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const
 	return hipGetLastError();
 }
 
+// Receding horizon: the multiplier estimates of the trajectory rows move sbp breakpoints towards the start (row (j, i) <- row (j, i + sbp));
+// what enters the window at its end starts at 0.  alw: [batch][2][nal], estimates in the second half (what a warm-started solve reads).
+// One workgroup per (problem, trajectory constraint); the read of element i + sbp happens before any lane writes it (two phases).
+__global__ void mpc_shift_lambda_kernel(NtgDims D, int batch, int sbp, double *__restrict__ alw)
+{
+	extern __shared__ double s_row[];
+	const int b = blockIdx.x / D.nnltc, j = blockIdx.x % D.nnltc, P = D.P, nal = D.ncnln + D.nI;
+	if (b >= batch) return;
+	double *t = alw + (size_t)b * 2 * nal + nal + D.nnlic + (size_t)j * P;
+	for (int i = threadIdx.x; i < P; i += blockDim.x) s_row[i] = i + sbp < P ? t[i + sbp] : 0.0;
+	__syncthreads();
+	for (int i = threadIdx.x; i < P; i += blockDim.x) t[i] = s_row[i];
+}
+hipError_t ntg_launch_mpc_shift_lambda(const NtgDims &D, int batch, int sbp, double *alw, hipStream_t st)
+{
+	if (D.nnltc <= 0) return hipSuccess;
+	hipLaunchKernelGGL(mpc_shift_lambda_kernel, dim3(batch * D.nnltc), dim3(128), (size_t)D.P * 8, st, D, batch, sbp, alw);
+	return hipGetLastError();
+}
+
 // SplineInterp (colloc.c:449-484) for a batch: flat flag of every problem at ntimes shared points in time.
 // tblk [class][t][q][r] and toff [class][t] come from basis_kernel run on the times instead of the breakpoints;
 // one thread per (problem, time, flag entry), consecutive threads = consecutive flag entries of one time.

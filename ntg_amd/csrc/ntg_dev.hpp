@@ -122,6 +122,7 @@ struct SmemLayout {
 struct SolveParams {
 	int itlim, memcap, ls_maxfev, hessian, fixed_iters;
 	int stamps;   // diagnostic: clambda[b][0..7] receives per-phase cycle counts instead of multipliers
+	int warm;     // augmented-Lagrangian rows: start from the multiplier estimates the previous solve left in the workspace
 	double sr, steplimit, ls_mu, ls_eta;
 };
 

@@ -37,7 +37,7 @@ extern "C" int ntg_device_count(void)
 extern "C" void ntg_default_opts(ntg_solve_opts *o)
 {
 	o->itlim = 0; o->opttol = 0.0; o->steplimit = 2.0; o->ls_mu = 1e-4; o->ls_eta = 0.9;
-	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->block_threads = 0; o->qn_memory = 0;
+	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->block_threads = 0; o->qn_memory = 0; o->warm_start = 0;
 }
 extern "C" const char *ntg_solve_kernel_name(void) { return "sqp_kernel"; }
 extern "C" const char *ntg_batch_solve_kernel(const ntg_plan *p, int batch, const ntg_solve_opts *o);
@@ -755,7 +755,7 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	sp->itlim = o->itlim > 0 ? o->itlim : std::max(50, 3 * (D.nC + D.nclin) + 10 * D.ncnln);
 	sp->memcap = std::min(sp->itlim, o->qn_memory > 0 ? o->qn_memory : 256);
 	sp->ls_maxfev = o->ls_maxfev > 0 ? o->ls_maxfev : 20;
-	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters;
+	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters; sp->warm = o->warm_start ? 1 : 0;
 	if (sp->hessian == 2 && !D.nwt_on) sp->hessian = 1;   // the structured Newton mode does not apply: collocation preconditioner
 	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
@@ -941,6 +941,25 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 // A receding-horizon run: nsteps times (solve, shift).  The first step runs directly (it may build the preconditioner);
 // the (solve, count, shift) sequence of the remaining steps is captured once into a hipGraph and replayed, so that a
 // step costs one graph launch instead of three kernel launches from the host loop.
+// The multipliers' share of the receding-horizon step (see ntg_amd.h): the estimates of the trajectory rows in the workspace move shift_bp
+// breakpoints towards the start of the horizon.
+extern "C" int ntg_batch_mpc_shift_multipliers(const ntg_plan *p, int batch, int shift_bp, const ntg_solve_opts *o, void *d_work, long long work_bytes,
+                                               void *stream)
+{
+	if (!p) return fail(NTG_E_BADARG, "null plan");
+	if (batch <= 0) return 0;
+	const NtgDims &D = p->D;
+	if (D.ncnln + D.nI == 0 || D.nnltc == 0 || shift_bp == 0) return 0;
+	if (shift_bp < 0 || shift_bp >= D.P) return fail(NTG_E_BADARG, "shift out of range");
+	if (!d_work || work_bytes < ntg_batch_workspace_bytes(p, batch, o)) return fail(NTG_E_BADARG, "workspace too small");
+	SolveParams sp; int nt;
+	resolve_params(p, o, &sp, &nt);
+	HIPCHK(hipSetDevice(p->device));
+	double *alw = (double *)d_work + hist_doubles(D, batch, sp);   // [batch][2][ncnln + nI]: multipliers, estimates (as ntg_batch_solve lays it out)
+	HIPCHK(ntg_launch_mpc_shift_lambda(D, batch, shift_bp, alw, (hipStream_t)stream));
+	return 0;
+}
+
 extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int shift_bp, int shift_knots, double *d_x,
                                  double *d_lower, double *d_upper, const ntg_solve_opts *o, int *d_inform, int *d_notconv,
                                  void *d_work, long long work_bytes, void *stream)
@@ -957,7 +976,10 @@ extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int s
 		int rc = ntg_batch_solve(p, batch, d_lower, d_upper, d_x, o, nullptr, d_inform, nullptr, nullptr, nullptr, d_work, work_bytes, st);
 		if (rc) return rc;
 		if (d_notconv) { hipError_t e = ntg_launch_count_notconv(batch, d_inform, d_notconv, st); if (e != hipSuccess) return fail(NTG_E_HIP, hipGetErrorString(e)); }
-		return ntg_batch_mpc_shift(p, batch, shift_bp, shift_knots, d_x, d_lower, d_upper, st);
+		rc = ntg_batch_mpc_shift(p, batch, shift_bp, shift_knots, d_x, d_lower, d_upper, st);
+		if (rc) return rc;
+		if (o && o->warm_start) rc = ntg_batch_mpc_shift_multipliers(p, batch, shift_bp, o, d_work, work_bytes, st);   // the multipliers travel with the horizon
+		return rc;
 	};
 	int rc = 0;
 	if (own) rc = hipDeviceSynchronize() == hipSuccess ? 0 : NTG_E_HIP;   // order after work queued on the default stream

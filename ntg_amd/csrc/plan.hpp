@@ -65,6 +65,7 @@ hipError_t ntg_launch_hostcost(const NtgDims &D, const NtgTables &T, const SmemL
                                hipStream_t st);
 hipError_t ntg_launch_hostcon(const NtgDims &D, const NtgTables &T, const double *dc, double *jband, double *cjac,
                               hipStream_t st);
+hipError_t ntg_launch_mpc_shift_lambda(const NtgDims &D, int batch, int sbp, double *alw, hipStream_t st);
 // per-problem grids: device-side setup algebra (grids.hip)
 struct NtgGridLin {
 	const double *blk, *linrows; const int *plan_off, *erow, *csr_ptr, *csr_col, *csc_ptr, *csc_row, *sinv_ptr, *sinv_col, *q_col, *q_row2coef;

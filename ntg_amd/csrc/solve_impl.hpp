@@ -1378,7 +1378,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 #define NTG_STAMP(slot) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot] += now_ - tlast; tlast = now_; } } while (0)
 	if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
 	const bool alprob = (HASCON && ncn > 0) || nI > 0;   // rows handled by the augmented-Lagrangian loop
-	ALState al{(alprob && !NWT) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
+	ALState al{(alprob && (!NWT || sp.warm)) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
 	// structured Newton mode: band matrix / factor and the per-breakpoint blocks of this problem (HBM), flags
 	using FamN = Family<FAM>;
 	constexpr int NWT_CG2 = FamN::CG * FamN::CG;
@@ -1387,7 +1387,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	bool nwt_curv = false;        // the current factor includes the constraint curvature
 	int nwt_bad = 0;              // diagnostic: non-positive pivots replaced in Gauss-Newton factorisations (wave 0's count)
 	int nwt_nfact = 0, nwt_nfail = 0, nwt_napply = 0;   // diagnostic (sp.stamps == 3): factorisations, of which not positive definite, solves
-	bool phase0 = NWT && alprob;  // the pass on the objective alone is still running
+	bool phase0 = NWT && alprob && !sp.warm;  // the pass on the objective alone is still running (a warm start goes straight to the multipliers it was given)
 	int *nwt_flag = (int *)(smem_raw + L.red) + 2 * (32 * (NT / 64) + 2) - 2;   // last word pair of the reduction scratch: "not positive definite"
 	// K = model at the trial point buffer `xs` (must be the iterate x; needs the multiplier estimates al_t of the evaluation
 	// at x), factored; then out = W v.  allow_curv = false: Gauss-Newton terms only.
@@ -1503,7 +1503,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		make_feasible();
 		for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 		if (alprob) {
-			for (int j = tid; j < nal; j += NT) { al_lam[j] = 0.0; if (NWT) al_t[j] = 0.0; }
+			// cold: multipliers 0.  Warm (ntg_solve_opts.warm_start): the estimates the previous solve of this batch left in the workspace
+			// (shifted with the horizon by ntg_batch_mpc_shift_multipliers) are the starting multipliers
+			for (int j = tid; j < nal; j += NT) {
+				if (sp.warm) al_lam[j] = al_t[j];
+				else { al_lam[j] = 0.0; if (NWT) al_t[j] = 0.0; }
+			}
 			sri = fmax(sp.sr, 1e-3);
 			__syncthreads();   // multipliers cross lanes through HBM: full barrier
 		}

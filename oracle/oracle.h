@@ -125,6 +125,9 @@ typedef struct {
 	int verbose;
 	int qn_memory;       /* BFGS updates kept before W restarts from W0 (the device's pair memory); <= 0: 256 */
 	int banded;          /* 1: evaluate with the banded, allocation-free path (orc_problem.banded) -- timing flavour only */
+	const double *warm_lam; /* NULL: multipliers of the augmented-Lagrangian rows start at 0.  Else [ncnln + nI] starting multipliers in
+	                      * the internal sign (= -clambda of those rows): the warm start of a receding-horizon re-solve (ntg.h:64-68);
+	                      * the structured Newton mode then skips its pass on the objective alone (mirrors ntg_solve_opts.warm_start) */
 } orc_sqp_opts;
 void orc_sqp_default_opts(orc_sqp_opts *o);
 

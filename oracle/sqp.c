@@ -40,7 +40,7 @@
 void orc_sqp_default_opts(orc_sqp_opts *o)
 {
 	o->itlim = 0; o->opttol = 0.0; o->steplimit = 2.0; o->ls_mu = 1e-4; o->ls_eta = 0.9;
-	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->verbose = 0; o->qn_memory = 0; o->banded = 0;
+	o->ls_maxfev = 20; o->hessian = 0; o->fixed_iters = 0; o->verbose = 0; o->qn_memory = 0; o->banded = 0; o->warm_lam = NULL;
 }
 
 /* ---------------- dense helpers (column-major, ld explicit) ---------------- */
@@ -705,6 +705,7 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	pj.A = AE; pj.n = n; pj.m = m; pj.S = NULL; pj.tmpm = malloc((m + 1) * sizeof(double));
 	al.p = p; al.n = n; al.nc = nc; al.mu = 10.0; al.nfev = 0; al.nI = nI; al.irow = irow;
 	al.lam = calloc(nal + 1, sizeof(double)); al.tnew = calloc(nal + 1, sizeof(double)); al.c = calloc(nal + 1, sizeof(double));
+	if (o->warm_lam && nal > 0) memcpy(al.lam, o->warm_lam, (size_t)nal * sizeof(double));
 	if (m > 0) {
 		pj.S = malloc((size_t)m * m * sizeof(double));
 		for (i = 0; i < m; i++) for (j = 0; j < m; j++) {
@@ -721,7 +722,7 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 		W0 = malloc((size_t)n * n * sizeof(double));
 		if (build_colloc_W0(p, AE, m, W0)) { free(W0); W0 = NULL; }
 	}
-	if (newton) { nw = nwt_make(p, AE, m); al.mu = 0.0; outer0 = -1; }
+	if (newton) { nw = nwt_make(p, AE, m); if (!(o->warm_lam && nal > 0)) { al.mu = 0.0; outer0 = -1; } else al.mu = NWT_MU0; }
 /* out = W v, and the restart of W (from W0 / the identity, or -- structured Newton mode -- a Gauss-Newton refactorisation at x) */
 #define APPLY_W(v, out) do { if (nw) nwt_apply(nw, (v), (out)); else { int i_, j_; for (i_ = 0; i_ < n; i_++) { double sum_ = 0.0; for (j_ = 0; j_ < n; j_++) sum_ += M_(W, n, i_, j_) * (v)[j_]; (out)[i_] = sum_; } } } while (0)
 #define RESET_W() do { nupd = 0; if (nw) nwt_refresh(nw, x, al.mu, t_x, 0); else if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double)); \

@@ -38,7 +38,7 @@ class AVc(C.Structure):
 class Opts(C.Structure):
     _fields_ = [("itlim", C.c_int), ("opttol", C.c_double), ("steplimit", C.c_double),
                 ("ls_mu", C.c_double), ("ls_eta", C.c_double), ("ls_maxfev", C.c_int),
-                ("hessian", C.c_int), ("fixed_iters", C.c_int), ("verbose", C.c_int), ("qn_memory", C.c_int), ("banded", C.c_int)]
+                ("hessian", C.c_int), ("fixed_iters", C.c_int), ("verbose", C.c_int), ("qn_memory", C.c_int), ("banded", C.c_int), ("warm_lam", C.c_void_p)]
 
 
 class Result(C.Structure):
@@ -168,9 +168,13 @@ def solve_batch(spec, lowerb, upperb, x0, opts=None, nthreads=1):
     return dict(x=x, objective=obj, inform=inform, iters=iters, nfev=nfev)
 
 
-def solve_one(spec, lowerb, upperb, x0, opts=None, trace_cap=0, want_R=False):
+def solve_one(spec, lowerb, upperb, x0, opts=None, trace_cap=0, want_R=False, warm_lam=None):
+    """warm_lam: starting multipliers of the augmented-Lagrangian rows [ncnln + nI], internal sign (= -clambda of those rows)"""
     cs = CSpec(spec)
     o = opts or default_opts()
+    if warm_lam is not None:
+        wl = np.ascontiguousarray(warm_lam, dtype=np.float64)
+        o.warm_lam = wl.ctypes.data
     lo = np.ascontiguousarray(lowerb, dtype=np.float64); up = np.ascontiguousarray(upperb, dtype=np.float64)
     x = np.array(x0, dtype=np.float64, copy=True)
     res = Result()

@@ -100,3 +100,45 @@ def test_mpc_run_graph_replay_is_the_host_loop():
     torch.cuda.synchronize()
     assert int(bad.item()) == 0 and (inform == 0).all()
     assert torch.equal(x1, x2) and torch.equal(lo1, lo2) and torch.equal(up1, up2)
+
+
+def test_obstacle_mpc_with_multiplier_carry_over():
+    """Receding horizon with a nonlinear inequality row (kincar + circular obstacle): the multiplier estimates travel with the horizon
+    (ntg_solve_opts.warm_start + ntg_batch_mpc_shift_multipliers -- the use NPSOL's clambda was meant for, ntg.h:64-68).  Every re-solve
+    is compared with the oracle started from the SAME multipliers, and the carry-over has to pay: fewer majors than re-solving cold."""
+    spec = cf.config_O(20); p = api.Plan(spec, 0)
+    nb, nsteps, sknot = 6, 4, 1
+    sbp = 5 * sknot
+    P, n0 = spec.nbps, spec.nC + spec.nclin
+    lo, up = cf.obstacle_bounds(nb)
+    cold, warm = api.default_opts(hessian=1), api.default_opts(hessian=1, warm_start=1)
+    work = torch.empty(p.workspace_bytes(nb, warm), dtype=torch.uint8, device="cuda:0")
+
+    def loop(carry):
+        x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+        lo_d, up_d = dev(lo), dev(up)
+        majors, lam_prev = 0, None
+        for step in range(nsteps):
+            o = warm if (carry and step > 0) else cold
+            lo_h, up_h, x_h = lo_d.cpu().numpy(), up_d.cpu().numpy(), x.cpu().numpy()
+            out = p.solve(lo_d, up_d, x, o, work=work, want_lambda=True)
+            torch.cuda.synchronize()
+            assert (out["inform"].cpu().numpy() == 0).all(), (step, out["inform"])
+            majors += int(out["iters"].sum().item())
+            if carry:
+                for i in range(nb):   # the oracle on exactly this re-solve: same bounds, same start, same starting multipliers
+                    ref = orc.solve_one(spec, lo_h[i], up_h[i], x_h[i], orc.default_opts(hessian=1), warm_lam=None if lam_prev is None else lam_prev[i])
+                    assert ref["inform"] == 0
+                    assert abs(out["objective"][i].item() - ref["objective"]) <= 1e-9 * max(1.0, abs(ref["objective"])), (step, i)
+                    assert np.abs(x[i].cpu().numpy() - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max()), (step, i)
+                    assert abs(int(out["iters"][i]) - ref["iters"]) <= 2, (step, i, int(out["iters"][i]), ref["iters"])
+            lam = -out["clambda"][:, n0:].cpu().numpy()                 # internal sign of the nonlinear rows' estimates
+            p.mpc_shift(x, lo_d, up_d, sbp, sknot)
+            if carry:
+                p.mpc_shift_multipliers(nb, sbp, warm, work)
+                lam_prev = np.concatenate([lam[:, sbp:], np.zeros((nb, sbp))], axis=1)   # numpy statement of the multiplier shift
+        return majors
+
+    m_warm = loop(True)
+    m_cold = loop(False)
+    assert m_warm < m_cold, (m_warm, m_cold)
