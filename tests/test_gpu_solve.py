@@ -189,3 +189,34 @@ def test_c_abi_error_returns():
     rc = L.ntg_batch_eval(p.h, 1, x.data_ptr(), 5, None, None, None, None, None, None)
     assert rc == -2 and b"mode" in L.ntg_last_error()
     assert torch.equal(x, torch.ones_like(x))                      # nothing was touched
+
+
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M4", 2), ("M", 3)])
+def test_wave_kernel_is_what_runs_and_agrees_with_the_workgroup_kernel(name, ncars):
+    """The kincar class is solved by sqp_wave_kernel (one wavefront per problem, solve_wave.hpp); NTG_AMD_NOWAVE=1 forces sqp_kernel.
+    Same algorithm, different summation orders: identical evaluation counts in the fixed-work mode, objectives to 1e-7 (both are
+    within 1e-7 of the oracle, test_fixed_50_majors_parity_with_oracle), optima to 1e-9 / 1e-6; every other plan reports sqp_kernel."""
+    import os
+    p = plan_for(name); spec = p.spec
+    nb = 37                                                      # not a multiple of the waves per workgroup
+    lo, up = cf.kincar_random_bounds(ncars, nb)
+    fixed, conv = dict(itlim=50, fixed_iters=1), dict(hessian=1)
+    assert p.solve_kernel(nb, api.default_opts(**fixed)) == "sqp_wave_kernel" and p.solve_kernel(nb, api.default_opts(**conv)) == "sqp_wave_kernel"
+    assert plan_for("K0").solve_kernel(nb, api.default_opts()) == "sqp_kernel"      # order 5, 2 intervals: outside the class
+    res = {}
+    for mode in ("wave", "wg"):
+        if mode == "wg":
+            os.environ["NTG_AMD_NOWAVE"] = "1"
+        try:
+            res[mode] = (solve(name, lo, up, np.ones((nb, spec.nC)), **fixed), solve(name, lo, up, np.ones((nb, spec.nC)), **conv))
+        finally:
+            os.environ.pop("NTG_AMD_NOWAVE", None)
+    (xf_w, of_w), (xc_w, oc_w) = res["wave"]
+    (xf_g, of_g), (xc_g, oc_g) = res["wg"]
+    assert np.array_equal(of_w["nfev"], of_g["nfev"]) and (of_w["iters"] == 50).all()
+    assert rel(of_w["objective"], of_g["objective"]) <= 2e-7
+    assert (oc_w["inform"] == 0).all() and (oc_g["inform"] == 0).all()
+    assert rel(oc_w["objective"], oc_g["objective"]) <= 1e-9
+    assert np.abs(xc_w - xc_g).max() <= 1e-6 * np.abs(xc_g).max()
+    # multipliers of the equality rows (final pass at x) agree as well
+    np.testing.assert_allclose(oc_w["clambda"][:, spec.nC:], oc_g["clambda"][:, spec.nC:], rtol=1e-6, atol=1e-7 * np.abs(oc_g["clambda"]).max())
