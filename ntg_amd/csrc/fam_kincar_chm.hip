@@ -18,10 +18,14 @@ hipError_t ntg_launch_eval_kincar_chm(const NtgDims &D, const NtgTables &T, cons
 		if (D.nout == 6 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 6, 2, 6, 4, 4, 20>(T, FI, a);
 	}
 	if (shared_grid && !a.c && !a.jb && !a.cj && !getenv("NTG_AMD_EVAL_V1")) {   // one lane per (knot interval, pair of outputs)
-		// (instances for 20 knot intervals: BASELINE's kincar configs; other grids take the breakpoint-lane kernel below)
+		// (instances for 20 knot intervals: BASELINE's kincar configs; 16 below; other grids take the breakpoint-lane kernel)
 		if (D.nout == 2 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 2, 2, 6, 4, 4, 20>(T, FI, a);
 		if (D.nout == 4 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 4, 2, 6, 4, 4, 20>(T, FI, a);
 		if (D.nout == 6 && D.ig_n == 20 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 6, 2, 6, 4, 4, 20>(T, FI, a);
+		// ... and for 16 (the second interval count with tuned solve instances: `generic_instances` of bench.py)
+		if (D.nout == 2 && D.ig_n == 16 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 2, 2, 6, 4, 4, 16>(T, FI, a);
+		if (D.nout == 4 && D.ig_n == 16 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 4, 2, 6, 4, 4, 16>(T, FI, a);
+		if (D.nout == 6 && D.ig_n == 16 && eval_interval_match(D, 4, 3, 6, 2, &FI)) return launch_eval_interval<NTG_FAM_KINCAR, 6, 2, 6, 4, 4, 16>(T, FI, a);
 	}
 	FastEvalDims F;
 	if (shared_grid && a.nt == 128 && !a.c && !a.jb && !a.cj && eval_fast_match(D, 4, 3, 128, &F)) {

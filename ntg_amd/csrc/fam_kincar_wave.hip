@@ -13,10 +13,10 @@ using namespace ntgw;
 
 namespace {
 
-template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false>
+template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false, int NINT = 20>
 hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
 {
-	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, 20, NWV, MINW, NREG, NLDS, HESS, XLDS>;
+	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, NINT, NWV, MINW, NREG, NLDS, HESS, XLDS>;
 	WaveArgs A;
 	A.batch = a.batch; A.cap = w.cap; A.lower = a.lo; A.upper = a.up; A.xio = a.x; A.objective = a.obj; A.inform = a.inf; A.iters = a.it;
 	A.nfev = a.nf; A.clambda = a.cl; A.hist = a.hist; A.counter = a.counter; A.hbm_slots = w.hbm_slots;
@@ -30,7 +30,7 @@ hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &s
 // LDS bytes of a workgroup (xlds: with the preconditioner blocks and the sparse linear operator staged)
 size_t wave_lds(const NtgDims &D, const NtgTables &T, int hessian, int nwv, int cap, int nlds, int epl, bool xlds = false)
 {
-	size_t tab = (size_t)wave_tab_doubles<1, 6, 20>() * 8 + (size_t)D.q_nt * 6 * 8 + (size_t)D.q_nt * 8 * 4;
+	size_t tab = (size_t)(D.ig_n == 16 ? wave_tab_doubles<1, 6, 16>() : wave_tab_doubles<1, 6, 20>()) * 8 + (size_t)D.q_nt * 6 * 8 + (size_t)D.q_nt * 8 * 4;
 	if (xlds) {
 		const int lnz = std::max(D.lin_nnz, 1), snz = std::max(D.sinv_nnz, 1);
 		tab += (size_t)(hessian == 1 ? T.n0b_nblk * 64 * 64 : 0) * 8 + (size_t)(2 * lnz + snz) * 8 + (size_t)((2 * (D.mE + 1) + (D.nC + 1) + 2 * lnz + snz + 3) & ~3) * 4;
@@ -54,7 +54,8 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 	if (getenv("NTG_AMD_NOWAVE")) return false;
 	if (D.family != NTG_FAM_KINCAR || !(D.nout == 2 || D.nout == 4 || D.nout == 6)) return false;
 	const int opl = D.nout == 2 ? 1 : 2;
-	if (!wave_match(D, T, sp, 4, 3, 6, opl, 20)) return false;
+	// 20 knot intervals (BASELINE's kincar configs), and 16 for the four-output shape (bench.py `generic_instances`)
+	if (!wave_match(D, T, sp, 4, 3, 6, opl, 20) && !(D.nout == 4 && wave_match(D, T, sp, 4, 3, 6, opl, 16))) return false;
 	const int epl = opl * 3;
 	w->cap = std::min(sp.memcap, sp.itlim) + 4;
 	w->fat = (sp.hessian != 1 && !getenv("NTG_AMD_WAVE_LEAN")) ? 1 : 0;
@@ -89,6 +90,14 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 {
 	if (!a.counter) return hipErrorInvalidValue;
 	constexpr int R3 = (256 - NTGW_ABASE) / 6, R6 = (256 - NTGW_ABASE) / 12;
+	if (D.ig_n == 16) {   // four outputs on 16 knot intervals
+		if (w.fat && w.nlds == FAT_NLDS) return launch_one<4, 2, 4, 1, R6, FAT_NLDS, false, false, 16>(D, T, sp, a, w);
+		if (w.fat) return launch_one<4, 2, 4, 1, R6, FAT_NLDS2, false, false, 16>(D, T, sp, a, w);
+		const bool xl16 = sp.hessian != 1 || T.n0b_sp <= 64;
+		if (w.nwv == 8 && xl16) return launch_one<4, 2, 8, LEAN_MINW, 0, LEAN_NLDS, true, true, 16>(D, T, sp, a, w);
+		if (xl16) return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, true, 16>(D, T, sp, a, w);
+		return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, false, 16>(D, T, sp, a, w);
+	}
 	if (w.fat && w.nlds == FAT_NLDS) {
 		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, FAT_NLDS, false>(D, T, sp, a, w);
 		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, FAT_NLDS, false>(D, T, sp, a, w);

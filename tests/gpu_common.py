@@ -8,7 +8,8 @@ from ntg_amd import api, configs as cf
 SPECS = {"A": cf.config_A, "K0": cf.config_K0, "B": cf.config_B, "M": cf.config_M, "T": cf.config_T,
          "D8": lambda: cf.config_D(ninterv=8), "E8": lambda: cf.config_E(ninterv=8, narms=2)}
 # shapes without a reference-code fixture (compared with the oracle only): two cars = 4 flat outputs
-EXTRA = {"M4": lambda: cf._kincar_spec(2, 6, 3, 20, 101, 5.0, "M4:kincar-4out-k6-l20")}
+EXTRA = {"M4": lambda: cf._kincar_spec(2, 6, 3, 20, 101, 5.0, "M4:kincar-4out-k6-l20"),
+         "M4b": lambda: cf._kincar_spec(2, 6, 3, 16, 81, 5.0, "M4b:kincar-4out-k6-l16")}   # the wave kernels' second interval count
 _plans = {}
 
 

@@ -46,7 +46,7 @@ def test_vanderpol_known_answer(hessian):
     assert out["iters"][0] == o["iters"] and out["nfev"][0] == o["nfev"]
 
 
-@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3), ("M4", 2)])
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3), ("M4", 2), ("M4b", 2)])
 @pytest.mark.parametrize("hessian", [0, 1])
 def test_optimum_matches_kkt_and_oracle(name, ncars, hessian):
     spec = plan_for(name).spec
@@ -71,7 +71,7 @@ def test_optimum_matches_kkt_and_oracle(name, ncars, hessian):
         assert np.abs(out["iters"] - ref["iters"]).max() <= 1
 
 
-@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3), ("M4", 2)])
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M", 3), ("M4", 2), ("M4b", 2)])
 def test_fixed_50_majors_parity_with_oracle(name, ncars):
     """The benchmark mode: exactly 50 majors, identity cold start."""
     spec = plan_for(name).spec
@@ -191,7 +191,7 @@ def test_c_abi_error_returns():
     assert torch.equal(x, torch.ones_like(x))                      # nothing was touched
 
 
-@pytest.mark.parametrize("name,ncars", [("B", 1), ("M4", 2), ("M", 3)])
+@pytest.mark.parametrize("name,ncars", [("B", 1), ("M4", 2), ("M4b", 2), ("M", 3)])
 def test_wave_kernel_is_what_runs_and_agrees_with_the_workgroup_kernel(name, ncars):
     """The kincar class is solved by sqp_wave_kernel (one wavefront per problem, solve_wave.hpp); NTG_AMD_NOWAVE=1 forces sqp_kernel.
     Same algorithm, different summation orders: identical evaluation counts in the fixed-work mode, objectives to 1e-7 (both are
