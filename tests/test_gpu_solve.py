@@ -220,3 +220,43 @@ def test_wave_kernel_is_what_runs_and_agrees_with_the_workgroup_kernel(name, nca
     assert np.abs(xc_w - xc_g).max() <= 1e-6 * np.abs(xc_g).max()
     # multipliers of the equality rows (final pass at x) agree as well
     np.testing.assert_allclose(oc_w["clambda"][:, spec.nC:], oc_g["clambda"][:, spec.nC:], rtol=1e-6, atol=1e-7 * np.abs(oc_g["clambda"]).max())
+
+
+@pytest.mark.parametrize("itlim,memory", [(70, 8), (40, 3)])
+def test_wave_kernel_restarts_with_a_short_memory(itlim, memory):
+    """Several restarts of the quasi-Newton memory inside one solve (each stores its first pair as two chain slots):
+    same iterates as the oracle's dense W restarted at the same counts."""
+    spec = plan_for("M").spec
+    nb = 6
+    lo, up = cf.kincar_random_bounds(3, nb)
+    kw = dict(itlim=itlim, fixed_iters=1, qn_memory=memory)
+    assert plan_for("M").solve_kernel(nb, api.default_opts(**kw)) == "sqp_wave_kernel"
+    x, out = solve("M", lo, up, np.ones((nb, spec.nC)), **kw)
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(**kw), nthreads=8)
+    assert (out["iters"] == itlim).all()
+    assert np.array_equal(out["nfev"], ref["nfev"])
+    assert rel(out["objective"], ref["objective"]) <= 1e-7
+
+
+def test_wave_kernel_cold_start_to_convergence_and_outputs():
+    """NPSOL-equivalent cold start run to convergence on the wave kernel (the long-memory instance): optimum, multipliers of the
+    equality rows, feasibility against the oracle; a problem whose bounds are not equalities is refused per problem (inform 9)."""
+    spec = plan_for("B").spec
+    nb = 5
+    lo, up = cf.kincar_random_bounds(1, nb)
+    up2 = up.copy(); up2[3, 2] += 0.25                                   # problem 3: a range where the plan has an equality row
+    x, out = solve("B", lo, up2, np.ones((nb, spec.nC)), hessian=0)
+    ref = orc.solve_batch(spec, lo, up, np.ones((nb, spec.nC)), orc.default_opts(hessian=0), nthreads=8)
+    good = np.array([0, 1, 2, 4])
+    assert (out["inform"][good] == 0).all() and out["inform"][3] == 9
+    assert np.array_equal(x[3], np.ones(spec.nC)) and (out["clambda"][3] == 0).all()
+    assert rel(out["objective"][good], ref["objective"][good]) <= 1e-9
+    assert np.abs(x[good] - ref["x"][good]).max() <= 1e-6 * np.abs(ref["x"]).max()
+    A = plan_for("B").tables()["A"]
+    assert np.abs(x[good] @ A.T - lo[good]).max() <= 1e-8
+    for i in good[:2]:
+        o = orc.solve_one(spec, lo[i], up[i], np.ones(spec.nC), orc.default_opts(hessian=0))
+        lam = out["clambda"][i]
+        assert np.all(lam[:spec.nC] == 0)
+        # (first-order quantities of two solutions that agree to 1e-6 in x: the cost's curvature amplifies the difference)
+        np.testing.assert_allclose(lam[spec.nC:], o["clambda"][spec.nC:], rtol=1e-3, atol=1e-4 * np.abs(o["clambda"]).max())
