@@ -21,6 +21,10 @@
 #pragma once
 #include "solve_impl.hpp"
 
+#ifndef NTGW_HG
+#define NTGW_HG 2
+#endif
+
 namespace ntgw {
 
 template <int J, int N, class F>
@@ -46,7 +50,9 @@ __device__ __forceinline__ double from_next(double v)
 // The register allocator hands out accumulator registers from a0 upwards when the 256 architectural VGPRs run short (AV-class values:
 // load results, copies).  It cannot be told to keep out, so the chain starts at a[NTGW_ABASE]: a0 .. a[NTGW_ABASE - 1] are the compiler's,
 // and ntg_amd/isa_audit.py fails the build if compiler-generated code touches anything from a[NTGW_ABASE] up.
+#ifndef NTGW_ABASE
 #define NTGW_ABASE 16
+#endif
 // accumulator registers a[ABASE + 2 IDX], a[ABASE + 2 IDX + 1] as one double.  The kernel lists a0..a255 as clobbers once (which makes
 // the kernel descriptor allocate them all).
 template <int IDX>
@@ -417,7 +423,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	// On-chip slots: pass 1 (all dot products, 16 per butterfly), the kappa of every slot, pass 2 (axpys).  Slots in HBM are read ONCE:
 	// rounds of HG vectors through two register buffers, link by link (t += d_i (e delta_{i+1} + f delta_i) + d_{i+1} e delta_i), the
 	// first round requested before the on-chip passes start -- its latency hides behind them.
-	constexpr int H0 = NREG + NLDS, HG = 2;
+	constexpr int H0 = NREG + NLDS, HG = MINW == 1 ? NTGW_HG : 2;   // chain slots per round of the HBM tier (two register buffers of HG vectors)
 	auto sweep = [&](int ns, const double (&v)[EPL], double (&tv)[EPL]) {
 		if (ns < 2) return;   // a chain of one vector carries no update yet
 		const int nso = min(ns, H0);   // on-chip slots; the links nso-1 .. ns-2 belong to the HBM rounds
