@@ -348,6 +348,17 @@ hipError_t ntg_launch_mpc_shift(const NtgDims &D, const NtgTables &T, int batch,
 // ------------------------------------------------------------------------------------------
 static inline int align16(int x) { return (x + 15) & ~15; }
 
+// derivative orders named by the trajectory-constraint active variables: the channels the row emission of the banded Jacobian lists
+// (eval_constraints / emit_decode; an upper bound is all the layout needs)
+static int ntg_emit_channels(const NtgDims &D)
+{
+	unsigned um = 0;
+	for (int o = 0; o < D.nout; o++)
+		for (int r = 0; r < D.d[o] && r < NTG_MAX_ORDER; r++)
+			if ((D.tcon_mask >> (D.iz[o] + r)) & 1ull) um |= 1u << r;
+	return std::max(1, __builtin_popcount(um));
+}
+
 SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x, int hrc_pairs)
 {
 	SmemLayout L;
@@ -378,13 +389,15 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x,
 	L.red = p; p = align16(p + (32 * (nthreads / 64) + 2) * 8);   // two halves of 16 values x waves (block_sum) + the Newton mode's flag words
 	L.dfi = p; p = align16(p + (D.nz + 1) * 8);
 	L.dff = p; p = align16(p + (D.nz + 1) * 8);
-	L.vecs = p; p = align16(p + (nvec * npad + 2 * D.nclin + 2) * 8);
-	L.lam = p; p = align16(p + (D.nclin + 1) * 8);
+	// evaluation layouts (nvec == 0) carry no solver state: no vectors, multipliers or line-search records (config D's evaluation sits
+	// 640 bytes under the two-workgroups-per-CU line)
+	L.vecs = p; if (nvec > 0) p = align16(p + (nvec * npad + 2 * D.nclin + 2) * 8);
+	L.lam = p; if (nvec > 0) p = align16(p + (D.nclin + 1) * 8);
 	L.rho = L.c2 = p; L.hrc_n = hrc_pairs; p = align16(p + 2 * hrc_pairs * 8);   // (rho_i, c2_i) of a short quasi-Newton memory; longer ones keep them with the pair in HBM
 	L.oinfo = p; p = align16(p + D.nout * 10 * 4);
 	L.tavrow = p; p = align16(p + D.nz * 4);
 	L.tcomp = p; p = align16(p + D.nz * 4);
-	L.ls = p; p = align16(p + 2 * (int)sizeof(LineSearch));   // double buffered (see sqp_kernel)
+	L.ls = p; if (nvec > 0) p = align16(p + 2 * (int)sizeof(LineSearch));   // double buffered (see sqp_kernel)
 	L.tI = p; p = align16(p + (D.nI + 1) * 8);   // multiplier estimates of the linear inequality rows
 	L.q_idx = L.q_col = L.q_val = p;
 	L.with_lin = nvec > 0;
@@ -405,6 +418,10 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x,
 		L.sinv_col = p; p = align16(p + D.sinv_nnz * 4);
 		L.sinv_val = p; p = align16(p + D.sinv_nnz * 8);
 	}
+	// row emission of the banded Jacobian (eval_constraints): [64 lanes] (pair index | row slot) + [NTG_MAX_ORDER][64 lanes] (scratch offset,
+	// table offset) + the number of listed channels -- decoded once per workgroup instead of once per problem
+	L.emit = -1;
+	if (nvec == 0 && D.nnltc > 0) { L.emit = p; p = align16(p + 64 * 4 + ntg_emit_channels(D) * 64 * 8 + 16); }
 	L.total = p;
 	return L;
 }

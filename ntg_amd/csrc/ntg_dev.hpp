@@ -117,6 +117,7 @@ struct SmemLayout {
 	int dfz_rows;   // rows of the weighted-gradient area: every active variable (solve) or the cost's / one constraint chunk's (evaluation)
 	int hrc_n;   // pairs whose scalars (rho, c2) live in LDS at L.rho (0: they travel with the pair in HBM)
 	int nwt_y;   // structured Newton mode: byte offset (inside the dfz area, which is idle between evaluations) of the solve vectors; panels follow
+	int emit;    // evaluation layouts with trajectory constraint rows: byte offset of the row emission's per-lane decode (eval_constraints), -1: none
 };
 
 struct SolveParams {

@@ -892,7 +892,8 @@ extern "C" int ntg_batch_eval(const ntg_plan *p, int batch, const double *d_x, i
 	int ncu = 256;
 	{ hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, p->device) == hipSuccess && prop.multiProcessorCount > 0) ncu = prop.multiProcessorCount; }
 	const int wg_per_cu = std::max(1, std::min(std::min(8, 32 / (nt / 64)), (160 * 1024) / std::max(L.total, 1)));
-	const int grid = std::min(batch, ncu * wg_per_cu);
+	int grid = std::min(batch, ncu * wg_per_cu);
+	if (const char *eg = getenv("NTG_AMD_EVAL_GRID")) grid = std::max(1, std::min(grid, atoi(eg)));   // experiments only
 	EvalArgs ea{nt, grid, ncu, batch, mode, d_x, d_f, d_g, d_c, d_jband, d_cjac, st};
 	HIPCHK(ntg_launch_eval(D, p->T, L, ea));
 	return 0;

@@ -17,6 +17,22 @@
 #ifndef NTG_EVAL_WAVES
 #define NTG_EVAL_WAVES 2
 #endif
+// phase clock of eval_kernel (variant builds only, tests/tools_jac_clock.py): s_memtime ticks of workgroup 0's first lane per phase
+#ifdef NTG_EVAL_CLOCK
+// accumulators in LDS: a global read-modify-write here would wait for vmcnt(0), i.e. for the wave's outstanding stores -- the clock would
+// charge the drain of the emission's stores to the emission
+#define EVCLK(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); ntg_evclk_s[slot] += t_ - ntg_evclk_s[7]; ntg_evclk_s[7] = t_; } } while (0)
+#define EVCLK0() do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 7; i_++) ntg_evclk_s[i_] = 0; ntg_evclk_s[7] = __builtin_readcyclecounter(); } } while (0)
+#define EVCLK_DECL __shared__ unsigned long long ntg_evclk_s[8];
+#define EVCLK_ARG , unsigned long long *ntg_evclk_s
+#define EVCLK_PASS , ntg_evclk_s
+#else
+#define EVCLK(slot) do { } while (0)
+#define EVCLK0() do { } while (0)
+#define EVCLK_DECL
+#define EVCLK_ARG
+#define EVCLK_PASS
+#endif
 #ifndef NTG_HIST_G
 #define NTG_HIST_G 6
 #endif
@@ -755,11 +771,49 @@ __device__ __forceinline__ double eval_cost(const NtgDims &D, const Smem &S, con
 	return F;
 }
 
+// Per-lane decode of the banded Jacobian's row emission (eval_constraints, the pair form), once per workgroup: lane ln of a wave owns the
+// pair of entries (2 e2, 2 e2 + 1) of row slot rsub; tab[i][ln] = (scratch offset or -1, table offset) of the i-th derivative channel that
+// contributes to ANY entry.  Returns false (nothing written) when the pair form does not apply: generic instance, odd order, a row wider
+// than a wave's 64 pairs.
+template <int NOUT, int K, int DM>
+__device__ __forceinline__ bool emit_decode(const NtgDims &D, const Smem &S, int *emit_tab)
+{
+	if (!(NOUT > 0 && K > 0 && K % 2 == 0 && DM <= NTG_MAX_ORDER) || !emit_tab) return false;
+	const int s2 = D.sumk >> 1, P = D.P;
+	if (s2 > 64 || (D.sumk & 1)) return false;
+	if (threadIdx.x >= 64) return true;
+	const int ln = threadIdx.x, rpi = 64 / s2, rsub = ln / s2, e2 = ln - rsub * s2;
+	const bool live = rsub < rpi;
+	const int e = 2 * e2, o = min(e / (K > 0 ? K : 1), NOUT > 0 ? NOUT - 1 : 0), q = e - o * K, cc = D.cls[o], iz = DM * o;
+	unsigned um = 0;
+#pragma unroll
+	for (int r = 0; r < DM; r++) {
+		const bool on = live && S.tcomp[iz + r] >= 0 && S.chrow[cc * NTG_MAX_ORDER + r] >= 0;
+		if (__ballot(on) != 0ull) um |= 1u << r;
+	}
+	um = __builtin_amdgcn_readfirstlane(um);
+	const int na = __popc(um);
+	int2 *tab = reinterpret_cast<int2 *>(emit_tab + 68);
+#pragma unroll
+	for (int i = 0; i < DM; i++) {
+		if (i >= na) break;   // the layout holds the listed channels only
+		const int r = um ? __ffs(um) - 1 : 0;
+		const bool have = um != 0;
+		um &= um - 1;
+		const int comp = S.tcomp[iz + r], chr = S.chrow[cc * NTG_MAX_ORDER + r];
+		const bool on = live && have && comp >= 0 && chr >= 0;
+		tab[i * 64 + ln] = make_int2(on ? comp * P : -1, on ? chr + q * P : 0);
+	}
+	emit_tab[ln] = live ? (e2 | (rsub << 16)) : -1;
+	if (ln == 0) emit_tab[64] = na;
+	return true;
+}
+
 // NPfuncon (ntg.c:337-371, constraints.c:36-195): residuals and banded Jacobian rows straight
 // to HBM.  Row order [initial; trajectory constraint-major x breakpoint; final].
 template <int FAM, int NOUT, int K, int NT>
 __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S, const double *sx, int mode,
-                                 double *c_out, double *jband, double *cjac, double *scratch, int scratch_cap)
+                                 double *c_out, double *jband, double *cjac, double *scratch, int scratch_cap, const int *emit_tab EVCLK_ARG)
 {
 	using Fam = Family<FAM>;
 	constexpr int DM = Fam::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
@@ -833,6 +887,7 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 			}
 			if (coalesced) {
 				lds_sync();
+				EVCLK(1);
 				// a wave takes whole rows (stride NW); its lanes are the entries of the row, 64 at a time: a store
 				// instruction writes 64 consecutive words, and what an entry needs to know about itself -- output, block
 				// column, which derivative channels contribute -- is decoded once per lane, outside the loop over rows
@@ -845,7 +900,7 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 					const int rpi = 64 / width, rsub = ln / width, e = e0 + ln % width;
 					if (rsub >= rpi) return;
 					int o = 0;
-					if (NOUT > 0 && K > 0) o = e / K;                 // one order for every output
+					if (NOUT > 0 && K > 0) o = e / (K > 0 ? K : 1);    // one order for every output
 					else while (o + 1 < nout && D.koff[o + 1] <= e) o++;
 					const int q = e - (NOUT > 0 && K > 0 ? o * K : D.koff[o]), cc = D.cls[o], d = NOUT > 0 ? DM : D.d[o];
 					const int iz = NOUT > 0 ? DM * o : D.iz[o];
@@ -868,8 +923,100 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 						while (bp >= P) { bp -= P; jc++; }
 					}
 				};
+				// The tuned instances (one even order for every output, 16-byte aligned rows) emit PAIRS of adjacent entries: a lane
+				// owns block columns (q, q + 1) of one output -- the functor's derivative is shared by the pair, the store is 16 bytes
+				// per lane (1 KB per wave instruction).  The phase is bound by instruction issue (one or two waves per SIMD: ~8 cycles
+				// per instruction, measured 760 cycles per 128 stored words before), so what counts is instructions per stored word:
+				//  * the derivative channels that contribute to ANY entry of the wave (a wave-uniform set: the trajectory-constraint
+				//    active variables name few derivatives -- 2 of config D's 6 channels, 1 of config E's 4) are compacted into a
+				//    list once; the row loop is instantiated for the list's length NA and touches nothing else;
+				//  * every load of a trip is unconditional (a lane whose entry lacks a listed channel multiplies by zero) and all of
+				//    them -- UR rows x NA channels x 3 -- are in flight before the first is used: the empty asm makes every operand
+				//    live at one point; under this kernel's register pressure the scheduler otherwise pairs each read with its wait;
+				//  * the breakpoint index wraps branch-free.
+				//  * what a lane needs to know about its pair is the same for every problem: it is decoded once per workgroup into LDS
+				//    (emit_decode, called by eval_kernel before the problem loop) and costs 1 + NA reads here; decoding it per problem
+				//    (two integer divisions, 4 DM table lookups, DM ballots) was HALF of the phase: 6.5 k of 13.5 k cycles, config D.
+				auto emit_pairs = [&]() {
+					const int s2 = sumk >> 1, rpi = 64 / s2;
+					const int pk = emit_tab[ln];
+					if (pk < 0) return;
+					const int e2 = pk & 0xffff, rsub = pk >> 16;
+					const int2 *tab = reinterpret_cast<const int2 *>(emit_tab + 68);
+					const int na = __builtin_amdgcn_readfirstlane(emit_tab[64]);
+					const int step = NW * rpi, cs = ncomp * P;
+					double2 *dst2 = reinterpret_cast<double2 *>(dst);
+					auto rows = [&](auto na_) {
+						constexpr int NA = decltype(na_)::value, UR = NA == 1 ? 4 : (NA == 2 ? 4 : (NA <= 4 ? 2 : 1));
+						int cofA[NA > 0 ? NA : 1], rofA[NA > 0 ? NA : 1]; double useA[NA > 0 ? NA : 1];
+#pragma unroll
+						for (int i = 0; i < NA; i++) {
+							const int2 t = tab[i * 64 + ln];
+							cofA[i] = max(t.x, 0); rofA[i] = t.y; useA[i] = t.x >= 0 ? 1.0 : 0.0;
+						}
+						int row = wv * rpi + rsub, jc = 0, bp = row;
+						while (bp >= P) { bp -= P; jc++; }
+						EVCLK(4);
+						if (step <= P) {
+							for (; row + (UR - 1) * step < nrows; row += UR * step) {
+								int jcu[UR], bpu[UR];
+								jcu[0] = jc; bpu[0] = bp;
+#pragma unroll
+								for (int u = 1; u < UR; u++) {
+									const int bb = bpu[u - 1] + step; const bool w = bb >= P;
+									bpu[u] = bb - (w ? P : 0); jcu[u] = jcu[u - 1] + (w ? 1 : 0);
+								}
+								double sa[UR][NA > 0 ? NA : 1], r0[UR][NA > 0 ? NA : 1], r1[UR][NA > 0 ? NA : 1];
+#pragma unroll
+								for (int u = 0; u < UR; u++)
+#pragma unroll
+									for (int i = 0; i < NA; i++) {
+										sa[u][i] = scratch[jcu[u] * cs + cofA[i] + bpu[u]];
+										r0[u][i] = S.rowv[rofA[i] + bpu[u]];
+										r1[u][i] = S.rowv[rofA[i] + P + bpu[u]];
+									}
+#pragma unroll
+								for (int u = 0; u < UR; u++)
+#pragma unroll
+									for (int i = 0; i < NA; i++) asm volatile("" : "+v"(sa[u][i]), "+v"(r0[u][i]), "+v"(r1[u][i]));
+#pragma unroll
+								for (int u = 0; u < UR; u++) {
+									double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+									for (int i = 0; i < NA; i++) { const double t = sa[u][i] * useA[i]; a0 += t * r0[u][i]; a1 += t * r1[u][i]; }
+									dst2[(size_t)(row + u * step) * s2 + e2] = make_double2(a0, a1);
+								}
+								{ const int bb = bpu[UR - 1] + step; const bool w = bb >= P; bp = bb - (w ? P : 0); jc = jcu[UR - 1] + (w ? 1 : 0); }
+							}
+						}
+						for (; row < nrows; row += step) {
+							double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+							for (int i = 0; i < NA; i++) {
+								const double t = scratch[jc * cs + cofA[i] + bp] * useA[i];
+								a0 += t * S.rowv[rofA[i] + bp]; a1 += t * S.rowv[rofA[i] + P + bp];
+							}
+							dst2[(size_t)row * s2 + e2] = make_double2(a0, a1);
+							bp += step;
+							while (bp >= P) { bp -= P; jc++; }
+						}
+					};
+					if (na == 0) rows(std::integral_constant<int, 0>{});
+					else if (na == 1) rows(std::integral_constant<int, 1>{});
+					else if (na == 2) rows(std::integral_constant<int, 2>{});
+					else if (na == 3) rows(std::integral_constant<int, 3>{});
+					else if (na == 4) rows(std::integral_constant<int, 4>{});
+					else if (na == 5) rows(std::integral_constant<int, (RMAX >= 5 ? 5 : 0)>{});
+					else if (na == 6) rows(std::integral_constant<int, (RMAX >= 6 ? 6 : 0)>{});
+					else if (na == 7) rows(std::integral_constant<int, (RMAX >= 7 ? 7 : 0)>{});
+					else rows(std::integral_constant<int, (RMAX >= 8 ? 8 : 0)>{});
+					EVCLK(5);
+				};
+				if (emit_tab && ((uintptr_t)dst & 15) == 0) emit_pairs();
+				else
 				for (int e0 = 0; e0 < sumk; e0 += 64) emit_pass(e0, min(64, sumk - e0));
 				lds_sync();
+				EVCLK(2);
 			}
 		}
 	}
@@ -893,9 +1040,16 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
             double *__restrict__ jband, double *__restrict__ cjac)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	EVCLK_DECL
 	Smem S(smem_raw, L, D, T);
 	const bool pp = T.pp_rowv != 0;   // per-problem grids: the value tables are staged again for every problem
 	if (!pp) stage_tables<NT>(D, T, S, smem_raw, L);
+	const int *emit_tab = nullptr;   // the row emission's decode depends on the plan only (not on the grid's values): once per workgroup
+	if (L.emit >= 0 && jband && mode != 0) {
+		if (pp) stage_tables<NT>(D, T, S, smem_raw, L, blockIdx.x < batch ? blockIdx.x : 0);
+		lds_sync();
+		if (emit_decode<NOUT, K, Family<FAM>::DM>(D, S, (int *)(smem_raw + L.emit))) emit_tab = (const int *)(smem_raw + L.emit);
+	}
 	double *sg = S.x;   // the gradient is assembled (owner lanes, after the last read of x) into the x buffer
 	lds_sync();
 	CoefMap<EPT> cm;
@@ -909,6 +1063,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 #pragma unroll
 		for (int e = 0; e < XE; e++) { const int i = threadIdx.x + e * NT; xn[e] = i < D.nC ? x[(size_t)blockIdx.x * D.nC + i] : 0.0; }
 	}
+	EVCLK0();
 	for (int b = blockIdx.x; b < batch; b += gridDim.x) {
 		lds_sync();
 		if (pp) { stage_tables<NT>(D, T, S, smem_raw, L, b); lds_sync(); }
@@ -924,12 +1079,13 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 			for (int i = threadIdx.x; i < D.nC; i += NT) S.x[i] = x[(size_t)b * D.nC + i];
 		}
 		const int P1 = D.P + 1;
+		EVCLK(0);
 		if (D.ncnln && (c || jband || cjac)) {   // constraints first: they still need x, the cost pass overwrites it with g
 			lds_sync();
 			eval_constraints<FAM, NOUT, K, NT>(D, S, S.x, mode, c ? c + (size_t)b * D.ncnln : nullptr,
 			                                jband ? jband + (size_t)b * D.ncnln * D.sumk : nullptr,
 			                                cjac ? cjac + (size_t)b * D.ncnln * D.nC : nullptr,
-			                                S.dfz, L.dfz_rows * (P1) + ntg_dfz_tail(D));
+			                                S.dfz, L.dfz_rows * (P1) + ntg_dfz_tail(D), emit_tab EVCLK_PASS);
 		}
 		double gn2;
 		const double F = eval_cost<FAM, NOUT, K, NT, EPT, (NOUT >= 3), CHM>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr},
@@ -937,7 +1093,13 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
 		if (g && mode != 0)
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
+		EVCLK(3);
 	}
+#ifdef NTG_EVAL_CLOCK
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		printf("evclk: stage-x %llu functor %llu emission %llu cost+g %llu | emission: prologue %llu rows %llu\n", ntg_evclk_s[0], ntg_evclk_s[1], ntg_evclk_s[2], ntg_evclk_s[3], ntg_evclk_s[4], ntg_evclk_s[5]);
+	}
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
