@@ -42,6 +42,7 @@ struct DenseTraj {
 
 template <> struct Family<NTG_FAM_KINCAR> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = true;   // ucf(nout, ...) is a sum of identical terms over the outputs: a subset of the outputs gives its share
 	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
@@ -66,6 +67,7 @@ template <> struct Family<NTG_FAM_KINCAR> {
 
 template <> struct Family<NTG_FAM_VANDERPOL> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
@@ -91,6 +93,7 @@ template <> struct Family<NTG_FAM_VANDERPOL> {
 // dc is [ncon][nz] row-major (== the reference's dc[constraint][variable])
 template <> struct Family<NTG_FAM_TESTFAM> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 0, CG = 1;   // no structured Newton mode
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *, const double *, double, bool, double *) {}
@@ -156,6 +159,7 @@ template <> struct Family<NTG_FAM_TESTFAM> {
 
 template <> struct Family<NTG_FAM_OBSTACLE> {
 	static constexpr int DM = 3, TAPE = 1;
+	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 2, CG = 2;   // one group (x, y); constraint flag entries x, y
 	// B (CG x CG) = mu a a' [row active] + t d2c/dz2 [curv]: the second-order model of the row's augmented-Lagrangian term
@@ -183,6 +187,8 @@ template <> struct Family<NTG_FAM_OBSTACLE> {
 
 template <> struct Family<NTG_FAM_QUADROTOR> {
 	static constexpr int DM = 5, TAPE = 1;
+	// flag entries (5 o + r) a trajectory constraint row can depend on: first and second derivatives of x, y, z
+	static constexpr u64 TCON_VARS = (1ull << 1) | (1ull << 2) | (1ull << 6) | (1ull << 7) | (1ull << 11) | (1ull << 12);
 	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int COUPLE = 4, CG = 6;   // one group; constraint flag entries in flag order: x', x'', y', y'', z', z''
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *z, const double *t, double mu, bool curv, double *B)
@@ -235,10 +241,12 @@ template <> struct Family<NTG_FAM_QUADROTOR> {
 	}
 };
 
+constexpr u64 ntg_manip_vars(int narms) { u64 m = 0; for (int j = 0; j < narms && 9 * j + 6 < 64; j++) m |= (1ull << (9 * j)) | (1ull << (9 * j + 3)) | (1ull << (9 * j + 6)); return m; }
 template <> struct Family<NTG_FAM_MANIP> {
 	static constexpr int DM = 3;
 	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int MAXARMS = NTG_MAX_OUT / 3, TAPE = 3 * (NTG_MAX_OUT / 3);
+	static constexpr u64 TCON_VARS = ntg_manip_vars(NTG_MAX_OUT / 3);   // the three joint angles of every arm (flag entries 9 j, 9 j + 3, 9 j + 6)
 	static constexpr int COUPLE = 3, CG = 3;   // one group per arm; constraint flag entries qa, qb, qc
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int g, const double *z, const double *t, double mu, bool curv, double *B)
 	{

@@ -21,15 +21,17 @@
 #ifdef NTG_EVAL_CLOCK
 // accumulators in LDS: a global read-modify-write here would wait for vmcnt(0), i.e. for the wave's outstanding stores -- the clock would
 // charge the drain of the emission's stores to the emission
-#define EVCLK(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); ntg_evclk_s[slot] += t_ - ntg_evclk_s[7]; ntg_evclk_s[7] = t_; } } while (0)
-#define EVCLK0() do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 7; i_++) ntg_evclk_s[i_] = 0; ntg_evclk_s[7] = __builtin_readcyclecounter(); } } while (0)
-#define EVCLK_DECL __shared__ unsigned long long ntg_evclk_s[8];
+#define EVCLK(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); ntg_evclk_s[slot] += t_ - ntg_evclk_s[15]; ntg_evclk_s[15] = t_; } } while (0)
+#define EVCLK0() do { if (blockIdx.x == 0 && threadIdx.x == 0) { for (int i_ = 0; i_ < 15; i_++) ntg_evclk_s[i_] = 0; ntg_evclk_s[15] = __builtin_readcyclecounter(); } } while (0)
+#define EVCLK_DECL __shared__ unsigned long long ntg_evclk_s[16];
+#define EVCLK_TK (blockIdx.x == 0 ? ntg_evclk_s + 4 : nullptr)
 #define EVCLK_ARG , unsigned long long *ntg_evclk_s
 #define EVCLK_PASS , ntg_evclk_s
 #else
 #define EVCLK(slot) do { } while (0)
 #define EVCLK0() do { } while (0)
 #define EVCLK_DECL
+#define EVCLK_TK nullptr
 #define EVCLK_ARG
 #define EVCLK_PASS
 #endif
@@ -851,6 +853,8 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 	// this; constraints are processed in chunks that fit it.
 	const int ncomp = __popcll(D.tcon_mask);
 	const bool coalesced = Fam::NNLTC > 0 && D.nnltc && jband && mode != 0 && ncomp > 0 && ncomp * P <= scratch_cap;
+	constexpr u64 TV = Fam::TCON_VARS;
+	const bool sparse_vars = TV != ~0ull && (D.tcon_mask & ~TV) == 0ull;   // every flagged entry is one the family's rows can touch
 	if (Fam::NNLTC > 0 && D.nnltc) {
 		const int chunk = coalesced ? max(1, min(D.nnltc, scratch_cap / (ncomp * P))) : D.nnltc;
 		// with one breakpoint per lane (P <= NT) the flag, the values and the functor's tape are computed once and kept in
@@ -863,6 +867,7 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 				if (!keep || j0 == 0) {
 					compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
 					Fam::template nltc_val<NZ>(nout, i, z, c, tape);
+					EVCLK(6);
 				}
 				for (int j = j0; j < j0 + jn; j++) {
 					const int row = D.nnlic + j * P + i;              // constraints.c:139,153
@@ -877,7 +882,14 @@ __device__ __forceinline__ void eval_constraints(const NtgDims &D, const Smem &S
 					for (int v = 0; v < NZ; v++) dcr[v] = 0.0;
 					Fam::template nltc_vjp<NZ>(nout, nz, i, z, t, dcr, tape);
 					if (cjac || !coalesced) emit_row(row, i, dcr, coalesced ? nullptr : jband);
-					if (coalesced) {
+					if (coalesced && sparse_vars) {
+						// the family says which flag entries its rows can touch: only those are copied (12 of config E's 36, 6 of D's 20;
+						// the walk over all NZ entries with a wave-uniform branch each was 5 k cycles per constraint)
+#pragma unroll
+						for (int v = 0; v < NZ; v++)
+							if (((TV >> v) & 1ull) && ((D.tcon_mask >> v) & 1ull))   // compact index: scalar bit count, nothing kept in registers
+								scratch[((j - j0) * ncomp + __popcll(D.tcon_mask & ((1ull << v) - 1ull))) * P + i] = dcr[v];
+					} else if (coalesced) {
 						int comp = 0;
 #pragma unroll
 						for (int v = 0; v < NZ; v++)
@@ -1089,7 +1101,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 		}
 		double gn2;
 		const double F = eval_cost<FAM, NOUT, K, NT, EPT, (NOUT >= 3), CHM>(D, S, S.x, sg, &gn2, cm, ALState{0.0, nullptr, nullptr, nullptr, nullptr},
-		                                                                   nullptr, nullptr, nullptr, nullptr, CHM != 0);
+		                                                                   nullptr, nullptr, EVCLK_TK, nullptr, CHM != 0);
 		if (f && mode != 1 && threadIdx.x == 0) f[b] = F;
 		if (g && mode != 0)
 			for (int i = threadIdx.x; i < D.nC; i += NT) g[(size_t)b * D.nC + i] = sg[i];
@@ -1097,7 +1109,7 @@ eval_kernel(NtgDims D, NtgTables T, SmemLayout L, int batch, int mode, const dou
 	}
 #ifdef NTG_EVAL_CLOCK
 	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		printf("evclk: stage-x %llu functor %llu emission %llu cost+g %llu | emission: prologue %llu rows %llu\n", ntg_evclk_s[0], ntg_evclk_s[1], ntg_evclk_s[2], ntg_evclk_s[3], ntg_evclk_s[4], ntg_evclk_s[5]);
+		printf("evclk: stage-x %llu functor %llu emission %llu cost+g %llu | emission: prologue %llu rows %llu | functor: z+val %llu | cost: phase1 %llu phase2 %llu\n", ntg_evclk_s[0], ntg_evclk_s[1], ntg_evclk_s[2], ntg_evclk_s[3], ntg_evclk_s[4], ntg_evclk_s[5], ntg_evclk_s[6], ntg_evclk_s[10], ntg_evclk_s[11]);
 	}
 #endif
 }
