@@ -162,7 +162,7 @@ __device__ __forceinline__ void nwt_to_operand2(const nwt_d4 &Ta, const nwt_d4 &
 __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__ Kc, int ng, int hb, nwt_lds_dp panel, int strict)
 {
 	const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
-	nwt_lds_dp colbuf = panel, xbuf = panel + 32 * NWT_PIVOTS;   // NWT_PIVOTS columns of both tiles; one tile of 16 x NWT_PSTRIDE
+	constexpr int CS = 52;   // LDS stride (doubles) of a panel column of 48 rows: 104 words = 8 banks, the four columns of a group do not collide
 	int fail = 0;
 	// Addressing of the window relative to block column J: element (tile row a, register r) of a tile whose columns are block J + b sits
 	// at  Kc[16 J ld + off],  off = (16 a + 4 r + lk) (ld - 1) + 16 b + li + hb  -- a lane constant; whether it lies inside the band
@@ -181,99 +181,81 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 		}
 		return t;
 	};
+	// the lane's k index of the operand layout (lk) picks one of a group's four columns
+	const bool k1 = (lk & 1) != 0, k2 = (lk & 2) != 0;
+	auto pick = [&](const double (&v)[4]) { const double lo = k1 ? v[1] : v[0], hi = k1 ? v[3] : v[2]; return k2 ? hi : lo; };
 	nwt_d4 T00 = load_tile(0, 0, 0), T10 = load_tile(0, 1, 0), T11 = load_tile(0, 1, 1);
 	nwt_d4 T20 = load_tile(0, 2, 0), T21 = load_tile(0, 2, 1), T22 = load_tile(0, 2, 2);
 	for (int J = 0; J < nbr; J++) {
 		// next block row of the window: in flight during the panel factorisation
 		const nwt_d4 N0 = load_tile(J, 3, 1), N1 = load_tile(J, 3, 2), N2 = load_tile(J, 3, 3);
-		nwt_d4 E;
+		nwt_glb_dp base = Kc + (size_t)16 * J * ld;
+		const int rows_left = ng - 16 * J;
+		double x1[4], x2[4];   // the finished sub-diagonal tiles in the operand layout: x[s] = L[row li][column 4 s + lk]
 #pragma unroll
-		for (int r = 0; r < 4; r++) E[r] = (4 * r + lk == li) ? 1.0 : 0.0;
-		double mypiv = 1.0;   // pivot of this lane's column
-		// NP pivots per LDS round trip: columns j .. j + NP - 1 go to LDS together; every lane then redoes, in registers, what the earlier
-		// steps of the group do to the later columns of the group (its own rows of both tiles, the entries of the NP x NP pivot block, the
-		// entry of its own column) -- the same operations in the same order as NP single-pivot steps, so the results are bit-identical --
-		// and applies the NP column operations.  (The round trip, write -> wait -> read -> wait, is about half of a single-pivot step's
-		// latency: 12.0 k ticks per block column with one pivot per trip, 10.6 k with two or four.)
-		constexpr int NP = NWT_PIVOTS;
+		for (int s = 0; s < 4; s++) {
+			const int g = 4 * s;
+			// 1. columns g .. g + 3 of the panel (48 rows), from the accumulator layout (the 16 lanes that hold them) to LDS, read back by ROW
+			nwt_lds_dp cb = panel + (s & 1) * (4 * CS);   // alternate buffers: the next group's writes never meet this group's reads
+			if ((li >> 2) == s) {
+				const int o = (li & 3) * CS + lk;
 #pragma unroll
-		for (int j = 0; j < 16; j += NP) {
-			if (li >= j && li < j + NP) {   // columns j .. j + NP - 1: rows 4 r + lk of the two tiles
-				const int o = (li - j) * 32;
-#pragma unroll
-				for (int r = 0; r < 4; r++) { colbuf[o + 4 * lk + r] = T00[r]; colbuf[o + 16 + 4 * lk + r] = E[r]; }
+				for (int r = 0; r < 4; r++) { cb[o + 4 * r] = T00[r]; cb[o + 16 + 4 * r] = T10[r]; cb[o + 32 + 4 * r] = T20[r]; }
 			}
 			nwt_wave_sync();
-			double blk[NP][NP], ck[NP], c[NP][4], cE[NP][4];   // blk[p][q]: (row j + q, column j + p), q >= p;  ck[p]: (row li, column j + p)
+			double blk[4][4], c0[4], c1[4], c2[4];   // blk[p][q]: (row g + q, column g + p), q >= p;  c_t[p]: (row li of tile t, column g + p)
 #pragma unroll
-			for (int p = 0; p < NP; p++) {
+			for (int p = 0; p < 4; p++) {
 #pragma unroll
-				for (int q = p; q < NP; q++) blk[p][q] = colbuf[32 * p + ((j + q) & 3) * 4 + ((j + q) >> 2)];
-				ck[p] = colbuf[32 * p + (li & 3) * 4 + (li >> 2)];
-#pragma unroll
-				for (int r = 0; r < 4; r++) { c[p][r] = colbuf[32 * p + 4 * lk + r]; cE[p][r] = colbuf[32 * p + 16 + 4 * lk + r]; }
+				for (int q = p; q < 4; q++) blk[p][q] = cb[p * CS + g + q];
+				c0[p] = cb[p * CS + li]; c1[p] = cb[p * CS + 16 + li]; c2[p] = cb[p * CS + 32 + li];
 			}
-			double mown[NP];
+			// 2. the four pivots of the group in registers: every lane eliminates the 4 x 4 pivot block (redundantly) and its own row of the
+			// three tiles.  Columns stay unscaled (y = column of L times sqrt(pivot)): the reciprocal, not the reciprocal square root, is
+			// on the critical path.
+			double ip[4], dd[4];
 #pragma unroll
-			for (int p = 0; p < NP; p++) {
+			for (int p = 0; p < 4; p++) {
 				double piv = blk[p][p];
 				if (!(piv > 0.0)) { fail++; piv = strict ? 1.0 : 1e-30; }
-				const double ip = nwt_rcp(piv);
-				if (li == j + p) mypiv = piv;
-				mown[p] = li > j + p ? -ck[p] * ip : 0.0;
+				dd[p] = piv; ip[p] = nwt_rcp(piv);
 #pragma unroll
-				for (int pp = p + 1; pp < NP; pp++) {   // step j + p applied to the later columns of the group
-					const double mm = -blk[p][pp] * ip;
+				for (int pp = p + 1; pp < 4; pp++) {
+					const double mm = -blk[p][pp] * ip[p];
 #pragma unroll
-					for (int q = pp; q < NP; q++) blk[pp][q] = fma(blk[p][q], mm, blk[pp][q]);
-					ck[pp] = fma(ck[p], mm, ck[pp]);
-#pragma unroll
-					for (int r = 0; r < 4; r++) { c[pp][r] = fma(c[p][r], mm, c[pp][r]); cE[pp][r] = fma(cE[p][r], mm, cE[pp][r]); }
+					for (int q = pp; q < 4; q++) blk[pp][q] = fma(blk[p][q], mm, blk[pp][q]);
+					c0[pp] = fma(c0[p], mm, c0[pp]); c1[pp] = fma(c1[p], mm, c1[pp]); c2[pp] = fma(c2[p], mm, c2[pp]);
 				}
 			}
-#pragma unroll
-			for (int p = 0; p < NP; p++)
-#pragma unroll
-				for (int r = 0; r < 4; r++) { T00[r] = fma(c[p][r], mown[p], T00[r]); E[r] = fma(cE[p][r], mown[p], E[r]); }
-			nwt_wave_sync();   // the columns are consumed before the next group overwrites them
-		}
-		const double dinv = nwt_rsqrt(mypiv);
-#pragma unroll
-		for (int r = 0; r < 4; r++) { T00[r] *= dinv; E[r] *= dinv; }
-		// sub-diagonal tiles: X = T L00^-T = T E  (E[k][j] in the accumulator layout = operand B[k = 4 s + l/16][j = l%16])
-		{
-			double a1[4], a2[4];
-			nwt_to_operand2(T10, T20, xbuf, li, lk, a1, a2);
-			nwt_d4 X1 = {0.0, 0.0, 0.0, 0.0}, X2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-			for (int s = 0; s < 4; s++) {
-				X1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[s], E[s], X1, 0, 0, 0);
-				X2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[s], E[s], X2, 0, 0, 0);
+			// 3. rank-4 update of the later columns on the matrix cores, in the accumulator layout:  T_t -= (Y_t D^-1) Y_0',  operands
+			// A[i = li][k = lk] = y_t / d_k,  B[k = lk][j = li] = y_0 -- both are "row li, column g + lk": this lane's own values.  Rows of
+			// the diagonal tile at or above the pivot are masked (their entries are the unused upper triangle); finished and current
+			// columns receive no (finished) or unused (current) updates.
+			const double ys0 = pick(c0), ys1 = pick(c1), ys2 = pick(c2), ipk = pick(ip), dk = pick(dd);
+			const int dg = li - (g + lk);   // row minus pivot row inside the diagonal tile
+			const double y0 = dg > 0 ? ys0 : 0.0;
+			if (s < 3) {
+				T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-(y0 * ipk), y0, T00, 0, 0, 0);
+				T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-(ys1 * ipk), y0, T10, 0, 0, 0);
+				T20 = __builtin_amdgcn_mfma_f64_16x16x4f64(-(ys2 * ipk), y0, T20, 0, 0, 0);
 			}
-			T10 = X1; T20 = X2;
-		}
-		// the finished block column of L to HBM (band entries only; the diagonal inverted)
-		{
-			nwt_glb_dp base = Kc + (size_t)16 * J * ld;
-			const int rows_left = ng - 16 * J;
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const int rr = 4 * r + lk;
-				if (inband(0, 0, r) && rr < rows_left) base[off_of(0, 0, r)] = rr == li ? dinv : T00[r];
-				if (inband(1, 0, r) && 16 + rr < rows_left) base[off_of(1, 0, r)] = T10[r];
-				if (inband(2, 0, r) && 32 + rr < rows_left) base[off_of(2, 0, r)] = T20[r];
+			// 4. the group's columns of L (scaled once, off the critical path): to HBM by row (band entries only; the diagonal inverted), and
+			// kept as the operands of the trailing update -- which is the layout they are already in
+			const double rs = nwt_rsqrt(dk);
+			x1[s] = ys1 * rs; x2[s] = ys2 * rs;
+			{
+				const int d1 = 16 + dg, d2 = 32 + dg;   // row - column of the two sub-diagonal tiles
+				if (dg >= 0 && dg <= hb && li < rows_left) base[li * ld + (hb - dg)] = dg == 0 ? rs : y0 * rs;
+				if (d1 <= hb && 16 + li < rows_left) base[(16 + li) * ld + (hb - d1)] = x1[s];
+				if (d2 <= hb && 32 + li < rows_left) base[(32 + li) * ld + (hb - d2)] = x2[s];
 			}
 		}
 		// trailing update of the window
-		{
-			double x1[4], x2[4];
-			nwt_to_operand2(T10, T20, xbuf, li, lk, x1, x2);
 #pragma unroll
-			for (int s = 0; s < 4; s++) {
-				T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s], x1[s], T11, 0, 0, 0);
-				T21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x1[s], T21, 0, 0, 0);
-				T22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x2[s], T22, 0, 0, 0);
-			}
+		for (int s = 0; s < 4; s++) {
+			T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s], x1[s], T11, 0, 0, 0);
+			T21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x1[s], T21, 0, 0, 0);
+			T22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x2[s], T22, 0, 0, 0);
 		}
 		T00 = T11; T10 = T21; T11 = T22; T20 = N0; T21 = N1; T22 = N2;
 		if (strict && fail) break;   // not positive definite: the caller repeats with the Gauss-Newton terms, the rest is not needed
@@ -282,97 +264,99 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 }
 
 // y <- L^-T L^-1 y for one group by ONE wavefront.  y: LDS, 16 nbr + 48 doubles, entries >= ng zero.
+// Blocked by 16: lane (q, part) stands for row (forward) / column (backward) q of the block; the four parts split the products with the
+// entries outside the diagonal block, the 16 steps inside it exchange the finished unknowns through v_readlane.  The routine is bound by
+// instruction issue (one wave, dependent stream), so it is written for few instructions per block: entries a lane does not use are
+// loaded as zeros ONCE (at load time), the elimination steps are then unconditional (mul, readlane, fma -- no per-step predicates),
+// the coefficients of the next block are in flight in a second register set (the loop is unrolled by two: no copies), and the diagonal
+// (stored inverted) is a separate load instead of a 16-way select.  (Before: ~600 instructions per block and direction, 7.0 k ticks
+// per block; the arithmetic is 16 x 3.)
+struct NwtBlk { double o[8], l[16], dq; };
 __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict__ Lc, int ng, int hb, nwt_lds_dp y)
 {
 	const int lane = threadIdx.x & 63, q = lane & 15, part = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
+	// Which entries of a block a lane uses is a lane constant: kept as 0 / 1 factors (a multiply per loaded value, no predicates -- as
+	// booleans they were 24 SGPR pairs per direction, spilled to VGPR lanes and read back for every select) next to offsets clamped into
+	// the row, so that every load reads an initialised (finite) band entry.  What depends on the block -- rows beyond the end of the
+	// matrix, columns before its start -- needs no mask: those rows' unknowns are and stay zero (y is written for rows < ng only), and the
+	// band slots of columns < 0 hold the zeros they were initialised with (the factorisation stores inside the matrix only).
 	// ---- forward: L w = y ----
 	{
-		double off[8], lrow[16];
-		auto load = [&](int J, double (&o)[8], double (&lr)[16]) {
-			const int R = 16 * J + q;
+		double mo[8], ml[16]; int eo[8], el[16];
 #pragma unroll
-			for (int u = 0; u < 8; u++) {   // entries left of the diagonal block: columns R - hb + e < 16 J  <=>  e < hb - q
-				const int e = part + 4 * u, col = R - hb + e;
-				const bool ok = R < ng && e < hb - q && col >= 0;   // every load unconditional (clamped address, value selected): the wait for the
-				const double lv = Lc[NWT_IDX(ok ? (long long)R * ld + e : 0, (long long)ng * ld, "fo")];   // current block is then a counted vmcnt
-				o[u] = ok ? lv : 0.0;
-			}
+		for (int u = 0; u < 8; u++) { const int e = part + 4 * u; const bool ok = e < hb - q; mo[u] = ok ? 1.0 : 0.0; eo[u] = ok ? e : hb; }   // left of the diagonal block
 #pragma unroll
-			for (int c = 0; c < 16; c++) {   // row R of the diagonal block (every part loads it: the values are lane-uniform per q)
-				const int e = hb - (q - c);
-				const bool ok = R < ng && c <= q && e >= 0;
-				const double lv = Lc[NWT_IDX(ok ? (long long)R * ld + e : 0, (long long)ng * ld, "fd")];
-				lr[c] = ok ? lv : (c == q ? 1.0 : 0.0);
-			}
+		for (int c = 0; c < 16; c++) { const int e = hb - (q - c); const bool ok = c < q && e >= 0; ml[c] = ok ? 1.0 : 0.0; el[c] = ok ? e : hb; }   // row of the block, left of the diagonal
+		auto load = [&](int J, NwtBlk &b) {
+			nwt_glb_cdp rowp = Lc + (size_t)min(16 * J + q, ng - 1) * ld;
+#pragma unroll
+			for (int u = 0; u < 8; u++) b.o[u] = rowp[eo[u]];
+#pragma unroll
+			for (int c = 0; c < 16; c++) b.l[c] = rowp[el[c]];
+			b.dq = rowp[hb];
 		};
-		load(0, off, lrow);
-		for (int J = 0; J < nbr; J++) {
-			double offn[8], lrown[16];
-			load(min(J + 1, nbr - 1), offn, lrown);   // always (the last block loads itself again): no branch around the prefetch
+		auto step = [&](int J, NwtBlk &b, NwtBlk &nxt) {
+			load(min(J + 1, nbr - 1), nxt);   // always (the last block loads itself again): no branch around the prefetch
 			const int R = 16 * J + q;
 			double acc = 0.0;
 #pragma unroll
-			for (int u = 0; u < 8; u++) { const int col = R - hb + part + 4 * u; acc += off[u] * y[NWT_IDX(col >= 0 ? col : 0, 16 * nbr + 48, "y1")]; }
+			for (int u = 0; u < 8; u++) acc = fma(b.o[u] * mo[u], y[max(R - hb + part + 4 * u, 0)], acc);
 			acc += lane_xchg<16>(acc);
 			acc += lane_xchg<32>(acc);
-			double r = y[NWT_IDX(R, 16 * nbr + 48, "y2")] - acc;
+			double r = y[R] - acc;
 #pragma unroll
-			for (int j = 0; j < 16; j++) {
-				if (q == j) r = r * lrow[j];   // the diagonal is stored inverted
-				const double yj = nwt_readlane(r, j);
-				if (q > j) r -= lrow[j] * yj;
-			}
-			if (part == 0) y[R] = r;
+			for (int c = 0; c < 16; c++) b.l[c] *= ml[c];
+#pragma unroll
+			for (int j = 0; j < 16; j++) r = fma(-b.l[j], nwt_readlane(r * b.dq, j), r);   // lanes q <= j: l[j] = 0
+			if (part == 0 && R < ng) y[R] = r * b.dq;
 			nwt_wave_sync();
-#pragma unroll
-			for (int u = 0; u < 8; u++) off[u] = offn[u];
-#pragma unroll
-			for (int c = 0; c < 16; c++) lrow[c] = lrown[c];
+		};
+		NwtBlk A, B;
+		load(0, A);
+		for (int J = 0; J < nbr; J += 2) {
+			step(J, A, B);
+			if (J + 1 < nbr) step(J + 1, B, A);
 		}
 	}
 	// ---- backward: L' z = w ----
 	{
-		double off[8], lcol[16];
-		auto load = [&](int J, double (&o)[8], double (&lc)[16]) {
-			const int i = 16 * J + q;
+		// entry (row j, column i) sits at  j (ld - 1) + i + hb;  rows are clamped to the last one (whose unknown multiplies a zero)
+		double mo[8], ml[16];
 #pragma unroll
-			for (int u = 0; u < 8; u++) {   // rows below the diagonal block: j = 16 J + 16 + part + 4 u,  j - i <= hb
-				const int j = 16 * J + 16 + part + 4 * u;
-				const bool ok = j < ng && j - i <= hb;
-				const double lv = Lc[NWT_IDX(ok ? (long long)j * ld + (i - j + hb) : 0, (long long)ng * ld, "bo")];
-				o[u] = ok ? lv : 0.0;
-			}
+		for (int u = 0; u < 8; u++) mo[u] = (16 + part + 4 * u - q <= hb) ? 1.0 : 0.0;             // rows below the block: j - i <= hb
 #pragma unroll
-			for (int c = 0; c < 16; c++) {   // column q of the diagonal block: L[16 J + c][16 J + q], c >= q
-				const int j = 16 * J + c, e = hb - (c - q);
-				const bool ok = j < ng && c >= q && e >= 0;
-				const double lv = Lc[NWT_IDX(ok ? (long long)j * ld + e : 0, (long long)ng * ld, "bd")];
-				lc[c] = ok ? lv : (c == q ? 1.0 : 0.0);
-			}
+		for (int c = 0; c < 16; c++) ml[c] = (c > q && c - q <= hb) ? 1.0 : 0.0;                    // column of the block, below the diagonal
+		auto load = [&](int J, NwtBlk &b) {
+			// both indices clamped into the matrix: the address then lies inside the band's memory for used and unused entries alike
+			const int ic = min(16 * J + q, ng - 1);
+			nwt_glb_cdp colp = Lc + (ic + hb);
+#pragma unroll
+			for (int u = 0; u < 8; u++) b.o[u] = colp[(size_t)min(16 * J + 16 + part + 4 * u, ng - 1) * (ld - 1)];
+#pragma unroll
+			for (int c = 0; c < 16; c++) b.l[c] = colp[(size_t)min(16 * J + c, ng - 1) * (ld - 1)];
+			b.dq = colp[(size_t)ic * (ld - 1)];
 		};
-		load(nbr - 1, off, lcol);
-		for (int J = nbr - 1; J >= 0; J--) {
-			double offn[8], lcoln[16];
-			load(max(J - 1, 0), offn, lcoln);
+		auto step = [&](int J, NwtBlk &b, NwtBlk &nxt) {
+			load(max(J - 1, 0), nxt);
 			const int i = 16 * J + q;
 			double acc = 0.0;
 #pragma unroll
-			for (int u = 0; u < 8; u++) acc += off[u] * y[NWT_IDX(16 * J + 16 + part + 4 * u, 16 * nbr + 48, "y3")];
+			for (int u = 0; u < 8; u++) acc = fma(b.o[u] * mo[u], y[16 * J + 16 + part + 4 * u], acc);
 			acc += lane_xchg<16>(acc);
 			acc += lane_xchg<32>(acc);
-			double r = y[NWT_IDX(i, 16 * nbr + 48, "y4")] - acc;
+			double r = y[i] - acc;
 #pragma unroll
-			for (int j = 15; j >= 0; j--) {
-				if (q == j) r = r * lcol[j];   // the diagonal is stored inverted
-				const double zj = nwt_readlane(r, j);
-				if (q < j) r -= lcol[j] * zj;
-			}
-			if (part == 0) y[i] = r;
+			for (int c = 0; c < 16; c++) b.l[c] *= ml[c];
+#pragma unroll
+			for (int j = 15; j >= 0; j--) r = fma(-b.l[j], nwt_readlane(r * b.dq, j), r);   // lanes q >= j: l[j] = 0
+			if (part == 0 && i < ng) y[i] = r * b.dq;
 			nwt_wave_sync();
-#pragma unroll
-			for (int u = 0; u < 8; u++) off[u] = offn[u];
-#pragma unroll
-			for (int c = 0; c < 16; c++) lcol[c] = lcoln[c];
+		};
+		NwtBlk A, B;
+		load(nbr - 1, A);
+		for (int J = nbr - 1; J >= 0; J -= 2) {
+			step(J, A, B);
+			if (J - 1 >= 0) step(J - 1, B, A);
 		}
 	}
 }
