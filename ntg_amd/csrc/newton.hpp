@@ -181,6 +181,32 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 		}
 		return t;
 	};
+	// the block row prefetched per block column (tiles (J + 3, J + 1 .. J + 3)): which entries lie in the band is a lane constant, kept
+	// as a 0 / 1 factor and an offset clamped into the row (every address an initialised band entry of a row < ng); only "row < ng"
+	// moves with J, and beyond the end the tile is the identity
+	double nmask[3][4]; int noff[3][4]; double nident[4];
+#pragma unroll
+	for (int r = 0; r < 4; r++) {
+#pragma unroll
+		for (int b = 0; b < 3; b++) {
+			const int d = 16 * (3 - (b + 1)) + 4 * r + lk - li;   // row - column
+			const bool ok = d >= 0 && d <= hb;
+			nmask[b][r] = ok ? 1.0 : 0.0; noff[b][r] = ok ? hb - d : hb;   // entry e = column - row + hb of the row
+		}
+		nident[r] = (4 * r + lk == li) ? 1.0 : 0.0;
+	}
+	auto load_next = [&](int J, int b) {
+		nwt_d4 t;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int row = 16 * (J + 3) + 4 * r + lk;
+			const double v = Kc[(size_t)min(row, ng - 1) * ld + noff[b][r]];
+			// the select sits on the factor, not on the loaded value: the load stays unconditional (in flight across the panel factorisation)
+			t[r] = fma(v, row < ng ? nmask[b][r] : 0.0, (b == 2 && row >= ng) ? nident[r] : 0.0);
+		}
+		return t;
+	};
+	const double badpiv = strict ? 1.0 : 1e-30;
 	// the lane's k index of the operand layout (lk) picks one of a group's four columns
 	const bool k1 = (lk & 1) != 0, k2 = (lk & 2) != 0;
 	auto pick = [&](const double (&v)[4]) { const double lo = k1 ? v[1] : v[0], hi = k1 ? v[3] : v[2]; return k2 ? hi : lo; };
@@ -188,7 +214,7 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 	nwt_d4 T20 = load_tile(0, 2, 0), T21 = load_tile(0, 2, 1), T22 = load_tile(0, 2, 2);
 	for (int J = 0; J < nbr; J++) {
 		// next block row of the window: in flight during the panel factorisation
-		const nwt_d4 N0 = load_tile(J, 3, 1), N1 = load_tile(J, 3, 2), N2 = load_tile(J, 3, 3);
+		const nwt_d4 N0 = load_next(J, 0), N1 = load_next(J, 1), N2 = load_next(J, 2);
 		nwt_glb_dp base = Kc + (size_t)16 * J * ld;
 		const int rows_left = ng - 16 * J;
 		double x1[4], x2[4];   // the finished sub-diagonal tiles in the operand layout: x[s] = L[row li][column 4 s + lk]
@@ -217,7 +243,8 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 #pragma unroll
 			for (int p = 0; p < 4; p++) {
 				double piv = blk[p][p];
-				if (!(piv > 0.0)) { fail++; piv = strict ? 1.0 : 1e-30; }
+				const bool bad = !(piv > 0.0);   // (branch-free: a select and an add)
+				fail += bad ? 1 : 0; piv = bad ? badpiv : piv;
 				dd[p] = piv; ip[p] = nwt_rcp(piv);
 #pragma unroll
 				for (int pp = p + 1; pp < 4; pp++) {
