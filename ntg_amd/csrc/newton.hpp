@@ -463,6 +463,9 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 			}
 #pragma unroll
 			for (int e = 0; e < 12; e++) kv[e] = Kg[NWT_IDX(idx[e] >= 0 ? idx[e] : 0, (long long)ng * ld, "asm")];
+			// an interval none of whose breakpoints carries an active row or a multiplier has all-zero blocks: nothing to add (wave uniform;
+			// most intervals of most refreshes -- the requests above are simply dropped)
+			if (__ballot(bl[0] != 0.0 || bl[1] != 0.0 || bl[2] != 0.0 || bl[3] != 0.0) == 0ull) continue;
 #pragma unroll
 			for (int u = 0; u < 4; u++) if (lane + 64 * u < 216) wbuf[lane + 64 * u] = bl[u];
 			nwt_wave_sync();
