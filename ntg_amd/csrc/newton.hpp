@@ -417,6 +417,7 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 	if (tkx) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tkx[0] += t1 - tx0; tx0 = t1; }
 	if (!Bz) return;
 	double *wbuf = wbuf_all + wave * 216;
+	const unsigned long long *act = (const unsigned long long *)(wbuf_all + NW * 216);   // written by the block pass (sqp_kernel, nwt_refresh)
 	// the two local columns (block-coefficient index a = q go + o) this lane stands for in the operand tiles
 	const int a0 = li, a1 = 16 + li;
 	const int qa0 = a0 / go, oa0 = a0 - qa0 * go, qa1 = a1 / go, oa1 = a1 - qa1 * go;
@@ -439,7 +440,16 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 		const int ntc = (nint - color + cover - 1) / cover;   // intervals of this colour
 		for (int w = wave; w < ngp * ntc; w += NW) {
 			const int g = w / ntc, t = color + (w - g * ntc) * cover;
-			const int bp0 = D.igb[t], cnt = D.igb[t + 1] - bp0, of = offt[bp0];
+			const int bp0 = D.igb[t], cnt = D.igb[t + 1] - bp0;
+			{	// nothing to add when none of the interval's breakpoints has a non-zero block (flags of the block pass, wave uniform)
+				const unsigned long long *am = act + g * ((P + 63) >> 6);
+				const int w0 = bp0 >> 6, sh = bp0 & 63;
+				unsigned long long bits = am[w0] >> sh;
+				if (sh + cnt > 64) bits |= am[w0 + 1] << (64 - sh);
+				if (cnt < 64) bits &= (1ull << cnt) - 1ull;
+				if (__builtin_amdgcn_readfirstlane((int)(bits != 0ull)) == 0) continue;
+			}
+			const int of = offt[bp0];
 			const int kdim = cnt * cg, ksteps = (kdim + 3) >> 2, nb = cnt * cg * cg;
 			// requests: the interval's blocks ...
 			const double *Bsrc = Bz + ((size_t)g * P + bp0) * cg * cg;
@@ -463,9 +473,6 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 			}
 #pragma unroll
 			for (int e = 0; e < 12; e++) kv[e] = Kg[NWT_IDX(idx[e] >= 0 ? idx[e] : 0, (long long)ng * ld, "asm")];
-			// an interval none of whose breakpoints carries an active row or a multiplier has all-zero blocks: nothing to add (wave uniform;
-			// most intervals of most refreshes -- the requests above are simply dropped)
-			if (__ballot(bl[0] != 0.0 || bl[1] != 0.0 || bl[2] != 0.0 || bl[3] != 0.0) == 0ull) continue;
 #pragma unroll
 			for (int u = 0; u < 4; u++) if (lane + 64 * u < 216) wbuf[lane + 64 * u] = bl[u];
 			nwt_wave_sync();

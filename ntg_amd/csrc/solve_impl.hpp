@@ -1568,6 +1568,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	auto nwt_refresh = [&](const double *xs, bool allow_curv) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, P2 = D.P;
 		const int wave = tid >> 6;
+		unsigned long long *nwt_act = (unsigned long long *)((double *)(smem_raw + L.nwt_y) + (NT / 64) * 216);   // after the assembly's staging buffers
 		double *panel = (double *)(smem_raw + L.nwt_y) + (size_t)ngp * (16 * ((ng + 15) >> 4) + 48);
 		for (int attempt = (allow_curv && al.mu > 0.0) ? 0 : 1; attempt < 2; attempt++) {
 			const bool curv = attempt == 0;
@@ -1582,8 +1583,13 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					for (int g = 0; g < ngp; g++) {
 						double Bk[NWT_CG2];
 						FamN::template nltc_block<NZ>(NOUT > 0 ? NOUT : D.nout, g, z, t, al.mu, curv, Bk);
+						bool nzb = false;
 #pragma unroll
-						for (int e = 0; e < NWT_CG2; e++) nwt_B[((size_t)g * P2 + i) * NWT_CG2 + e] = Bk[e];
+						for (int e = 0; e < NWT_CG2; e++) { nwt_B[((size_t)g * P2 + i) * NWT_CG2 + e] = Bk[e]; nzb = nzb || Bk[e] != 0.0; }
+						// which breakpoints carry a non-zero block: one 64-bit word per wave and sweep (a wave's lanes are 64 consecutive
+						// breakpoints), read by the assembly to skip intervals that add nothing before it requests anything
+						const unsigned long long mb = __ballot(nzb);
+						if ((tid & 63) == 0) nwt_act[g * ((P2 + 63) >> 6) + (i >> 6)] = mb;
 					}
 				}
 				__syncthreads();
