@@ -49,6 +49,44 @@ def test_eval_matches_oracle(name, l):
     assert np.isclose(np.abs(jb).sum(), np.abs(J).sum(), rtol=1e-12)
 
 
+def _band_from_dense(spec, J, off):
+    """the banded rows as the dense Jacobian defines them: row r holds, output by output, the k entries that start at the first coefficient
+    of r's breakpoint (off[o][i]: the collocation offsets, equal to the reference's -- tests/test_gpu_basis_eval.py)"""
+    nb, ncnln, nC = J.shape
+    P, sumk = spec.nbps, sum(spec.order)
+    jb = np.zeros((nb, ncnln, sumk))
+    starts = np.r_[0, np.cumsum(spec.ncoef)]
+    for o in range(spec.nout):
+        k, ko = spec.order[o], int(np.sum(spec.order[:o]))
+        for i in range(P):
+            c0 = starts[o] + off[o][i]
+            rows = [spec.nnlic + j * P + i for j in range(spec.nnltc)]
+            jb[:, rows, ko:ko + k] = J[:, rows, c0:c0 + k]
+    return jb
+
+
+@pytest.mark.parametrize("name,l,flags", [("D", 8, [(o, r) for o in range(4) for r in range(5)]),      # 5 channels, one row per trip
+                                          ("D", 8, [(o, r) for o in range(3) for r in (0, 1, 2)]),       # 3 channels, two rows per trip
+                                          ("E", 8, [(o, r) for o in range(12) for r in range(3)]),        # flags the family's rows never touch
+                                          ("D", 40, None), ("E", 60, None)])
+def test_banded_rows_entry_by_entry_with_other_flag_sets(name, l, flags):
+    """the pair-of-entries emission of the banded Jacobian rows (eval_constraints): every instance of its row loop (1 .. 5 listed derivative
+    channels), with flag sets larger than what the family's rows touch (structural zeros are stored as zeros), entry by entry"""
+    spec, _ = _case(name, l)
+    if flags is not None:
+        spec.tcav = list(flags)
+    p = api.Plan(spec, 0)
+    x = np.random.default_rng(12).normal(size=(3, spec.nC)) * 0.5 + 1.0
+    ev = p.eval(dev(x), 2, want_dense_jac=True)
+    ref = orc.eval_batch(spec, x, 2, nthreads=3)
+    J = ev["cJac"].cpu().numpy()
+    assert rel(ev["c"].cpu().numpy(), ref["c"]) <= 1e-12 and rel(J, ref["cJac"]) <= 1e-12
+    jb = ev["jband"].cpu().numpy().reshape(3, spec.ncnln, -1)
+    want = _band_from_dense(spec, ref["cJac"], p.tables()["off"])
+    assert np.isclose(np.abs(want).sum(), np.abs(ref["cJac"]).sum(), rtol=1e-12)   # nothing of the dense Jacobian lies outside the band
+    assert jb.shape == want.shape and rel(jb, want) <= 1e-12
+
+
 def _kkt(spec, p, x, lo, up, lam, inf, feas_tol=1e-7):
     """first-order conditions of  min F  s.t.  A x = b,  bl <= c(x) <= bu  at the returned points"""
     ev = p.eval(x, 2, want_dense_jac=True)
