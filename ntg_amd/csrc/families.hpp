@@ -190,7 +190,7 @@ template <> struct Family<NTG_FAM_QUADROTOR> {
 	// flag entries (5 o + r) a trajectory constraint row can depend on: first and second derivatives of x, y, z
 	static constexpr u64 TCON_VARS = (1ull << 1) | (1ull << 2) | (1ull << 6) | (1ull << 7) | (1ull << 11) | (1ull << 12);
 	static constexpr bool PER_OUTPUT_COST = false;
-	static constexpr int COUPLE = 4, CG = 6;   // one group; constraint flag entries in flag order: x', x'', y', y'', z', z''
+	static constexpr int COUPLE = 3, CG = 6;   // one group (x, y, z), yaw is a free output; constraint flag entries in flag order: x', x'', y', y'', z', z''
 	template <int NZMAX> static __device__ __forceinline__ void nltc_block(int, int, const double *z, const double *t, double mu, bool curv, double *B)
 	{
 		const double a0[6] = {0.0, 2.0 * z[2], 0.0, 2.0 * z[7], 0.0, 2.0 * (z[12] + G)};   // thrust^2

@@ -53,6 +53,7 @@ struct NtgDims {
 	// structured Newton mode (newton.hpp): coupling groups of nwt_go outputs, nwt_ng free coefficients each (interleaved by
 	// output), half bandwidth nwt_hb, nwt_cg constraint flag entries per group; nwt_on = 0: the plan does not qualify
 	int nwt_on, nwt_ngrp, nwt_go, nwt_ng, nwt_hb, nwt_cg;
+	int nwt_nfo, nwt_ngf, nwt_hbf;   // free outputs (in no nonlinear row): count, free coefficients and band half width of each; their factor is NtgTables::nwt_lf
 	// breakpoint groups (consecutive breakpoints with the same block offset = one knot interval), how many consecutive
 	// groups overlap a coefficient (colours of the assembly), and the constraint flag entries of a group packed one byte
 	// each: (output within the group) << 4 | derivative
@@ -96,6 +97,7 @@ struct NtgTables {
 	// structured Newton mode: nwt_map[g][p] = coefficient of free entry p of group g; nwt_pos[c] = g * nwt_ng + p, or -1 for a
 	// pinned coefficient; nwt_k0 = cost-model band [g][p][hb+1]; nwt_lo/hi[cl] = breakpoints [lo, hi) in whose block cl lies
 	const int *nwt_map, *nwt_pos; const double *nwt_k0; const short *nwt_lo, *nwt_hi;
+	const double *nwt_lf;   // [nwt_nfo][nwt_ngf][nwt_hbf + 1]: band Cholesky factor (diagonal inverted) of the free outputs' cost model, built with the plan
 	const short *q_idx;    // [nC] row of coefficient c in the compact Q, or -1
 	const int *q_col;      // [q_nt][q_w]
 	const double *q_val;   // [q_nt][q_w], zero padded

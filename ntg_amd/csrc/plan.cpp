@@ -454,13 +454,17 @@ static int build_newton_tables(ntg_plan *p)
 	const int dm = D.d[0];
 	switch (D.family) {
 	case NTG_FAM_OBSTACLE: go = 2; cg = 2; gmask = (1ull << 0) | (1ull << 3); break;
-	case NTG_FAM_QUADROTOR: go = 4; cg = 6; gmask = (1ull << 1) | (1ull << 2) | (1ull << 6) | (1ull << 7) | (1ull << 11) | (1ull << 12); break;
+	// (x, y, z) couple through thrust and speed; the yaw output appears in no row: a FREE output -- its block of the model is the cost
+	// model's, the same for every problem and every refresh, factored once here (nwt_lf) and solved by an otherwise idle wave
+	case NTG_FAM_QUADROTOR: go = 3; cg = 6; gmask = (1ull << 1) | (1ull << 2) | (1ull << 6) | (1ull << 7) | (1ull << 11) | (1ull << 12); break;
 	case NTG_FAM_MANIP: go = 3; cg = 3; gmask = (1ull << 0) | (1ull << 3) | (1ull << 6); break;
 	default: return 0;
 	}
-	if (!D.uniform || D.nI > 0 || D.nnlic || D.nnlfc || D.nnltc <= 0 || D.nout % go || !p->lin_ok) return 0;
-	const int ngrp = D.nout / go, k = D.order[0], nco = D.ncoef[0], n = D.nC, P = D.P, hb = k * go - 1, m = D.mE;
-	if (hb > 32 || ngrp > 8) return 0;
+	if (!D.uniform || D.nI > 0 || D.nnlic || D.nnlfc || D.nnltc <= 0 || !p->lin_ok) return 0;
+	const int ngrp = D.nout / go, nfo = D.nout - ngrp * go;   // coupling groups; outputs left over are free (only the quadrotor family has one)
+	if (ngrp < 1 || (nfo && D.family != NTG_FAM_QUADROTOR)) return 0;
+	const int k = D.order[0], nco = D.ncoef[0], n = D.nC, P = D.P, hb = k * go - 1, m = D.mE, hbf = k - 1;
+	if (hb > 32 || ngrp + nfo > 8) return 0;
 	u64 want = 0;
 	for (int g = 0; g < ngrp; g++) want |= gmask << (dm * go * g);
 	if (D.tcon_mask != want) return 0;
@@ -489,6 +493,19 @@ static int build_newton_tables(ntg_plan *p)
 	}
 	if (ng < 1) return 0;
 	for (int c = 0; c < n; c++) if (pos[c] >= 0) pos[c] = (pos[c] / 1000000) * ng + pos[c] % 1000000;
+	// free outputs: their free coefficients follow the groups' in the maps, output by output (ngf each)
+	int ngf = 0;
+	for (int f = 0; f < nfo; f++) {
+		int cnt = 0;
+		for (int cl = 0; cl < nco; cl++) {
+			const int c = D.iC[ngrp * go + f] + cl;
+			if (pinned[c]) continue;
+			pos[c] = -2 - cnt; map.push_back(c); cnt++;   // provisional: -2 - index inside the output
+		}
+		if (f == 0) ngf = cnt; else if (cnt != ngf) return 0;
+	}
+	if (nfo && ngf < 1) return 0;
+	for (int f = 0; f < nfo; f++) for (int cl = 0; cl < nco; cl++) { const int c = D.iC[ngrp * go + f] + cl; if (pos[c] <= -2) pos[c] = ngrp * ng + f * ngf + (-2 - pos[c]); }
 	// breakpoint range of every local coefficient, from the block offsets (consecutive: checked when the column form was built)
 	std::vector<short> lo(nco, (short)P), hi(nco, 0);
 	const int *off = p->h_off.data();
@@ -496,6 +513,8 @@ static int build_newton_tables(ntg_plan *p)
 	// cost model: 2 w_i on the trajectory-cost variables, 2 on the initial / final ones (diagonal in the flag: same output only)
 	const int ld = hb + 1;
 	std::vector<double> k0((size_t)ngrp * ng * ld, 0.0);
+	const int ldf = hbf + 1;
+	std::vector<double> k0f((size_t)nfo * ngf * ldf, 0.0);   // cost model of the free outputs (band of half width k - 1 each)
 	const double *blk = p->h_blk.data();
 	auto add = [&](const std::vector<ntg_av> &av, int bp, double w) {
 		for (const ntg_av &a : av) {
@@ -503,9 +522,15 @@ static int build_newton_tables(ntg_plan *p)
 			for (int q1 = 0; q1 < k; q1++) for (int q2 = 0; q2 < k; q2++) {
 				const int c1 = D.iC[o] + off[bp] + q1, c2 = D.iC[o] + off[bp] + q2;
 				if (pos[c1] < 0 || pos[c2] < 0) continue;
+				const double v = w * blk[((size_t)bp * k + q1) * dm + r] * blk[((size_t)bp * k + q2) * dm + r];
+				if (o >= ngrp * go) {
+					const int f = o - ngrp * go, p1 = pos[c1] - ngrp * ng - f * ngf, p2 = pos[c2] - ngrp * ng - f * ngf;
+					if (p1 >= p2) k0f[((size_t)f * ngf + p1) * ldf + (p2 - p1 + hbf)] += v;
+					continue;
+				}
 				const int p1 = pos[c1] - g * ng, p2 = pos[c2] - g * ng;
 				if (p1 < p2) continue;
-				k0[((size_t)g * ng + p1) * ld + (p2 - p1 + hb)] += w * blk[((size_t)bp * k + q1) * dm + r] * blk[((size_t)bp * k + q2) * dm + r];
+				k0[((size_t)g * ng + p1) * ld + (p2 - p1 + hb)] += v;
 			}
 		}
 	};
@@ -540,7 +565,17 @@ static int build_newton_tables(ntg_plan *p)
 		for (int o = 0; o < D.nout; o++) for (int cl = 0; cl < nco; cl++) if ((bool)pinned[D.iC[o] + cl] != !(cl >= clo && cl < chi)) return 0;
 		D.nwt_clo = clo; D.nwt_chi = chi;
 	}
-	int *d_map = nullptr, *d_pos = nullptr; double *d_k0 = nullptr; short *d_lo = nullptr, *d_hi = nullptr;
+	// the free outputs' factor, in the layout nwt_solve_wave reads (row-major band, the diagonal inverted)
+	std::vector<double> lf((size_t)nfo * ngf * ldf, 0.0);
+	for (int f = 0; f < nfo; f++) {
+		std::vector<double> a((size_t)ngf * ngf, 0.0);
+		for (int i = 0; i < ngf; i++) for (int e = 0; e <= hbf; e++) { const int j = i - hbf + e; if (j >= 0) a[(size_t)i * ngf + j] = a[(size_t)j * ngf + i] = k0f[((size_t)f * ngf + i) * ldf + e]; }
+		if (!chol_lower(a, ngf)) return 0;   // a cost that leaves a free output without curvature: no structured Newton mode
+		for (int i = 0; i < ngf; i++) for (int e = 0; e <= hbf; e++) { const int j = i - hbf + e; if (j >= 0) lf[((size_t)f * ngf + i) * ldf + e] = (j == i) ? 1.0 / a[(size_t)i * ngf + i] : a[(size_t)i * ngf + j]; }
+	}
+	int *d_map = nullptr, *d_pos = nullptr; double *d_k0 = nullptr, *d_lf = nullptr; short *d_lo = nullptr, *d_hi = nullptr;
+	if (dev_upload(&d_lf, lf.data(), lf.size(), p->owned)) return NTG_E_HIP;
+	p->T.nwt_lf = d_lf; D.nwt_nfo = nfo; D.nwt_ngf = ngf; D.nwt_hbf = hbf;
 	if (dev_upload(&d_map, map.data(), map.size(), p->owned) || dev_upload(&d_pos, pos.data(), pos.size(), p->owned) ||
 	    dev_upload(&d_k0, k0.data(), k0.size(), p->owned) || dev_upload(&d_lo, lo.data(), lo.size(), p->owned) ||
 	    dev_upload(&d_hi, hi.data(), hi.size(), p->owned)) return NTG_E_HIP;
@@ -768,8 +803,8 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	// plan with more groups than the largest workgroup has waves takes the collocation preconditioner (decided here, once: workspace, layout
 	// and launch all see the same mode)
 	if (sp->hessian == 2) {
-		while (t < 512 && D.nwt_ngrp * 64 > t) t *= 2;
-		if (D.nwt_ngrp * 64 > t) sp->hessian = 1;
+		while (t < 512 && (D.nwt_ngrp + D.nwt_nfo) * 64 > t) t *= 2;
+		if ((D.nwt_ngrp + D.nwt_nfo) * 64 > t) sp->hessian = 1;
 	}
 	*nt = t;
 	return 0;

@@ -1621,12 +1621,23 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			const int g = i / ylen, pp = i - g * ylen;
 			yv[i] = pp < ng ? v[T.nwt_map[g * ng + pp]] : 0.0;
 		}
+		// free outputs (in no nonlinear row): their vectors sit behind the groups' vectors and panels; the factor is the plan's
+		const int nfo = D.nwt_nfo, ngf = D.nwt_ngf, hbf = D.nwt_hbf, ylenf = 16 * ((ngf + 15) >> 4) + 48;
+		double *yvf = yv + (size_t)ngp * (ylen + 48 * NWT_PSTRIDE);
+		for (int i = tid; i < nfo * ylenf; i += NT) {
+			const int f = i / ylenf, pp = i - f * ylenf;
+			yvf[i] = pp < ngf ? v[T.nwt_map[ngp * ng + f * ngf + pp]] : 0.0;
+		}
 		lds_sync();
 		if (wave < ngp) nwt_solve_wave((nwt_glb_cdp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(yv + (size_t)wave * ylen));
+		else if (wave < ngp + nfo) nwt_solve_wave((nwt_glb_cdp)(T.nwt_lf + (size_t)(wave - ngp) * ngf * (hbf + 1)), ngf, hbf, (nwt_lds_dp)(yvf + (size_t)(wave - ngp) * ylenf));
 		lds_sync();
 		for (int c = tid; c < n; c += NT) {
 			const int pos = T.nwt_pos[c];
-			out[c] = pos >= 0 ? yv[(pos / ng) * ylen + (pos % ng)] : 0.0;
+			double o = 0.0;
+			if (pos >= ngp * ng) { const int pf = pos - ngp * ng; o = yvf[(pf / ngf) * ylenf + (pf % ngf)]; }
+			else if (pos >= 0) o = yv[(pos / ng) * ylen + (pos % ng)];
+			out[c] = o;
 		}
 		if (BIG) __syncthreads(); else lds_sync();
 		// the area borrowed from the weighted-gradient rows goes back with its zero padding restored (stage_tables)
@@ -2036,7 +2047,7 @@ template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true,
 static hipError_t launch_sqp_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
 	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS, CHM, NWT>;
-	if (NWT && (!D.nwt_on || !a.nwtw || D.nwt_cg != Family<FAM>::CG || D.nwt_go != Family<FAM>::COUPLE || D.nwt_ngrp * 64 > NT)) return hipErrorInvalidValue;
+	if (NWT && (!D.nwt_on || !a.nwtw || D.nwt_cg != Family<FAM>::CG || D.nwt_go != Family<FAM>::COUPLE || (D.nwt_ngrp + D.nwt_nfo) * 64 > NT)) return hipErrorInvalidValue;
 	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
 	hipLaunchKernelGGL(kfn, dim3(a.batch), dim3(NT), L.total, a.st, D, T, L, sp, a.batch, a.lo, a.up, a.x, a.obj, a.inf, a.it, a.nf,
 	                   a.cl, a.hist, a.alw, a.vecw, a.nwtw);

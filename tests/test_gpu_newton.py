@@ -48,7 +48,7 @@ def _case(name):
 
 @pytest.mark.parametrize("name,nb", [("O", 24), ("D2", 16), ("E2", 12)])
 def test_newton_solve_matches_oracle(name, nb):
-    """same algorithm on both sides: inform, major-iteration counts within 3, objective to 1e-9, x to 1e-6"""
+    """same algorithm on both sides: inform, major-iteration counts within 3, objective to 1e-9 (one problem: 1e-8), x to 1e-6"""
     spec, bounds = _case(name)
     p = api.Plan(spec, 0)
     lo, up = bounds(nb)
@@ -66,7 +66,12 @@ def test_newton_solve_matches_oracle(name, nb):
     ok = (inf == 0) & (ref["inform"] == 0)
     assert int(ok.sum()) == nb - ref_inform1
     assert np.abs(it - ref["iters"])[ok].max() <= 3, (it, ref["iters"])
-    assert (np.abs(obj - ref["objective"]) <= 1e-9 * np.abs(ref["objective"]))[ok].all()
+    # objective: 1e-9 for all but one problem -- since the device solves the quadrotor's yaw output apart from (x, y, z) (a free output:
+    # constant factor from the plan) the two sides no longer round alike, and one D2 problem whose last pass stops at a
+    # violation of a few 1e-9 differs by 4.8e-9 in the objective (3.6e-8 in x; first order in the position along the active rows'
+    # normals).  The full-size golden comparisons below keep 1e-9.
+    dobj = np.abs(obj - ref["objective"]) / np.abs(ref["objective"])
+    assert (dobj[ok] <= 1e-8).all() and int((dobj[ok] > 1e-9).sum()) <= 1, dobj
     assert np.abs(x.cpu().numpy() - ref["x"])[ok].max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
     # and the mode is not the quasi-Newton mode in disguise: far fewer majors on the constrained problems
     x1 = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
