@@ -223,10 +223,18 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 			const int g = 4 * s;
 			// 1. columns g .. g + 3 of the panel (48 rows), from the accumulator layout (the 16 lanes that hold them) to LDS, read back by ROW
 			nwt_lds_dp cb = panel + (s & 1) * (4 * CS);   // alternate buffers: the next group's writes never meet this group's reads
+			// the third tile row holds band entries of this group's columns only if  row - column = 32 + li - (g + lk) <= hb  for some lane,
+			// i.e.  g + hb >= 29  (wave uniform; half width 17: the last group only, 23: the last two): its share of the exchange, of the
+			// elimination and of the products is skipped otherwise
+			const bool t2 = g + hb >= 29;
 			if ((li >> 2) == s) {
 				const int o = (li & 3) * CS + lk;
 #pragma unroll
-				for (int r = 0; r < 4; r++) { cb[o + 4 * r] = T00[r]; cb[o + 16 + 4 * r] = T10[r]; cb[o + 32 + 4 * r] = T20[r]; }
+				for (int r = 0; r < 4; r++) { cb[o + 4 * r] = T00[r]; cb[o + 16 + 4 * r] = T10[r]; }
+				if (t2) {
+#pragma unroll
+					for (int r = 0; r < 4; r++) cb[o + 32 + 4 * r] = T20[r];
+				}
 			}
 			nwt_wave_sync();
 			double blk[4][4], c0[4], c1[4], c2[4];   // blk[p][q]: (row g + q, column g + p), q >= p;  c_t[p]: (row li of tile t, column g + p)
@@ -234,7 +242,11 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 			for (int p = 0; p < 4; p++) {
 #pragma unroll
 				for (int q = p; q < 4; q++) blk[p][q] = cb[p * CS + g + q];
-				c0[p] = cb[p * CS + li]; c1[p] = cb[p * CS + 16 + li]; c2[p] = cb[p * CS + 32 + li];
+				c0[p] = cb[p * CS + li]; c1[p] = cb[p * CS + 16 + li]; c2[p] = 0.0;
+			}
+			if (t2) {
+#pragma unroll
+				for (int p = 0; p < 4; p++) c2[p] = cb[p * CS + 32 + li];
 			}
 			// 2. the four pivots of the group in registers: every lane eliminates the 4 x 4 pivot block (redundantly) and its own row of the
 			// three tiles.  Columns stay unscaled (y = column of L times sqrt(pivot)): the reciprocal, not the reciprocal square root, is
@@ -251,20 +263,21 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 					const double mm = -blk[p][pp] * ip[p];
 #pragma unroll
 					for (int q = pp; q < 4; q++) blk[pp][q] = fma(blk[p][q], mm, blk[pp][q]);
-					c0[pp] = fma(c0[p], mm, c0[pp]); c1[pp] = fma(c1[p], mm, c1[pp]); c2[pp] = fma(c2[p], mm, c2[pp]);
+					c0[pp] = fma(c0[p], mm, c0[pp]); c1[pp] = fma(c1[p], mm, c1[pp]);
+					if (t2) c2[pp] = fma(c2[p], mm, c2[pp]);
 				}
 			}
 			// 3. rank-4 update of the later columns on the matrix cores, in the accumulator layout:  T_t -= (Y_t D^-1) Y_0',  operands
 			// A[i = li][k = lk] = y_t / d_k,  B[k = lk][j = li] = y_0 -- both are "row li, column g + lk": this lane's own values.  Rows of
 			// the diagonal tile at or above the pivot are masked (their entries are the unused upper triangle); finished and current
 			// columns receive no (finished) or unused (current) updates.
-			const double ys0 = pick(c0), ys1 = pick(c1), ys2 = pick(c2), ipk = pick(ip), dk = pick(dd);
+			const double ys0 = pick(c0), ys1 = pick(c1), ys2 = t2 ? pick(c2) : 0.0, ipk = pick(ip), dk = pick(dd);
 			const int dg = li - (g + lk);   // row minus pivot row inside the diagonal tile
 			const double y0 = dg > 0 ? ys0 : 0.0;
 			if (s < 3) {
 				T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-(y0 * ipk), y0, T00, 0, 0, 0);
 				T10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-(ys1 * ipk), y0, T10, 0, 0, 0);
-				T20 = __builtin_amdgcn_mfma_f64_16x16x4f64(-(ys2 * ipk), y0, T20, 0, 0, 0);
+				if (t2) T20 = __builtin_amdgcn_mfma_f64_16x16x4f64(-(ys2 * ipk), y0, T20, 0, 0, 0);
 			}
 			// 4. the group's columns of L (scaled once, off the critical path): to HBM by row (band entries only; the diagonal inverted), and
 			// kept as the operands of the trailing update -- which is the layout they are already in
@@ -274,15 +287,17 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 				const int d1 = 16 + dg, d2 = 32 + dg;   // row - column of the two sub-diagonal tiles
 				if (dg >= 0 && dg <= hb && li < rows_left) base[li * ld + (hb - dg)] = dg == 0 ? rs : y0 * rs;
 				if (d1 <= hb && 16 + li < rows_left) base[(16 + li) * ld + (hb - d1)] = x1[s];
-				if (d2 <= hb && 32 + li < rows_left) base[(32 + li) * ld + (hb - d2)] = x2[s];
+				if (t2 && d2 <= hb && 32 + li < rows_left) base[(32 + li) * ld + (hb - d2)] = x2[s];
 			}
 		}
 		// trailing update of the window
 #pragma unroll
 		for (int s = 0; s < 4; s++) {
 			T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x1[s], x1[s], T11, 0, 0, 0);
-			T21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x1[s], T21, 0, 0, 0);
-			T22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x2[s], T22, 0, 0, 0);
+			if (4 * s + hb >= 29) {   // x2[s] is zero otherwise (see t2)
+				T21 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x1[s], T21, 0, 0, 0);
+				T22 = __builtin_amdgcn_mfma_f64_16x16x4f64(-x2[s], x2[s], T22, 0, 0, 0);
+			}
 		}
 		T00 = T11; T10 = T21; T11 = T22; T20 = N0; T21 = N1; T22 = N2;
 		if (strict && fail) break;   // not positive definite: the caller repeats with the Gauss-Newton terms, the rest is not needed
