@@ -427,7 +427,19 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 	constexpr int cg = CG;
 	const int kg = D.order[0] * go, cover = D.nwt_cover, nint = D.nwt_nint, total = ngp * ng * ld, clo = D.nwt_clo, chi = D.nwt_chi;
 	const u64 upack = D.nwt_upack;
-	for (int e = tid; e < total; e += NT) Kc[e] = T.nwt_k0[e];
+	{	// the cost model into the band: 16-byte words, four requests in flight per lane (the copy is a latency chain otherwise: 306 KB per
+		// refresh for config E, 5-8 % of a solve)
+		const double2 *src = reinterpret_cast<const double2 *>(T.nwt_k0);
+		double2 *dst = reinterpret_cast<double2 *>(Kc);
+		const int n2 = ((((size_t)Kc | (size_t)T.nwt_k0) & 15) == 0) ? total >> 1 : 0;
+		int e = tid;
+		for (; e + 3 * NT < n2; e += 4 * NT) {
+			const double2 a = src[e], b = src[e + NT], c = src[e + 2 * NT], d = src[e + 3 * NT];
+			dst[e] = a; dst[e + NT] = b; dst[e + 2 * NT] = c; dst[e + 3 * NT] = d;
+		}
+		for (; e < n2; e += NT) dst[e] = src[e];
+		for (int r = 2 * n2 + tid; r < total; r += NT) Kc[r] = T.nwt_k0[r];
+	}
 	__syncthreads();
 	if (tkx) { const unsigned long long t1 = __builtin_amdgcn_s_memtime(); tkx[0] += t1 - tx0; tx0 = t1; }
 	if (!Bz) return;
