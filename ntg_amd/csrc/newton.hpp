@@ -159,7 +159,9 @@ __device__ __forceinline__ void nwt_to_operand2(const nwt_d4 &Ta, const nwt_d4 &
 	for (int s = 0; s < 4; s++) { opa[s] = xb[li * NWT_PSTRIDE + 4 * s + lk]; opb[s] = xb2[li * NWT_PSTRIDE + 4 * s + lk]; }
 	nwt_wave_sync();
 }
-__device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__ Kc, int ng, int hb, nwt_lds_dp panel, int strict)
+// nstop: number of block columns to eliminate (>= the matrix's: all of it).  With nstop smaller the sweep stops there and the window -- the
+// Schur complement of the eliminated columns on the next 48 rows -- is written back into the band (two-sided factorisation, nwt_factor_pair).
+__device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__ Kc, int ng, int hb, nwt_lds_dp panel, int strict, int nstop)
 {
 	const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
 	constexpr int CS = 52;   // LDS stride (doubles) of a panel column of 48 rows: 104 words = 8 banks, the four columns of a group do not collide
@@ -212,7 +214,8 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 	auto pick = [&](const double (&v)[4]) { const double lo = k1 ? v[1] : v[0], hi = k1 ? v[3] : v[2]; return k2 ? hi : lo; };
 	nwt_d4 T00 = load_tile(0, 0, 0), T10 = load_tile(0, 1, 0), T11 = load_tile(0, 1, 1);
 	nwt_d4 T20 = load_tile(0, 2, 0), T21 = load_tile(0, 2, 1), T22 = load_tile(0, 2, 2);
-	for (int J = 0; J < nbr; J++) {
+	const int jend = min(nbr, nstop);
+	for (int J = 0; J < jend; J++) {
 		// next block row of the window: in flight during the panel factorisation
 		const nwt_d4 N0 = load_next(J, 0), N1 = load_next(J, 1), N2 = load_next(J, 2);
 		nwt_glb_dp base = Kc + (size_t)16 * J * ld;
@@ -302,6 +305,20 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 		T00 = T11; T10 = T21; T11 = T22; T20 = N0; T21 = N1; T22 = N2;
 		if (strict && fail) break;   // not positive definite: the caller repeats with the Gauss-Newton terms, the rest is not needed
 	}
+	if (jend < nbr && !(strict && fail)) {   // the window goes back to the band: rows 16 jend .. + 47, band entries inside the matrix
+		nwt_glb_dp base = Kc + (size_t)16 * jend * ld;
+		const int rows_left = ng - 16 * jend;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			const int rr = 4 * r + lk;
+			if (inband(0, 0, r) && rr < rows_left) base[off_of(0, 0, r)] = T00[r];
+			if (inband(1, 0, r) && 16 + rr < rows_left) base[off_of(1, 0, r)] = T10[r];
+			if (inband(2, 0, r) && 32 + rr < rows_left) base[off_of(2, 0, r)] = T20[r];
+			if (inband(1, 1, r) && 16 + rr < rows_left) base[off_of(1, 1, r)] = T11[r];
+			if (inband(2, 1, r) && 32 + rr < rows_left) base[off_of(2, 1, r)] = T21[r];
+			if (inband(2, 2, r) && 32 + rr < rows_left) base[off_of(2, 2, r)] = T22[r];
+		}
+	}
 	return fail;
 }
 
@@ -314,7 +331,11 @@ __device__ __attribute__((noinline)) int nwt_factor_wave(nwt_glb_dp __restrict__
 // (stored inverted) is a separate load instead of a 16-way select.  (Before: ~600 instructions per block and direction, 7.0 k ticks
 // per block; the arithmetic is 16 x 3.)
 struct NwtBlk { double o[8], l[16], dq; };
-__device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict__ Lc, int ng, int hb, nwt_lds_dp y)
+// Block ranges (two-sided factorisation, nwt_solve_pair): the forward pass runs over blocks [f0, f1), the blocks from facc on only
+// ACCUMULATE -- y[row] becomes the product of the row's entries left of its diagonal block with the unknowns found so far (the update a
+// separator row receives from this side), nothing is solved; the backward pass runs over blocks [b0, b1) downwards.  An empty range skips
+// the pass.  nwt_solve_wave(L, ng, hb, y) is the whole solve.
+__device__ __attribute__((noinline)) void nwt_solve_range(nwt_glb_cdp __restrict__ Lc, int ng, int hb, nwt_lds_dp y, int f0, int f1, int facc, int b0, int b1)
 {
 	const int lane = threadIdx.x & 63, q = lane & 15, part = lane >> 4, ld = hb + 1, nbr = (ng + 15) >> 4;
 	// Which entries of a block a lane uses is a lane constant: kept as 0 / 1 factors (a multiply per loaded value, no predicates -- as
@@ -345,6 +366,11 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 			for (int u = 0; u < 8; u++) acc = fma(b.o[u] * mo[u], y[max(R - hb + part + 4 * u, 0)], acc);
 			acc += lane_xchg<16>(acc);
 			acc += lane_xchg<32>(acc);
+			if (J >= facc) {   // (wave uniform) a separator block seen from this side: the update only
+				if (part == 0 && R < ng) y[R] = acc;
+				nwt_wave_sync();
+				return;
+			}
 			double r = y[R] - acc;
 #pragma unroll
 			for (int c = 0; c < 16; c++) b.l[c] *= ml[c];
@@ -353,11 +379,13 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 			if (part == 0 && R < ng) y[R] = r * b.dq;
 			nwt_wave_sync();
 		};
-		NwtBlk A, B;
-		load(0, A);
-		for (int J = 0; J < nbr; J += 2) {
-			step(J, A, B);
-			if (J + 1 < nbr) step(J + 1, B, A);
+		if (f0 < f1) {
+			NwtBlk A, B;
+			load(f0, A);
+			for (int J = f0; J < f1; J += 2) {
+				step(J, A, B);
+				if (J + 1 < f1) step(J + 1, B, A);
+			}
 		}
 	}
 	// ---- backward: L' z = w ----
@@ -394,13 +422,96 @@ __device__ __attribute__((noinline)) void nwt_solve_wave(nwt_glb_cdp __restrict_
 			if (part == 0 && i < ng) y[i] = r * b.dq;
 			nwt_wave_sync();
 		};
-		NwtBlk A, B;
-		load(nbr - 1, A);
-		for (int J = nbr - 1; J >= 0; J -= 2) {
-			step(J, A, B);
-			if (J - 1 >= 0) step(J - 1, B, A);
+		if (b0 < b1) {
+			NwtBlk A, B;
+			load(b1 - 1, A);
+			for (int J = b1 - 1; J >= b0; J -= 2) {
+				step(J, A, B);
+				if (J - 1 >= b0) step(J - 1, B, A);
+			}
 		}
 	}
+}
+__device__ __forceinline__ void nwt_solve_wave(nwt_glb_cdp Lc, int ng, int hb, nwt_lds_dp y)
+{
+	const int nbr = (ng + 15) >> 4;
+	nwt_solve_range(Lc, ng, hb, y, 0, nbr, nbr, 0, nbr);
+}
+
+// ---- two-sided factorisation: TWO wavefronts per coupling group ----
+// The band Cholesky is a chain of block columns; one wave walks it at the pace of its dependent instruction stream while the other waves of
+// the workgroup idle (config D: one group; config E: four groups on eight waves).  Split in the middle it is two chains of half the
+// length: the top wave eliminates block columns 0 .. ja - 1 downwards, the bottom wave eliminates the LAST jb block columns upwards -- which
+// is the same routine on the reversed matrix P K P, kept as a second band array (Kb: row p' = n - 1 - p; the assembly writes the entries of
+// bottom rows there, newton.hpp nwt_assemble; the cost model's share comes reversed from the plan).  Both stop at the separator, the
+// sep = n - 16 (ja + jb) rows in the middle (32 <= sep < 48 >= the half width, so no entry couples top and bottom directly): each writes
+// its Schur complement on the separator back into its array (nwt_factor_wave, nstop), the top wave adds the bottom wave's (the same band
+// offsets: entry (p, c) sits at row n - 1 - c of the reversed array), factors the separator and leaves L_SS in the top array.  The factor is
+//     L = [ L_TT . . ; . L_BB . ; L_ST L_SB L_SS ]   (unknowns ordered top, bottom, separator),
+// L_ST in the separator rows of the top array, L_SB in those of the bottom array.  Solves: both sides forward in parallel, the bottom wave
+// also forms L_SB w_B (the accumulate-only blocks of nwt_solve_range), the top wave finishes the separator forward and backward, both sides
+// backward in parallel.  Chain length 29 -> 13 + 3 block columns (config D), 34 -> 16 + 3 (config E).
+struct NwtPair { int n, hb, ja, jb; };   // free coefficients of a group, half width, block columns eliminated from the top / from the bottom
+__device__ __forceinline__ int nwt_pair_sep(const NwtPair &q) { return q.n - 16 * (q.ja + q.jb); }
+__device__ __forceinline__ int nwt_pair_brows(const NwtPair &q) { return 16 * q.jb + 48; }   // rows of the reversed array (allocation)
+
+// Called by EVERY wave of the workgroup (it contains workgroup barriers).  Waves [0, ngp) are the groups' top waves, [ngp, 2 ngp) their bottom
+// waves.  Kt: [ngp][n][ld], Kb: [ngp][brows][ld].  panel: LDS, 48 * NWT_PSTRIDE doubles per wave (2 ngp waves).  flag: LDS word, preset
+// to 0 by the caller, set when a strict factorisation met a non-positive pivot.  Returns this wave's count of replaced pivots.
+__device__ __forceinline__ int nwt_factor_pairs(double *Kt, double *Kb, int ngp, const NwtPair q, double *panel, int strict, int *flag)
+{
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ld = q.hb + 1, sep = nwt_pair_sep(q), brows = nwt_pair_brows(q);
+	int f = 0;
+	if (wave < ngp)
+		f = nwt_factor_wave((nwt_glb_dp)(Kt + (size_t)wave * q.n * ld), 16 * q.ja + sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), strict, q.ja);
+	else if (wave < 2 * ngp)
+		f = nwt_factor_wave((nwt_glb_dp)(Kb + (size_t)(wave - ngp) * brows * ld), 16 * q.jb + sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), strict, q.jb);
+	if (f && strict && lane == 0) *flag = 1;
+	__syncthreads();
+	if (wave < ngp && !(strict && *flag)) {
+		double *kt = Kt + (size_t)wave * q.n * ld, *kb = Kb + (size_t)wave * brows * ld;
+		for (int i = lane; i < sep * ld; i += 64) {
+			const int r = i / ld, e = i - r * ld, p = 16 * q.ja + r, col = p - q.hb + e;
+			if (col >= 16 * q.ja) {
+				const size_t ib = (size_t)(q.n - 1 - col) * ld + e;
+				kt[(size_t)p * ld + e] += kb[ib];
+				kb[ib] = 0.0;   // the bottom wave's forward pass multiplies these slots with the separator's unknowns-to-be
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores, before its tile loads of the same entries
+		const int f2 = nwt_factor_wave((nwt_glb_dp)(kt + (size_t)16 * q.ja * ld), sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), strict, 1 << 20);
+		if (f2 && strict && lane == 0) *flag = 1;
+		f += f2;
+	}
+	return f;
+}
+
+// y <- K^-1 y for every group with the two-sided factor.  Called by EVERY wave of the workgroup (barriers).  ya: [ngp][lena], the group's top
+// and separator entries in band order, zero padded (lena = 16 (ja + 3) + 48); yb: [ngp][lenb], the bottom entries REVERSED (yb[p'] = entry
+// n - 1 - p'), the rest zero (lenb = 16 (jb + 3) + 48).  On return the solution sits in the same places (separator: ya).
+// extra(): what the waves beyond 2 ngp do meanwhile (free outputs), called once.
+template <class F>
+__device__ __forceinline__ void nwt_solve_pairs(const double *Kt, const double *Kb, int ngp, const NwtPair q, double *ya, double *yb, F extra)
+{
+	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ld = q.hb + 1, sep = nwt_pair_sep(q), brows = nwt_pair_brows(q), nst = (sep + 15) >> 4;
+	const int lena = 16 * (q.ja + 3) + 48, lenb = 16 * (q.jb + 3) + 48, never = 1 << 20;
+	const int g = wave < ngp ? wave : wave - ngp;
+	nwt_glb_cdp kt = (nwt_glb_cdp)(Kt + (size_t)g * q.n * ld), kb = (nwt_glb_cdp)(Kb + (size_t)g * brows * ld);
+	nwt_lds_dp a = (nwt_lds_dp)(ya + (size_t)g * lena), b = (nwt_lds_dp)(yb + (size_t)g * lenb);
+	if (wave < ngp) nwt_solve_range(kt, 16 * q.ja + sep, q.hb, a, 0, q.ja, never, 0, 0);
+	else if (wave < 2 * ngp) nwt_solve_range(kb, 16 * q.jb + sep, q.hb, b, 0, q.jb + nst, q.jb, 0, 0);
+	else extra();
+	__syncthreads();
+	if (wave < ngp) {
+		if (lane < sep) a[16 * q.ja + lane] -= b[16 * q.jb + sep - 1 - lane];
+		nwt_wave_sync();
+		nwt_solve_range(kt, 16 * q.ja + sep, q.hb, a, q.ja, q.ja + nst, never, q.ja, q.ja + nst);
+		if (lane < sep) b[16 * q.jb + sep - 1 - lane] = a[16 * q.ja + lane];
+	}
+	__syncthreads();
+	if (wave < ngp) nwt_solve_range(kt, 16 * q.ja + sep, q.hb, a, 0, 0, never, 0, q.ja);
+	else if (wave < 2 * ngp) nwt_solve_range(kb, 16 * q.jb + sep, q.hb, b, 0, 0, never, 0, q.jb);
+	__syncthreads();
 }
 
 // K (compact band, every group) = cost model + sum over the breakpoints of M_i' B_i M_i, on the matrix cores.

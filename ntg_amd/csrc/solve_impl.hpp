@@ -1599,7 +1599,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), sp.stamps == 4 ? tk : nullptr);   // ends with a full barrier
 			NTG_STAMP(3);
 			if (wave < ngp) {
-				const int f = nwt_factor_wave((nwt_glb_dp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), curv ? 1 : 0);
+				const int f = nwt_factor_wave((nwt_glb_dp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), curv ? 1 : 0, 1 << 20);
 				if (f && curv && (tid & 63) == 0) nwt_flag[0] = 1;
 				if (f && !curv) nwt_bad += f;
 			}

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(64) unit_kernel(double *K, int ng, int hb, dou
 	for (int i = threadIdx.x; i < ylen; i += 64) y[i] = i < ng ? yio[i] : 0.0;
 	__syncthreads();
 	const long long t0 = __builtin_amdgcn_s_memtime();
-	const int f = nwt_factor_wave((nwt_glb_dp)K, ng, hb, (nwt_lds_dp)panel, 1);
+	const int f = nwt_factor_wave((nwt_glb_dp)K, ng, hb, (nwt_lds_dp)panel, 1, 1 << 20);
 	__syncthreads();
 	const long long t1 = __builtin_amdgcn_s_memtime();
 	nwt_solve_wave((nwt_glb_cdp)K, ng, hb, (nwt_lds_dp)y);
@@ -25,6 +25,27 @@ __global__ void __launch_bounds__(64) unit_kernel(double *K, int ng, int hb, dou
 	if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = t2 - t1; }
 	for (int i = threadIdx.x; i < ng; i += 64) yio[i] = y[i];
 	if (threadIdx.x == 0) *fail = f;
+}
+
+// two-sided factorisation (nwt_factor_pairs / nwt_solve_pairs): two waves, one group
+__global__ void __launch_bounds__(128) pair_kernel(double *Kt, double *Kb, NwtPair q, double *yio, int *fail, long long *cyc)
+{
+	extern __shared__ double sm[];
+	const int lena = 16 * (q.ja + 3) + 48, lenb = 16 * (q.jb + 3) + 48, sep = nwt_pair_sep(q);
+	double *ya = sm, *yb = sm + lena, *panel = yb + lenb;
+	__shared__ int flag;
+	if (threadIdx.x == 0) flag = 0;
+	for (int i = threadIdx.x; i < lena; i += 128) ya[i] = i < 16 * q.ja + sep ? yio[i] : 0.0;
+	for (int i = threadIdx.x; i < lenb; i += 128) yb[i] = i < 16 * q.jb ? yio[q.n - 1 - i] : 0.0;
+	__syncthreads();
+	const long long t0 = __builtin_amdgcn_s_memtime();
+	const int f = nwt_factor_pairs(Kt, Kb, 1, q, panel, 1, &flag);
+	__syncthreads();
+	const long long t1 = __builtin_amdgcn_s_memtime();
+	nwt_solve_pairs(Kt, Kb, 1, q, ya, yb, [] {});
+	const long long t2 = __builtin_amdgcn_s_memtime();
+	if (threadIdx.x == 0) { cyc[0] = t1 - t0; cyc[1] = t2 - t1; *fail = f + flag; }
+	for (int i = threadIdx.x; i < q.n; i += 128) yio[i] = i < 16 * q.ja + sep ? ya[i] : yb[q.n - 1 - i];
 }
 
 int main(int argc, char **argv)
@@ -55,6 +76,30 @@ int main(int argc, char **argv)
 	x = rhs;
 	for (int i = 0; i < ng; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[(size_t)i * ng + k] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
 	for (int i = ng - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < ng; k++) s -= L[(size_t)k * ng + i] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
+	if (argc > 4 && atoi(argv[4]) == 2) {   // two-sided: nwt_unit ng hb spread 2
+		NwtPair q; q.n = ng; q.hb = hb; const int jt = (ng - 32) / 16; q.ja = (jt + 1) / 2; q.jb = jt / 2;
+		const int sep = ng - 16 * (q.ja + q.jb), ngt = 16 * q.ja + sep, brows = 16 * q.jb + 48;
+		std::vector<double> Kt((size_t)ng * ld, 0.0), Kb((size_t)brows * ld, 0.0);
+		for (int i = 0; i < ng; i++) for (int e = 0; e <= hb; e++) {
+			const int j = i - hb + e; if (j < 0) continue;
+			if (i < ngt) Kt[(size_t)i * ld + e] = K[(size_t)i * ld + e];
+			else Kb[(size_t)(ng - 1 - j) * ld + e] = K[(size_t)i * ld + e];
+		}
+		double *dKt, *dKb, *dy2; int *df2; long long *dc2, hc2[2] = {0, 0};
+		hipMalloc(&dKt, Kt.size() * 8); hipMalloc(&dKb, Kb.size() * 8); hipMalloc(&dy2, ng * 8); hipMalloc(&df2, 4); hipMalloc(&dc2, 16);
+		hipMemcpy(dKt, Kt.data(), Kt.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dKb, Kb.data(), Kb.size() * 8, hipMemcpyHostToDevice);
+		hipMemcpy(dy2, rhs.data(), ng * 8, hipMemcpyHostToDevice);
+		const size_t lds2 = (size_t)(16 * (q.ja + 3) + 48 + 16 * (q.jb + 3) + 48 + 2 * 48 * NWT_PSTRIDE) * 8;
+		hipLaunchKernelGGL(pair_kernel, dim3(1), dim3(128), lds2, 0, dKt, dKb, q, dy2, df2, dc2);
+		if (hipDeviceSynchronize() != hipSuccess) { printf("pair kernel failed\n"); return 2; }
+		std::vector<double> y2(ng); int fail2 = -1;
+		hipMemcpy(y2.data(), dy2, ng * 8, hipMemcpyDeviceToHost); hipMemcpy(&fail2, df2, 4, hipMemcpyDeviceToHost); hipMemcpy(hc2, dc2, 16, hipMemcpyDeviceToHost);
+		double err2 = 0.0, nx2 = 0.0;
+		for (int i = 0; i < ng; i++) { err2 = fmax(err2, fabs(y2[i] - x[i])); nx2 = fmax(nx2, fabs(x[i])); }
+		printf("  two-sided: ja %d jb %d sep %d; clock ticks: factor %lld, solve %lld\n", q.ja, q.jb, sep, hc2[0], hc2[1]);
+		printf("ng %d hb %d fail %d: max rel err two-sided factor-solve: %.3e\n", ng, hb, fail2, err2 / nx2);
+		return (fail2 == 0 && err2 / nx2 < 1e-9) ? 0 : 1;
+	}
 	double *dK, *dy; int *df; long long *dc, hc[2] = {0, 0};
 	hipMalloc(&dK, K.size() * 8); hipMalloc(&dy, ng * 8); hipMalloc(&df, 4); hipMalloc(&dc, 16);
 	hipMemcpy(dK, K.data(), K.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dy, rhs.data(), ng * 8, hipMemcpyHostToDevice);
