@@ -21,7 +21,8 @@
 #include <hip/hip_runtime.h>
 #include "ntg_dev.hpp"
 
-#define NWT_PSTRIDE 17   // LDS row stride (doubles) of the 48 x 16 panel
+#define NWT_PSTRIDE 17   // LDS row stride (doubles) of a 48 x 16 panel in operand order (nwt_to_operand: diagnostics, tests/tools_mfma.hip)
+#define NWT_PANEL 416    // LDS doubles a factoring wave owns (nwt_factor_wave: two buffers of four panel columns, stride 52)
 #ifndef NWT_PIVOTS
 #define NWT_PIVOTS 2     // pivots per LDS round trip of the factorisation's sweep (1, 2 or 4; 4 is no faster standalone and 15-30 % slower
                          // inside the solve kernels, whose instances compile the routine for at most 256 registers)
@@ -456,16 +457,16 @@ __device__ __forceinline__ int nwt_pair_sep(const NwtPair &q) { return q.n - 16 
 __device__ __forceinline__ int nwt_pair_brows(const NwtPair &q) { return 16 * q.jb + 48; }   // rows of the reversed array (allocation)
 
 // Called by EVERY wave of the workgroup (it contains workgroup barriers).  Waves [0, ngp) are the groups' top waves, [ngp, 2 ngp) their bottom
-// waves.  Kt: [ngp][n][ld], Kb: [ngp][brows][ld].  panel: LDS, 48 * NWT_PSTRIDE doubles per wave (2 ngp waves).  flag: LDS word, preset
+// waves.  Kt: [ngp][n][ld], Kb: [ngp][brows][ld].  panel: LDS, NWT_PANEL doubles per wave (2 ngp waves).  flag: LDS word, preset
 // to 0 by the caller, set when a strict factorisation met a non-positive pivot.  Returns this wave's count of replaced pivots.
 __device__ __forceinline__ int nwt_factor_pairs(double *Kt, double *Kb, int ngp, const NwtPair q, double *panel, int strict, int *flag)
 {
 	const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, ld = q.hb + 1, sep = nwt_pair_sep(q), brows = nwt_pair_brows(q);
 	int f = 0;
 	if (wave < ngp)
-		f = nwt_factor_wave((nwt_glb_dp)(Kt + (size_t)wave * q.n * ld), 16 * q.ja + sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), strict, q.ja);
+		f = nwt_factor_wave((nwt_glb_dp)(Kt + (size_t)wave * q.n * ld), 16 * q.ja + sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * NWT_PANEL), strict, q.ja);
 	else if (wave < 2 * ngp)
-		f = nwt_factor_wave((nwt_glb_dp)(Kb + (size_t)(wave - ngp) * brows * ld), 16 * q.jb + sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), strict, q.jb);
+		f = nwt_factor_wave((nwt_glb_dp)(Kb + (size_t)(wave - ngp) * brows * ld), 16 * q.jb + sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * NWT_PANEL), strict, q.jb);
 	if (f && strict && lane == 0) *flag = 1;
 	__syncthreads();
 	if (wave < ngp && !(strict && *flag)) {
@@ -479,7 +480,7 @@ __device__ __forceinline__ int nwt_factor_pairs(double *Kt, double *Kb, int ngp,
 			}
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's own stores, before its tile loads of the same entries
-		const int f2 = nwt_factor_wave((nwt_glb_dp)(kt + (size_t)16 * q.ja * ld), sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), strict, 1 << 20);
+		const int f2 = nwt_factor_wave((nwt_glb_dp)(kt + (size_t)16 * q.ja * ld), sep, q.hb, (nwt_lds_dp)(panel + (size_t)wave * NWT_PANEL), strict, 1 << 20);
 		if (f2 && strict && lane == 0) *flag = 1;
 		f += f2;
 	}
@@ -536,7 +537,11 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
 	const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ld = hb + 1, go = D.nwt_go, P = D.P;
 	constexpr int cg = CG;
-	const int kg = D.order[0] * go, cover = D.nwt_cover, nint = D.nwt_nint, total = ngp * ng * ld, clo = D.nwt_clo, chi = D.nwt_chi;
+	const int kg = D.order[0] * go, cover = D.nwt_cover, nint = D.nwt_nint, clo = D.nwt_clo, chi = D.nwt_chi;
+	// two-sided factorisation: the entries of rows below the separator live in the reversed array behind the groups' top arrays
+	const bool tw = D.nwt_tw != 0;
+	const int brows = 16 * D.nwt_jb + 48, ngt = tw ? ng - 16 * D.nwt_jb : ng;   // top rows + separator rows
+	const int total = ngp * ng * ld + (tw ? ngp * brows * ld : 0);
 	const u64 upack = D.nwt_upack;
 	{	// the cost model into the band: 16-byte words, four requests in flight per lane (the copy is a latency chain otherwise: 306 KB per
 		// refresh for config E, 5-8 % of a solve)
@@ -596,6 +601,7 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 			for (int u = 0; u < 4; u++) bl[u] = lane + 64 * u < nb ? Bsrc[lane + 64 * u] : 0.0;
 			// ... and the band entries of the lower triangle of S: local index a -> free index p = (of + a/go - clo) go + a%go
 			double *Kg = Kc + (size_t)g * ng * ld;
+			const int kbd = (ngp - g) * ng * ld + g * brows * ld;
 			const int cb0 = of + qa0, cb1 = of + qa1;
 			const bool fb0 = va0 && cb0 >= clo && cb0 < chi, fb1 = va1 && cb1 >= clo && cb1 < chi;
 			const int pb0 = (cb0 - clo) * go + oa0, pb1 = (cb1 - clo) * go + oa1;
@@ -605,12 +611,15 @@ NWT_FN void nwt_assemble(const NtgDims &D, const NtgTables &T, const double *row
 				const int cr0 = of + qr0[r], cr1 = of + qr1[r];
 				const bool fr0 = 4 * r + lk < kg && cr0 >= clo && cr0 < chi, fr1 = 16 + 4 * r + lk < kg && cr1 >= clo && cr1 < chi;
 				const int pr0 = (cr0 - clo) * go + or0[r], pr1 = (cr1 - clo) * go + or1[r];
-				idx[3 * r] = (fr0 && fb0 && pr0 >= pb0) ? pr0 * ld + (pb0 - pr0 + hb) : -1;
-				idx[3 * r + 1] = (fr1 && fb0) ? pr1 * ld + (pb0 - pr1 + hb) : -1;
-				idx[3 * r + 2] = (fr1 && fb1 && pr1 >= pb1) ? pr1 * ld + (pb1 - pr1 + hb) : -1;
+				// entry (row pr, column pb) of the group's matrix: in the top array, or -- rows below the separator -- at row n - 1 - pb of the
+				// reversed array (same band offset), whose distance from the group's top array is kbd
+				auto at = [&](int pr, int pb) { return pr < ngt ? pr * ld + (pb - pr + hb) : kbd + (ng - 1 - pb) * ld + (pb - pr + hb); };
+				idx[3 * r] = (fr0 && fb0 && pr0 >= pb0) ? at(pr0, pb0) : -1;
+				idx[3 * r + 1] = (fr1 && fb0) ? at(pr1, pb0) : -1;
+				idx[3 * r + 2] = (fr1 && fb1 && pr1 >= pb1) ? at(pr1, pb1) : -1;
 			}
 #pragma unroll
-			for (int e = 0; e < 12; e++) kv[e] = Kg[NWT_IDX(idx[e] >= 0 ? idx[e] : 0, (long long)ng * ld, "asm")];
+			for (int e = 0; e < 12; e++) kv[e] = Kg[NWT_IDX(idx[e] >= 0 ? idx[e] : 0, (long long)total, "asm")];
 #pragma unroll
 			for (int u = 0; u < 4; u++) if (lane + 64 * u < 216) wbuf[lane + 64 * u] = bl[u];
 			nwt_wave_sync();

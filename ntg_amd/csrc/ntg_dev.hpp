@@ -53,6 +53,7 @@ struct NtgDims {
 	// structured Newton mode (newton.hpp): coupling groups of nwt_go outputs, nwt_ng free coefficients each (interleaved by
 	// output), half bandwidth nwt_hb, nwt_cg constraint flag entries per group; nwt_on = 0: the plan does not qualify
 	int nwt_on, nwt_ngrp, nwt_go, nwt_ng, nwt_hb, nwt_cg;
+	int nwt_tw, nwt_ja, nwt_jb;      // two-sided factorisation (newton.hpp, nwt_factor_pairs): on, block columns eliminated from the top / from the bottom
 	int nwt_nfo, nwt_ngf, nwt_hbf;   // free outputs (in no nonlinear row): count, free coefficients and band half width of each; their factor is NtgTables::nwt_lf
 	// breakpoint groups (consecutive breakpoints with the same block offset = one knot interval), how many consecutive
 	// groups overlap a coefficient (colours of the assembly), and the constraint flag entries of a group packed one byte

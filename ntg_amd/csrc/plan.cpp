@@ -565,6 +565,26 @@ static int build_newton_tables(ntg_plan *p)
 		for (int o = 0; o < D.nout; o++) for (int cl = 0; cl < nco; cl++) if ((bool)pinned[D.iC[o] + cl] != !(cl >= clo && cl < chi)) return 0;
 		D.nwt_clo = clo; D.nwt_chi = chi;
 	}
+	// two-sided factorisation: two waves per group when the band is long enough and the largest workgroup has the waves (newton.hpp).  The
+	// cost model is then split like the band: rows of the top part and the separator stay where they are, the entries of bottom rows move
+	// to the reversed array (entry (i, j) -> row n - 1 - j, same band offset), which follows the groups' top arrays in the table.
+	D.nwt_tw = 0; D.nwt_ja = D.nwt_jb = 0;
+	// (only while every working wave still has a SIMD of its own: with four groups -- config E, eight waves -- the second wave of a group
+	// shares its SIMD with another group's, both streams are issue bound, and the measured solve was 16 % SLOWER)
+	if (ng >= 128 && 2 * ngrp + nfo <= 4 && !getenv("NTG_AMD_NO_TWOSIDED")) {
+		const int jt = (ng - 32) / 16;
+		D.nwt_tw = 1; D.nwt_ja = (jt + 1) / 2; D.nwt_jb = jt / 2;
+		const int sepn = ng - 16 * (D.nwt_ja + D.nwt_jb), ngt = 16 * D.nwt_ja + sepn, brows = 16 * D.nwt_jb + 48;
+		std::vector<double> kb((size_t)ngrp * brows * ld, 0.0);
+		for (int g = 0; g < ngrp; g++)
+			for (int i = ngt; i < ng; i++) for (int e = 0; e <= hb; e++) {
+				const int j = i - hb + e;
+				double &src = k0[((size_t)g * ng + i) * ld + e];
+				if (j >= 0) kb[((size_t)g * brows + (ng - 1 - j)) * ld + e] = src;
+				src = 0.0;
+			}
+		k0.insert(k0.end(), kb.begin(), kb.end());
+	}
 	// the free outputs' factor, in the layout nwt_solve_wave reads (row-major band, the diagonal inverted)
 	std::vector<double> lf((size_t)nfo * ngf * ldf, 0.0);
 	for (int f = 0; f < nfo; f++) {
@@ -803,8 +823,9 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	// plan with more groups than the largest workgroup has waves takes the collocation preconditioner (decided here, once: workspace, layout
 	// and launch all see the same mode)
 	if (sp->hessian == 2) {
-		while (t < 512 && (D.nwt_ngrp + D.nwt_nfo) * 64 > t) t *= 2;
-		if ((D.nwt_ngrp + D.nwt_nfo) * 64 > t) sp->hessian = 1;
+		const int nwv = (D.nwt_tw ? 2 : 1) * D.nwt_ngrp + D.nwt_nfo;   // two waves per group with the two-sided factorisation
+		while (t < 512 && nwv * 64 > t) t *= 2;
+		if (nwv * 64 > t) sp->hessian = 1;
 	}
 	*nt = t;
 	return 0;
@@ -835,7 +856,8 @@ static size_t al_doubles(const NtgDims &D, int batch) { return (size_t)batch * 2
 static size_t nwt_doubles(const NtgDims &D, int batch, const SolveParams &sp)
 {
 	if (sp.hessian != 2 || !D.nwt_on) return 0;
-	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg);
+	const size_t rev = D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0;   // the reversed arrays of the two-sided factorisation
+	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + rev + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg);
 }
 
 static int plan_ncu(const ntg_plan *p)

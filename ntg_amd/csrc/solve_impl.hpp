@@ -1556,8 +1556,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	// structured Newton mode: band matrix / factor and the per-breakpoint blocks of this problem (HBM), flags
 	using FamN = Family<FAM>;
 	constexpr int NWT_CG2 = FamN::CG * FamN::CG;
-	double *nwt_K = NWT ? nwt_all + (size_t)b * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (size_t)D.nwt_ngrp * D.P * NWT_CG2) : nullptr;
-	double *nwt_B = NWT ? nwt_K + (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) : nullptr;
+	// per problem: the groups' band arrays, [two-sided factorisation: their reversed arrays,] the per-breakpoint blocks
+	const size_t nwt_ksz = (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0);
+	double *nwt_K = NWT ? nwt_all + (size_t)b * (nwt_ksz + (size_t)D.nwt_ngrp * D.P * NWT_CG2) : nullptr;
+	double *nwt_B = NWT ? nwt_K + nwt_ksz : nullptr;
+	const NwtPair nwt_q{D.nwt_ng, D.nwt_hb, D.nwt_ja, D.nwt_jb};
+	const int nwt_lena = 16 * (D.nwt_ja + 3) + 48, nwt_lenb = 16 * (D.nwt_jb + 3) + 48;
+	// LDS of the mode (the area at L.nwt_y): the groups' solve vectors, the factorisation panels (one per factoring wave), the free outputs' vectors
+	const int nwt_yall = D.nwt_ngrp * (D.nwt_tw ? nwt_lena + nwt_lenb : 16 * ((D.nwt_ng + 15) >> 4) + 48), nwt_npan = (D.nwt_tw ? 2 : 1) * D.nwt_ngrp;
 	bool nwt_curv = false;        // the current factor includes the constraint curvature
 	int nwt_bad = 0;              // diagnostic: non-positive pivots replaced in Gauss-Newton factorisations (wave 0's count)
 	int nwt_nfact = 0, nwt_nfail = 0, nwt_napply = 0;   // diagnostic (sp.stamps == 3): factorisations, of which not positive definite, solves
@@ -1569,7 +1575,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, P2 = D.P;
 		const int wave = tid >> 6;
 		unsigned long long *nwt_act = (unsigned long long *)((double *)(smem_raw + L.nwt_y) + (NT / 64) * 216);   // after the assembly's staging buffers
-		double *panel = (double *)(smem_raw + L.nwt_y) + (size_t)ngp * (16 * ((ng + 15) >> 4) + 48);
+		double *panel = (double *)(smem_raw + L.nwt_y) + nwt_yall;
 		for (int attempt = (allow_curv && al.mu > 0.0) ? 0 : 1; attempt < 2; attempt++) {
 			const bool curv = attempt == 0;
 			if (al.mu > 0.0) {
@@ -1598,8 +1604,11 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (tid == 0) nwt_flag[0] = 0;
 			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), sp.stamps == 4 ? tk : nullptr);   // ends with a full barrier
 			NTG_STAMP(3);
-			if (wave < ngp) {
-				const int f = nwt_factor_wave((nwt_glb_dp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(panel + (size_t)wave * 48 * NWT_PSTRIDE), curv ? 1 : 0, 1 << 20);
+			if (D.nwt_tw) {   // two waves per group (wave uniform: every wave takes this branch)
+				const int f = nwt_factor_pairs(nwt_K, nwt_K + (size_t)ngp * ng * (hb + 1), ngp, nwt_q, panel, curv ? 1 : 0, nwt_flag);
+				if (f && !curv) nwt_bad += f;
+			} else if (wave < ngp) {
+				const int f = nwt_factor_wave((nwt_glb_dp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(panel + (size_t)wave * NWT_PANEL), curv ? 1 : 0, 1 << 20);
 				if (f && curv && (tid & 63) == 0) nwt_flag[0] = 1;
 				if (f && !curv) nwt_bad += f;
 			}
@@ -1617,26 +1626,45 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		double *yv = (double *)(smem_raw + L.nwt_y);
 		nwt_napply++;
 		if (BIG) __syncthreads(); else lds_sync();
+		const bool tw = D.nwt_tw != 0;
+		const int ngt = ng - 16 * D.nwt_jb;   // two-sided: entries of the top part and the separator (vector a), the rest reversed (vector b)
+		double *yb = yv + (size_t)ngp * nwt_lena;
+		if (tw) {
+			for (int i = tid; i < ngp * nwt_lena; i += NT) { const int g = i / nwt_lena, pp = i - g * nwt_lena; yv[i] = pp < ngt ? v[T.nwt_map[g * ng + pp]] : 0.0; }
+			for (int i = tid; i < ngp * nwt_lenb; i += NT) { const int g = i / nwt_lenb, pp = i - g * nwt_lenb; yb[i] = pp < 16 * D.nwt_jb ? v[T.nwt_map[g * ng + ng - 1 - pp]] : 0.0; }
+		} else
 		for (int i = tid; i < ngp * ylen; i += NT) {
 			const int g = i / ylen, pp = i - g * ylen;
 			yv[i] = pp < ng ? v[T.nwt_map[g * ng + pp]] : 0.0;
 		}
 		// free outputs (in no nonlinear row): their vectors sit behind the groups' vectors and panels; the factor is the plan's
 		const int nfo = D.nwt_nfo, ngf = D.nwt_ngf, hbf = D.nwt_hbf, ylenf = 16 * ((ngf + 15) >> 4) + 48;
-		double *yvf = yv + (size_t)ngp * (ylen + 48 * NWT_PSTRIDE);
+		double *yvf = yv + (size_t)nwt_yall + (size_t)nwt_npan * NWT_PANEL;
+		const int wfree = tw ? 2 * ngp : ngp;   // first wave that takes a free output
 		for (int i = tid; i < nfo * ylenf; i += NT) {
 			const int f = i / ylenf, pp = i - f * ylenf;
 			yvf[i] = pp < ngf ? v[T.nwt_map[ngp * ng + f * ngf + pp]] : 0.0;
 		}
-		lds_sync();
-		if (wave < ngp) nwt_solve_wave((nwt_glb_cdp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(yv + (size_t)wave * ylen));
-		else if (wave < ngp + nfo) nwt_solve_wave((nwt_glb_cdp)(T.nwt_lf + (size_t)(wave - ngp) * ngf * (hbf + 1)), ngf, hbf, (nwt_lds_dp)(yvf + (size_t)(wave - ngp) * ylenf));
-		lds_sync();
+		auto free_solves = [&] {
+			if (wave >= wfree && wave < wfree + nfo) nwt_solve_wave((nwt_glb_cdp)(T.nwt_lf + (size_t)(wave - wfree) * ngf * (hbf + 1)), ngf, hbf, (nwt_lds_dp)(yvf + (size_t)(wave - wfree) * ylenf));
+		};
+		if (tw) {
+			__syncthreads();
+			nwt_solve_pairs(nwt_K, nwt_K + (size_t)ngp * ng * (hb + 1), ngp, nwt_q, yv, yb, free_solves);   // ends with a workgroup barrier
+		} else {
+			lds_sync();
+			if (wave < ngp) nwt_solve_wave((nwt_glb_cdp)(nwt_K + (size_t)wave * ng * (hb + 1)), ng, hb, (nwt_lds_dp)(yv + (size_t)wave * ylen));
+			else free_solves();
+			lds_sync();
+		}
 		for (int c = tid; c < n; c += NT) {
 			const int pos = T.nwt_pos[c];
 			double o = 0.0;
 			if (pos >= ngp * ng) { const int pf = pos - ngp * ng; o = yvf[(pf / ngf) * ylenf + (pf % ngf)]; }
-			else if (pos >= 0) o = yv[(pos / ng) * ylen + (pos % ng)];
+			else if (pos >= 0) {
+				const int g = pos / ng, pp = pos - g * ng;
+				o = !tw ? yv[g * ylen + pp] : (pp < ngt ? yv[g * nwt_lena + pp] : yb[g * nwt_lenb + (ng - 1 - pp)]);
+			}
 			out[c] = o;
 		}
 		if (BIG) __syncthreads(); else lds_sync();
@@ -2047,7 +2075,7 @@ template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true,
 static hipError_t launch_sqp_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
 	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS, CHM, NWT>;
-	if (NWT && (!D.nwt_on || !a.nwtw || D.nwt_cg != Family<FAM>::CG || D.nwt_go != Family<FAM>::COUPLE || (D.nwt_ngrp + D.nwt_nfo) * 64 > NT)) return hipErrorInvalidValue;
+	if (NWT && (!D.nwt_on || !a.nwtw || D.nwt_cg != Family<FAM>::CG || D.nwt_go != Family<FAM>::COUPLE || ((D.nwt_tw ? 2 : 1) * D.nwt_ngrp + D.nwt_nfo) * 64 > NT)) return hipErrorInvalidValue;
 	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
 	hipLaunchKernelGGL(kfn, dim3(a.batch), dim3(NT), L.total, a.st, D, T, L, sp, a.batch, a.lo, a.up, a.x, a.obj, a.inf, a.it, a.nf,
 	                   a.cl, a.hist, a.alw, a.vecw, a.nwtw);
