@@ -34,6 +34,13 @@ def test_band_cholesky_and_solves(unit_exe, ng, hb, spread):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("ng,hb,spread", [(462, 23, 0), (462, 23, 6), (531, 17, 6), (616, 31, 3), (128, 11, 0), (200, 29, 0), (143, 17, 0)])
+def test_two_sided_band_cholesky(unit_exe, ng, hb, spread):
+    """two waves per group (nwt_factor_pairs / nwt_solve_pairs): top sweep, reversed bottom sweep, merged separator; separator widths 32 .. 47"""
+    r = subprocess.run([unit_exe, str(ng), str(hb), str(spread), "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def _case(name):
     if name == "O":
         return cf.config_O(), cf.obstacle_bounds
