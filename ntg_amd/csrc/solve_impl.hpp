@@ -1548,9 +1548,17 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	// augmented-Lagrangian state (nonlinear rows, then linear inequality rows): multipliers and their estimates live in HBM
 	double *al_lam = al_all + (size_t)b * 2 * (ncn + D.nI), *al_t = al_lam + ncn + D.nI;
 	// diagnostic phase clock (sp.stamps): cycles spent in eval / project / history (structured Newton mode: model assembly) / W0 (Newton: factor + solve) / rest
+	// Variant builds only (-DNTG_CLOCK: tools/mkvariant2.sh; tests/tools_newton.py, tests/tools_stamps.py): compiled in, the eight 64-bit
+	// accumulators and the time base are 18 registers live across the whole kernel (the wave kernel gained 10 % when its clock went).
+#ifdef NTG_CLOCK
 	unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define NTG_STAMP(slot) do { if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot] += now_ - tlast; tlast = now_; } } while (0)
+#define NTG_CLOCK_TK(cond) ((cond) ? tk : nullptr)
 	if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
+#else
+#define NTG_STAMP(slot) do { } while (0)
+#define NTG_CLOCK_TK(cond) ((unsigned long long *)nullptr)
+#endif
 	const bool alprob = (HASCON && ncn > 0) || nI > 0;   // rows handled by the augmented-Lagrangian loop
 	ALState al{(alprob && (!NWT || sp.warm)) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
 	// structured Newton mode: band matrix / factor and the per-breakpoint blocks of this problem (HBM), flags
@@ -1600,9 +1608,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				}
 				__syncthreads();
 			}
-			if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[6] += now_ - tlast; tlast = now_; }
+			NTG_STAMP(6);
 			if (tid == 0) nwt_flag[0] = 0;
-			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), sp.stamps == 4 ? tk : nullptr);   // ends with a full barrier
+			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), NTG_CLOCK_TK(sp.stamps == 4));   // ends with a full barrier
 			NTG_STAMP(3);
 			if (D.nwt_tw) {   // two waves per group (wave uniform: every wave takes this branch)
 				const int f = nwt_factor_pairs(nwt_K, nwt_K + (size_t)ngp * ng * (hb + 1), ngp, nwt_q, panel, curv ? 1 : 0, nwt_flag);
@@ -1613,7 +1621,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				if (f && !curv) nwt_bad += f;
 			}
 			__syncthreads();
-			if (sp.stamps) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[7] += now_ - tlast; tlast = now_; }
+			NTG_STAMP(7);
 			nwt_curv = curv;
 			nwt_nfact++;
 			if (nwt_flag[0] == 0) break;
@@ -1747,7 +1755,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			// The evaluation leaves its four sums (quadrature, |g|^2, penalty, violation) as per-lane partials; the
 			// projection pass adds the slope of the line search, and ONE workgroup reduction serves all five.
 			double part[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, gdummy;
-			(void)eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gdummy, cm, al, nullptr, nullptr, (sp.stamps && !NWT) ? tk : nullptr,
+			(void)eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gdummy, cm, al, nullptr, nullptr, NTG_CLOCK_TK(sp.stamps && !NWT),
 			                                                        LIN ? &lin : nullptr, CHM != 0, part);
 			NTG_STAMP(1);
 			if (state != ST_FINAL && state != ST_REEVAL) {
@@ -2041,7 +2049,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			clambda[(size_t)b * ntot + i] = v;
 		}
+#ifdef NTG_CLOCK
 		if ((sp.stamps == 1 || sp.stamps == 4) && tid == 0) for (int i = 0; i < 8; i++) clambda[(size_t)b * ntot + i] = (double)tk[i];
+#endif
 		if (sp.stamps == 3 && tid == 0) {   // diagnostic: work counters of the structured Newton mode
 			double *o = clambda + (size_t)b * ntot;
 			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev;
@@ -2052,6 +2062,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		}
 	}
 #undef NTG_STAMP
+#undef NTG_CLOCK_TK
 	if (tid == 0) {
 		if (objective) objective[b] = Fp;
 		if (inform_out) inform_out[b] = inform;

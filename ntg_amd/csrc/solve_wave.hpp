@@ -564,11 +564,20 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3 };
 		int inform = 4, iter = 0, nfev = 0, nupd = 0, ns = 0, state = ST_INIT;
 		bool headpair = false;   // the quasi-Newton memory was restarted at an accepted step: its first pair is not in the span of the chain
+		// phase clock: variant builds only (-DNTGW_STAMPS, tools/mkvariant.sh + tests/tools_wave_stamps.py).  Compiled in, its eight 64-bit
+		// accumulators and the time base were 18 scalar registers live across the whole kernel -- the shipped FAT instance carried ~930
+		// v_writelane / v_readlane spill instructions in its major-iteration loop, most of them for these.
+#ifdef NTGW_STAMPS
 		unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 		// phase clock: the value a phase ends on is made opaque first, so that the phase's arithmetic cannot sink below the clock read
 #define NTGW_STAMPV(slot_, val_) do { if (sp.stamps) { asm volatile("" ::"v"(val_)); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tk[slot_] += now_ - tlast; tlast = now_; } } while (0)
+#else
+#define NTGW_STAMPV(slot_, val_) do { } while (0)
+#endif
 #define NTGW_STAMP(slot_) NTGW_STAMPV(slot_, x[0])
+#ifdef NTGW_STAMPS
 		if (sp.stamps) tlast = __builtin_amdgcn_s_memtime();
+#endif
 		// ---- scope check: every linear row is an equality (lower == upper), see sqp_kernel ----
 		{
 			double bad[1] = {0.0};
@@ -842,7 +851,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				if (inform != 9 && i >= nC && m > 0) v = s_tmp[64 + (i - nC)];
 				A.clambda[(size_t)b * ntot + i] = v;
 			}
+#ifdef NTGW_STAMPS
 			if (sp.stamps && lane == 0) for (int i = 0; i < 8; i++) A.clambda[(size_t)b * ntot + i] = (double)tk[i];
+#endif
 			nwt_wave_sync();
 		}
 #undef NTGW_STAMP

@@ -1,9 +1,11 @@
-"""Diagnostic (not a test): per-phase cycle shares of sqp_kernel.  NTG_AMD_STAMPS=1 python tests/tools_stamps.py"""
+"""Diagnostic (not a test): per-phase cycle shares of sqp_kernel.  NTG_AMD_STAMPS=1 python tests/tools_stamps.py
+Needs a variant library built with -DNTG_CLOCK (tools/mkvariant2.sh), passed as NTG_AMD_LIB: the shipped kernels carry no clock."""
 import os, sys
 os.environ["NTG_AMD_STAMPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ntg_amd import api, configs as cf
+api.LIB_PATH = os.environ.get("NTG_AMD_LIB", api.LIB_PATH)
 cfg = sys.argv[1] if len(sys.argv) > 1 else "M"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 if cfg == "D":

@@ -1,4 +1,5 @@
-"""Profiling one-off: phase clock of the wave kernel (NTG_AMD_STAMPS=1 -> clambda[b][0..7] = s_memtime ticks per phase)."""
+"""Profiling one-off: phase clock of the wave kernel (NTG_AMD_STAMPS=1 -> clambda[b][0..7] = s_memtime ticks per phase).
+Needs a variant library built with -DNTGW_STAMPS (tools/mkvariant.sh stamps -DNTGW_STAMPS), passed as NTG_AMD_LIB: the shipped wave kernel carries no clock."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
