@@ -1,4 +1,6 @@
-"""Summarise gpurun_out/r3prof (made by tests/tools_prof_r3.sh on the GPU box) into profiles/r03_*.  python profiles/summarize_r3.py"""
+"""Summarise gpurun_out/r3prof (made by tests/tools_prof_r3.sh on the GPU box) into profiles/r03_*.  python profiles/summarize_r3.py
+Remove gpurun_out/r3prof before the gpurun call: gpurun MERGES the box's output into the local directory, and run directories of an earlier
+call (other process ids) would be summarised instead of, or averaged with, the new ones."""
 import csv, glob, json, os, re, collections, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (locally: rm -rf gpurun_out/r3prof first -- gpurun merges into it, and stale run directories would be picked up by the summariser)
 # Round-3 profiles on the GPU box (run from the repo root through gpurun): kernel-trace statistics of the bench command, then
 # counter passes (--pmc only, one group per pass) over tests/tools_prof_r3.py.  Raw output under gpurun_out/r3prof/.
 set -o pipefail
