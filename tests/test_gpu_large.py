@@ -85,6 +85,10 @@ def test_banded_rows_entry_by_entry_with_other_flag_sets(name, l, flags):
     want = _band_from_dense(spec, ref["cJac"], p.tables()["off"])
     assert np.isclose(np.abs(want).sum(), np.abs(ref["cJac"]).sum(), rtol=1e-12)   # nothing of the dense Jacobian lies outside the band
     assert jb.shape == want.shape and rel(jb, want) <= 1e-12
+    # the same request without the dense Jacobian runs the BANDONLY instance of eval_kernel: bit-identical outputs
+    ev2 = p.eval(dev(x), 2)
+    for key in ("f", "g", "c", "jband"):
+        assert torch.equal(ev2[key], ev[key]), key
 
 
 def _kkt(spec, p, x, lo, up, lam, inf, feas_tol=1e-7):
