@@ -157,7 +157,9 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
  * run per problem, as the reference runs it per call.  d_knots [batch][ninterv+1], d_bps [batch][nbps] (device).  The combinatorial
  * structure must be the plan's: one basis class, and every breakpoint in the same knot interval as in the plan's grid (checked;
  * NTG_E_BADARG otherwise) -- the index tables stay shared, the VALUES (basis blocks, trapezoid weights, linear-constraint rows,
- * (A A')^-1, projector, with_precond != 0: the preconditioner blocks) become per problem.  Plans with linear equality rows only.
+ * (A A')^-1, projector, with_precond != 0: the preconditioner blocks) become per problem.  Nonlinear rows are allowed (free final time
+ * with obstacle / thrust / speed rows: their evaluation and the augmented-Lagrangian solve read the same per-problem tables); linear
+ * inequality rows are not (NTG_E_UNSUPPORTED).
  * Afterwards ntg_batch_eval / ntg_batch_solve of exactly `batch` problems use these grids (hessian = 2 acts as 1; ntg_batch_interp,
  * ntg_batch_mpc_shift and ntg_batch_mpc_run refuse with NTG_E_UNSUPPORTED: they work on the plan's shared grid) until ntg_plan_clear_grids(). */
 int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream);

@@ -811,7 +811,10 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	sp->memcap = std::min(sp->itlim, o->qn_memory > 0 ? o->qn_memory : 256);
 	sp->ls_maxfev = o->ls_maxfev > 0 ? o->ls_maxfev : 20;
 	sp->hessian = o->hessian; sp->fixed_iters = o->fixed_iters; sp->warm = o->warm_start ? 1 : 0;
-	if (sp->hessian == 2 && !D.nwt_on) sp->hessian = 1;   // the structured Newton mode does not apply: collocation preconditioner
+	// the structured Newton mode does not apply (or: per-problem grids -- its cost model and maps belong to the plan's grid): collocation
+	// preconditioner.  Decided HERE, once: workspace size, layout and launch all see the same mode (a switch after the workspace was sized
+	// for hessian = 2 -- no quasi-Newton history -- would let the quasi-Newton mode write its history past the end of the workspace).
+	if (sp->hessian == 2 && (!D.nwt_on || p->grid_batch)) sp->hessian = 1;
 	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
 	sp->sr = std::sqrt(r);
@@ -884,7 +887,6 @@ extern "C" const char *ntg_batch_solve_kernel(const ntg_plan *p, int batch, cons
 	if (!p) return "";
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
-	if (p->grid_batch && sp.hessian == 2) sp.hessian = 1;
 	if (sp.hessian == 1 && p->precond_ready && p->precond_singular) sp.hessian = 0;
 	NtgWavePlan w;
 	if (p->grid_batch) return "sqp_kernel";
@@ -972,7 +974,6 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	SolveParams sp; int nt;
 	resolve_params(p, o, &sp, &nt);
 	if (work_bytes < ntg_batch_workspace_bytes(p, batch, o) || !d_work) return fail(NTG_E_BADARG, "workspace too small");
-	if (p->grid_batch && sp.hessian == 2) sp.hessian = 1;
 	if (p->grid_batch && sp.hessian == 1 && !p->T.pp_n0b) return fail(NTG_E_BADARG, "per-problem grids were set without the preconditioner (with_precond = 0): solve with hessian = 0");
 	if (sp.hessian == 1) {   // built on first use, once: two threads or streams may first-solve the same plan
 		std::lock_guard<std::mutex> lk(p->precond_mutex);
@@ -1178,7 +1179,9 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 	const NtgDims &D = p->D;
 	if (D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans have one grid");
 	if (D.nclass != 1) return fail(NTG_E_UNSUPPORTED, "per-problem grids need one basis class (every output on the same knots / order / multiplicity)");
-	if (D.nI > 0 || D.ncnln > 0) return fail(NTG_E_UNSUPPORTED, "per-problem grids: plans with linear equality rows only (no inequality or nonlinear rows) so far");
+	// Nonlinear rows are fine: their evaluation reads the same per-problem tables, and the solve takes the quasi-Newton augmented-Lagrangian
+	// mode (the structured Newton step's cost model and maps are built for the plan's grid: hessian = 2 runs as hessian = 1, ntg_batch_solve).
+	if (D.nI > 0) return fail(NTG_E_UNSUPPORTED, "per-problem grids: plans without linear inequality rows so far");
 	HIPCHK(hipSetDevice(p->device));
 	ntg_plan_clear_grids(p);
 	if (with_precond) {

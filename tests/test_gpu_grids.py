@@ -114,12 +114,43 @@ def test_grid_structure_mismatch_is_refused():
         p.set_grids(dev(knots), dev(bad), with_precond=False)
     with pytest.raises(api.NtgError):
         p.set_grids(dev(knots[:, :-1]), dev(bps))
-    # a plan with nonlinear rows keeps one grid
-    q = api.Plan(cf.config_D(ninterv=8), 0)
-    sq = q.spec
-    kq, bq = grids_for(sq, 2)
-    with pytest.raises(api.NtgError, match="linear equality"):
-        q.set_grids(dev(kq), dev(bq))
+
+
+@pytest.mark.parametrize("name", ["O", "D8"])
+def test_nonlinear_rows_on_per_problem_horizons(name):
+    """free final time with nonlinear trajectory rows (obstacle avoidance; the quadrotor's thrust and speed bounds): evaluation (values,
+    gradient, residuals, dense Jacobian) and the augmented-Lagrangian solve on 8 horizons, each against the oracle built on that grid.
+    hessian = 2 is requested: with per-problem grids it runs as the collocation-preconditioned mode, on both sides."""
+    if name == "O":
+        spec = cf.config_O(); lo, up = cf.obstacle_bounds(8)
+    else:
+        spec = cf.config_D(ninterv=8); lo, up = cf.quadrotor_bounds(8)
+    nb = 8
+    knots, bps = grids_for(spec, nb, warp=0.2, seed=9)
+    if name == "D8":   # horizons in [0.9, 1.3] x the plan's: shorter flights violate the thrust bound outright
+        knots, bps = grids_for(spec, nb, warp=0.1, seed=9)
+        s0 = knots[:, :1]; sc = (0.9 + 0.4 * (knots[:, -1:] - s0 - 0.6 * 5.0) / 5.0)
+        knots = s0 + (knots - s0) / (knots[:, -1:] - s0) * 5.0 * sc; bps = s0 + (bps - s0) / (bps[:, -1:] - s0) * 5.0 * sc
+    p = api.Plan(spec, 0)
+    p.set_grids(dev(knots), dev(bps), with_precond=True)
+    x = np.random.default_rng(4).normal(size=(nb, spec.nC)) * 0.3 + 1.0
+    ev = p.eval(dev(x), 2, want_dense_jac=True)
+    for b in range(nb):
+        ref = orc.eval_batch(spec_on(spec, knots[b], bps[b]), x[b:b + 1], 2)
+        assert rel(ev["f"][b:b + 1].cpu().numpy(), ref["f"]) <= 1e-12 and rel(ev["g"][b].cpu().numpy(), ref["g"][0]) <= 1e-12
+        assert rel(ev["c"][b].cpu().numpy(), ref["c"][0]) <= 1e-12 and rel(ev["cJac"][b].cpu().numpy(), ref["cJac"][0]) <= 1e-12
+    xs = dev(np.ones((nb, spec.nC)))
+    out = p.solve(dev(lo), dev(up), xs, api.default_opts(hessian=2))
+    torch.cuda.synchronize()
+    inform = out["inform"].cpu().numpy(); obj = out["objective"].cpu().numpy()
+    assert np.isin(inform, (0, 1)).all(), inform
+    objs = []
+    for b in range(nb):
+        ref = orc.solve_one(spec_on(spec, knots[b], bps[b]), lo[b], up[b], np.ones(spec.nC), orc.default_opts(hessian=1))
+        assert ref["inform"] in (0, 1)
+        assert abs(obj[b] - ref["objective"]) <= 2e-5 * max(1.0, abs(ref["objective"])), (b, obj[b], ref["objective"])   # the quasi-Newton mode's accuracy (tests/test_gpu_large.py)
+        objs.append(ref["objective"])
+    assert np.ptp(objs) > 1e-3
 
 
 def test_mpc_shift_refuses_per_problem_grids():
