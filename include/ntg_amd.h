@@ -160,8 +160,9 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
  * (A A')^-1, projector, with_precond != 0: the preconditioner blocks) become per problem.  Nonlinear rows are allowed (free final time
  * with obstacle / thrust / speed rows: their evaluation and the augmented-Lagrangian solve read the same per-problem tables); linear
  * inequality rows are not (NTG_E_UNSUPPORTED).
- * Afterwards ntg_batch_eval / ntg_batch_solve of exactly `batch` problems use these grids (hessian = 2 acts as 1; ntg_batch_interp,
- * ntg_batch_mpc_shift and ntg_batch_mpc_run refuse with NTG_E_UNSUPPORTED: they work on the plan's shared grid) until ntg_plan_clear_grids(). */
+ * Afterwards ntg_batch_eval / ntg_batch_solve / ntg_batch_interp of exactly `batch` problems use these grids (hessian = 2 acts as 1;
+ * ntg_batch_interp then takes d_times as [batch][ntimes]: every problem at its own times; ntg_batch_mpc_shift and ntg_batch_mpc_run refuse
+ * with NTG_E_UNSUPPORTED: they work on the plan's shared grid) until ntg_plan_clear_grids(). */
 int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream);
 void ntg_plan_clear_grids(ntg_plan *p);
 

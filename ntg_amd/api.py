@@ -221,11 +221,15 @@ class Plan:
         return out
 
     def interp(self, x, times):
-        """Flat flag of every problem at the given times: x [batch, nC], times [ntimes] -> [batch, ntimes, nz]."""
+        """Flat flag of every problem at the given times: x [batch, nC], times [ntimes] -> [batch, ntimes, nz].
+        After set_grids: times [batch, ntimes], every problem at its own times on its own knots."""
         import torch
         assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous() and times.is_cuda and times.dtype == torch.float64
-        z = torch.empty((x.shape[0], times.numel(), self.spec.nz), dtype=torch.float64, device=x.device)
-        _check(lib().ntg_batch_interp(self.h, x.shape[0], _ptr(x), times.numel(), _ptr(times.contiguous()), _ptr(z), self._stream()))
+        if times.dim() == 2 and times.shape[0] != x.shape[0]:
+            raise NtgError("per-problem times must be [batch, ntimes]")
+        ntimes = times.shape[-1]
+        z = torch.empty((x.shape[0], ntimes, self.spec.nz), dtype=torch.float64, device=x.device)
+        _check(lib().ntg_batch_interp(self.h, x.shape[0], _ptr(x), ntimes, _ptr(times.contiguous()), _ptr(z), self._stream()))
         return z
 
     def set_grids(self, knots, bps, with_precond: bool = True):

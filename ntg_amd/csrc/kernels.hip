@@ -493,8 +493,9 @@ hipError_t ntg_launch_mpc_shift_lambda(const NtgDims &D, int batch, int sbp, dou
 // SplineInterp (colloc.c:449-484) for a batch: flat flag of every problem at ntimes shared points in time.
 // tblk [class][t][q][r] and toff [class][t] come from basis_kernel run on the times instead of the breakpoints;
 // one thread per (problem, time, flag entry), consecutive threads = consecutive flag entries of one time.
+// Per-problem grids: every problem has its own times, basis blocks and offsets (pp != 0: tblk [batch][t][q][r], toff [batch][t]; one class).
 __global__ void interp_kernel(NtgDims D, int batch, int ntimes, const double *__restrict__ x, const double *__restrict__ tblk,
-                              const int *__restrict__ toff, const int *__restrict__ tblk_base, double *__restrict__ z)
+                              const int *__restrict__ toff, const int *__restrict__ tblk_base, double *__restrict__ z, int pp)
 {
 	const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
 	const long long total = (long long)batch * ntimes * D.nz;
@@ -503,19 +504,19 @@ __global__ void interp_kernel(NtgDims D, int batch, int ntimes, const double *__
 	int o = 0;
 	while (o + 1 < D.nout && D.iz[o + 1] <= v) o++;
 	const int r = v - D.iz[o], c = D.cls[o], kk = D.order[o], d = D.d[o];
-	const double *blk = tblk + tblk_base[c] + ((size_t)t * kk) * d;
-	const double *cx = x + (size_t)b * D.nC + D.iC[o] + toff[(size_t)c * ntimes + t];
+	const double *blk = tblk + (pp ? (size_t)b * ntimes * kk * d : (size_t)tblk_base[c]) + ((size_t)t * kk) * d;
+	const double *cx = x + (size_t)b * D.nC + D.iC[o] + toff[(pp ? (size_t)b : (size_t)c) * ntimes + t];
 	double acc = 0.0;
 	for (int q = 0; q < kk; q++) acc += blk[q * d + r] * cx[q];   // colloc.c:476-481
 	z[idx] = acc;
 }
 
 hipError_t ntg_launch_interp(const NtgDims &D, int batch, int ntimes, const double *x, const double *tblk, const int *toff,
-                             const int *tblk_base, double *z, hipStream_t st)
+                             const int *tblk_base, double *z, hipStream_t st, int pp)
 {
 	const long long total = (long long)batch * ntimes * D.nz;
 	if (total == 0) return hipSuccess;
-	hipLaunchKernelGGL(interp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, D, batch, ntimes, x, tblk, toff, tblk_base, z);
+	hipLaunchKernelGGL(interp_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, D, batch, ntimes, x, tblk, toff, tblk_base, z, pp);
 	return hipGetLastError();
 }
 

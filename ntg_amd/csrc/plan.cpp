@@ -1068,10 +1068,23 @@ extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x,
 	if (!p) return fail(NTG_E_BADARG, "null plan");
 	if (batch <= 0 || ntimes <= 0) return 0;
 	if (!d_x || !d_times || !d_z) return fail(NTG_E_BADARG, "null argument");
-	if (p->grid_batch) return fail(NTG_E_UNSUPPORTED, "ntg_batch_interp evaluates on the plan's shared knots: clear the per-problem grids first");
+	if (p->grid_batch && batch != p->grid_batch) return fail(NTG_E_BADARG, "the plan carries per-problem grids for another batch size");
 	HIPCHK(hipSetDevice(p->device));
 	const NtgDims &D = p->D;
 	hipStream_t st = (hipStream_t)stream;
+	if (p->grid_batch) {
+		// per-problem grids: d_times is [batch][ntimes] -- every problem at its own times, on its own knots (one basis class)
+		double *d_tb = nullptr; int *d_to = nullptr;
+		const size_t per = (size_t)ntimes * D.cls_k[0] * D.cls_d[0];
+		hipError_t e2 = hipMallocAsync((void **)&d_tb, (size_t)batch * per * 8, st);
+		if (e2 == hipSuccess) e2 = hipMallocAsync((void **)&d_to, (size_t)batch * ntimes * 4, st);
+		if (e2 == hipSuccess) e2 = ntg_launch_basis(batch, D.cls_l[0], D.cls_k[0], D.cls_m[0], D.cls_d[0], ntimes, p->d_grid_knots, d_times, D.cls_l[0] + 1, ntimes, d_tb, d_to, st);
+		if (e2 == hipSuccess) e2 = ntg_launch_interp(D, batch, ntimes, d_x, d_tb, d_to, nullptr, d_z, st, 1);
+		if (d_tb) (void)hipFreeAsync(d_tb, st);
+		if (d_to) (void)hipFreeAsync(d_to, st);
+		if (e2 != hipSuccess) return fail(NTG_E_HIP, hipGetErrorString(e2));
+		return 0;
+	}
 	// basis of every class at the requested times (the same kernel that builds the collocation tables), stream ordered
 	double *d_tblk = nullptr; int *d_toff = nullptr, *d_base = nullptr;
 	std::vector<int> base(D.nclass);
@@ -1169,7 +1182,7 @@ extern "C" void ntg_plan_clear_grids(ntg_plan *p)
 	for (void *q : p->grid_owned) hipFree(q);
 	p->grid_owned.clear();
 	p->T = p->T_shared;
-	p->grid_batch = 0;
+	p->grid_batch = 0; p->d_grid_knots = nullptr;
 }
 
 extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream)
@@ -1216,9 +1229,9 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 	}
 	// 1. basis blocks and offsets of every problem: one launch of basis_kernel (bsplvd at every collocation point, colloc.c:95-111)
 	double *d_blk = nullptr; int *d_off = nullptr, *d_err = nullptr;
-	double *d_rowv = nullptr, *d_bpsc = nullptr, *d_csr = nullptr, *d_csc = nullptr, *d_sinv = nullptr, *d_q = nullptr, *d_n0b = nullptr;
+	double *d_rowv = nullptr, *d_bpsc = nullptr, *d_csr = nullptr, *d_csc = nullptr, *d_sinv = nullptr, *d_q = nullptr, *d_n0b = nullptr, *d_knc = nullptr;
 	auto fail_free = [&](int code, const std::string &msg) {
-		for (void *q : {(void *)d_blk, (void *)d_off, (void *)d_err, (void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b}) if (q) hipFree(q);
+		for (void *q : {(void *)d_blk, (void *)d_off, (void *)d_err, (void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b, (void *)d_knc}) if (q) hipFree(q);
 		return fail(code, msg);
 	};
 	const size_t n0b_sz = with_precond ? (size_t)p->T.n0b_nblk * p->T.n0b_sp * p->T.n0b_n + 16 : 0;
@@ -1226,11 +1239,12 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 	    hipMalloc((void **)&d_err, 16) != hipSuccess || hipMalloc((void **)&d_rowv, (size_t)batch * row_total * 8) != hipSuccess ||
 	    hipMalloc((void **)&d_bpsc, (size_t)batch * P * 8) != hipSuccess || hipMalloc((void **)&d_csr, (size_t)batch * lin_nnz * 8) != hipSuccess ||
 	    hipMalloc((void **)&d_csc, (size_t)batch * lin_nnz * 8) != hipSuccess || hipMalloc((void **)&d_sinv, (size_t)batch * sinv_nnz * 8) != hipSuccess ||
-	    hipMalloc((void **)&d_q, (size_t)batch * std::max(qn, 1) * 8) != hipSuccess ||
+	    hipMalloc((void **)&d_q, (size_t)batch * std::max(qn, 1) * 8) != hipSuccess || hipMalloc((void **)&d_knc, (size_t)batch * (l + 1) * 8) != hipSuccess ||
 	    (with_precond && hipMalloc((void **)&d_n0b, (size_t)batch * n0b_sz * 8) != hipSuccess)) return fail_free(NTG_E_HIP, "hipMalloc (per-problem grids)");
 	hipError_t e = hipMemsetAsync(d_err, 0, 16, st);
 	if (e == hipSuccess) e = hipMemsetAsync(d_rowv, 0, (size_t)batch * row_total * 8, st);
 	if (e == hipSuccess) e = hipMemcpyAsync(d_bpsc, d_bps, (size_t)batch * P * 8, hipMemcpyDeviceToDevice, st);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_knc, d_knots, (size_t)batch * (l + 1) * 8, hipMemcpyDeviceToDevice, st);   // kept: ntg_batch_interp evaluates the basis at other times
 	if (e == hipSuccess) e = ntg_launch_basis(batch, l, k, D.cls_m[0], d, P, d_knots, d_bps, l + 1, P, d_blk, d_off, st);
 	// 2. channel rows in the kernels' layout + the structure check (every breakpoint in the plan's knot interval); 3. the algebra of the
 	//    linear rows -- A_E on the plan's patterns, (A A')^-1, Q -- one wavefront per problem, all on the device (grids.hip)
@@ -1274,7 +1288,8 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 	hipFree(d_blk); hipFree(d_off); hipFree(d_err);
 	// 5. the kernels add b * stride to the value pointers (NtgTables::pp_*)
 	p->T_shared = p->T;
-	for (void *q : {(void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b}) if (q) p->grid_owned.push_back(q);
+	for (void *q : {(void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b, (void *)d_knc}) if (q) p->grid_owned.push_back(q);
+	p->d_grid_knots = d_knc;
 	NtgTables &T = p->T;
 	T.rowv = d_rowv; T.pp_rowv = row_total;
 	T.bps = d_bpsc; T.pp_bps = P;

@@ -7,6 +7,7 @@
 
 struct ntg_plan {
 	int device = 0;
+	double *d_grid_knots = nullptr;   // per-problem grids: device copy of the knots [grid_batch][ninterv + 1] (ntg_batch_interp)
 	mutable int ncu = 0;                        // compute units of the device (queried on first use)
 	NtgDims D;
 	NtgTables T;
@@ -51,7 +52,7 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,
                             long long knots_stride, long long bps_stride, double *blk, int *off, hipStream_t st);
 hipError_t ntg_launch_interp(const NtgDims &D, int batch, int ntimes, const double *x, const double *tblk, const int *toff,
-                             const int *tblk_base, double *z, hipStream_t st);
+                             const int *tblk_base, double *z, hipStream_t st, int pp = 0);
 hipError_t ntg_launch_kincar_reverse(long long nsamp, int nz, int ncars, double wheelbase, int reverse_gear, const double *z, double *out, hipStream_t st);
 hipError_t ntg_launch_count_notconv(int batch, const int *inform, int *count, hipStream_t st);
 hipError_t ntg_launch_linrows(const NtgDims &D, const NtgTables &T, const double *lic, const double *ltc,

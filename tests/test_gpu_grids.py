@@ -102,6 +102,40 @@ def test_solve_on_per_problem_horizons(name, ncars, hessian):
     assert np.ptp(objs) > 1e-3
 
 
+def test_interp_on_per_problem_grids():
+    """ntg_batch_interp after ntg_plan_set_grids: every problem at its own times on its own knots == SplineInterp (colloc.c:449-484,
+    restated in the oracle) with that problem's knots; a shared time vector is refused (shape), a batch of another size too"""
+    import ctypes as C
+    spec = cf.config_M(); nb = 6
+    knots, bps = grids_for(spec, nb, warp=0.3, seed=3)
+    p = api.Plan(spec, 0)
+    p.set_grids(dev(knots), dev(bps), with_precond=False)
+    rng = np.random.default_rng(8)
+    x = rng.normal(size=(nb, spec.nC))
+    nt = 17
+    times = np.stack([np.concatenate([[knots[b, 0], knots[b, -1]], knots[b, 1:4], rng.uniform(knots[b, 0], knots[b, -1], nt - 5)]) for b in range(nb)])
+    z = p.interp(dev(x), dev(times)).cpu().numpy()
+    assert z.shape == (nb, nt, spec.nz)
+    dp = C.POINTER(C.c_double)
+    iz = np.concatenate([[0], np.cumsum(spec.maxderiv)]); iC = np.concatenate([[0], np.cumsum(spec.ncoef)])
+    ref = np.zeros_like(z)
+    for b in range(nb):
+        kn = np.ascontiguousarray(knots[b])
+        for o in range(spec.nout):
+            co = np.ascontiguousarray(x[b, iC[o]:iC[o + 1]])
+            for ti in range(nt):
+                f = np.zeros(spec.maxderiv[o])
+                orc.lib().orc_spline_interp(f.ctypes.data_as(dp), C.c_double(float(times[b, ti])), kn.ctypes.data_as(dp), int(spec.kninterv[o]),
+                                            co.ctypes.data_as(dp), int(spec.ncoef[o]), int(spec.order[o]), int(spec.mult[o]), int(spec.maxderiv[o]))
+                ref[b, ti, iz[o]:iz[o + 1]] = f
+    assert rel(z, ref) <= 1e-13
+    with pytest.raises(api.NtgError):
+        p.interp(dev(x[:3]), dev(times[:3]))
+    p.clear_grids()
+    z0 = p.interp(dev(x), dev(times[0])).cpu().numpy()          # back on the plan's knots: one shared time vector
+    assert z0.shape == (nb, nt, spec.nz)
+
+
 def test_grid_structure_mismatch_is_refused():
     spec = cf.config_B()
     nb = 4
