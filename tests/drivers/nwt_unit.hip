@@ -76,7 +76,11 @@ int main(int argc, char **argv)
 	x = rhs;
 	for (int i = 0; i < ng; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= L[(size_t)i * ng + k] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
 	for (int i = ng - 1; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < ng; k++) s -= L[(size_t)k * ng + i] * x[k]; x[i] = s / L[(size_t)i * ng + i]; }
-	if (argc > 4 && atoi(argv[4]) == 2) {   // two-sided: nwt_unit ng hb spread 2
+	// nwt_unit ng hb spread 3 ROW: the matrix is made indefinite at ROW (strict factorisations must report it: exit 0 when BOTH the one-sided
+	// and the two-sided factorisation do, whichever part of the two-sided split ROW falls in)
+	const int indef_row = (argc > 5 && atoi(argv[4]) == 3) ? atoi(argv[5]) : -1;
+	if (indef_row >= 0 && indef_row < ng) K[(size_t)indef_row * ld + hb] = -fabs(K[(size_t)indef_row * ld + hb]);
+	if (argc > 4 && (atoi(argv[4]) == 2 || atoi(argv[4]) == 3)) {   // two-sided: nwt_unit ng hb spread 2
 		NwtPair q; q.n = ng; q.hb = hb; const int jt = (ng - 32) / 16; q.ja = (jt + 1) / 2; q.jb = jt / 2;
 		const int sep = ng - 16 * (q.ja + q.jb), ngt = 16 * q.ja + sep, brows = 16 * q.jb + 48;
 		std::vector<double> Kt((size_t)ng * ld, 0.0), Kb((size_t)brows * ld, 0.0);
@@ -98,7 +102,19 @@ int main(int argc, char **argv)
 		for (int i = 0; i < ng; i++) { err2 = fmax(err2, fabs(y2[i] - x[i])); nx2 = fmax(nx2, fabs(x[i])); }
 		printf("  two-sided: ja %d jb %d sep %d; clock ticks: factor %lld, solve %lld\n", q.ja, q.jb, sep, hc2[0], hc2[1]);
 		printf("ng %d hb %d fail %d: max rel err two-sided factor-solve: %.3e\n", ng, hb, fail2, err2 / nx2);
-		return (fail2 == 0 && err2 / nx2 < 1e-9) ? 0 : 1;
+		if (indef_row < 0) return (fail2 == 0 && err2 / nx2 < 1e-9) ? 0 : 1;
+		if (fail2 == 0) { printf("two-sided factorisation did not report the indefinite matrix\n"); return 1; }
+		// ... and the one-sided routine on the same matrix
+		double *dK1, *dy1; int *df1; long long *dc1;
+		hipMalloc(&dK1, K.size() * 8); hipMalloc(&dy1, ng * 8); hipMalloc(&df1, 4); hipMalloc(&dc1, 16);
+		hipMemcpy(dK1, K.data(), K.size() * 8, hipMemcpyHostToDevice); hipMemcpy(dy1, rhs.data(), ng * 8, hipMemcpyHostToDevice);
+		const size_t lds1 = (size_t)(16 * ((ng + 15) / 16) + 48 + 48 * NWT_PSTRIDE) * 8;
+		hipLaunchKernelGGL(unit_kernel, dim3(1), dim3(64), lds1, 0, dK1, ng, hb, dy1, df1, dc1);
+		int fail1 = 0;
+		if (hipDeviceSynchronize() != hipSuccess) { printf("kernel failed\n"); return 2; }
+		hipMemcpy(&fail1, df1, 4, hipMemcpyDeviceToHost);
+		printf("one-sided fail %d\n", fail1);
+		return fail1 != 0 ? 0 : 1;
 	}
 	double *dK, *dy; int *df; long long *dc, hc[2] = {0, 0};
 	hipMalloc(&dK, K.size() * 8); hipMalloc(&dy, ng * 8); hipMalloc(&df, 4); hipMalloc(&dc, 16);

@@ -41,6 +41,14 @@ def test_two_sided_band_cholesky(unit_exe, ng, hb, spread):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("row", [5, 200, 215, 240, 300, 461])   # top part, last top block, separator (208 .. 253), bottom part, last row
+def test_indefinite_matrix_is_reported_by_both_factorisations(unit_exe, row):
+    """a strict factorisation (the curvature attempt of a refresh) must report a non-positive pivot wherever it sits: in the top sweep,
+    the reversed bottom sweep or the merged separator of the two-sided form, and in the one-sided routine"""
+    r = subprocess.run([unit_exe, "462", "23", "0", "3", str(row)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def _case(name):
     if name == "O":
         return cf.config_O(), cf.obstacle_bounds
