@@ -13,10 +13,10 @@ using namespace ntgw;
 
 namespace {
 
-template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false, int NINT = 20>
+template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false, int NINT = 20, bool PPG = false>
 hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
 {
-	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, NINT, NWV, MINW, NREG, NLDS, HESS, XLDS>;
+	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, NINT, NWV, MINW, NREG, NLDS, HESS, XLDS, PPG>;
 	WaveArgs A;
 	A.batch = a.batch; A.cap = w.cap; A.lower = a.lo; A.upper = a.up; A.xio = a.x; A.objective = a.obj; A.inform = a.inf; A.iters = a.it;
 	A.nfev = a.nf; A.clambda = a.cl; A.hist = a.hist; A.counter = a.counter; A.hbm_slots = w.hbm_slots;
@@ -28,9 +28,10 @@ hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &s
 }
 
 // LDS bytes of a workgroup (xlds: with the preconditioner blocks and the sparse linear operator staged)
-size_t wave_lds(const NtgDims &D, const NtgTables &T, int hessian, int nwv, int cap, int nlds, int epl, bool xlds = false)
+size_t wave_lds(const NtgDims &D, const NtgTables &T, int hessian, int nwv, int cap, int nlds, int epl, bool xlds = false, bool ppg = false)
 {
-	size_t tab = (size_t)(D.ig_n == 16 ? wave_tab_doubles<1, 6, 16>() : wave_tab_doubles<1, 6, 20>()) * 8 + (size_t)D.q_nt * 6 * 8 + (size_t)D.q_nt * 8 * 4;
+	// value tables (basis, weights, projector values): one copy, or one per wave with per-problem grids; the projector's indices once
+	size_t tab = (size_t)(ppg ? nwv : 1) * ((size_t)(D.ig_n == 16 ? wave_tab_doubles<1, 6, 16>() : wave_tab_doubles<1, 6, 20>()) * 8 + (size_t)D.q_nt * 6 * 8) + (size_t)D.q_nt * 8 * 4;
 	if (xlds) {
 		const int lnz = std::max(D.lin_nnz, 1), snz = std::max(D.sinv_nnz, 1);
 		tab += (size_t)(hessian == 1 ? T.n0b_nblk * 64 * 64 : 0) * 8 + (size_t)(2 * lnz + snz) * 8 + (size_t)((2 * (D.mE + 1) + (D.nC + 1) + 2 * lnz + snz + 3) & ~3) * 4;
@@ -44,7 +45,7 @@ size_t wave_lds(const NtgDims &D, const NtgTables &T, int hessian, int nwv, int 
 #ifndef NTGW_LEAN_MINW
 #define NTGW_LEAN_MINW 2
 #endif
-constexpr int FAT_NLDS = 10, FAT_NLDS2 = 6, LEAN_NLDS = NTGW_LEAN_NLDS, LEAN_MINW = NTGW_LEAN_MINW;   // FAT_NLDS2: the instance for long chains (their scalars take more of the LDS)
+constexpr int FAT_NLDS = 10, FAT_NLDS2 = 6, PPG_NLDS = 2, LEAN_NLDS = NTGW_LEAN_NLDS, LEAN_MINW = NTGW_LEAN_MINW;   // PPG_NLDS: four copies of the value tables leave room for two chain slots per wave next to a full-length memory's scalars   // FAT_NLDS2: the instance for long chains (their scalars take more of the LDS)
 
 }   // namespace
 
@@ -58,13 +59,15 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 	if (!wave_match(D, T, sp, 4, 3, 6, opl, 20) && !(D.nout == 4 && wave_match(D, T, sp, 4, 3, 6, opl, 16))) return false;
 	const int epl = opl * 3;
 	w->cap = std::min(sp.memcap, sp.itlim) + 4;
-	w->fat = (sp.hessian != 1 && !getenv("NTG_AMD_WAVE_LEAN")) ? 1 : 0;
+	w->ppg = (T.pp_rowv || T.pp_bps || T.pp_q) ? 1 : 0;   // per-problem grids: the FAT instance with wave-private tables (wave_match: no preconditioner)
+	w->fat = ((sp.hessian != 1 && !getenv("NTG_AMD_WAVE_LEAN")) || w->ppg) ? 1 : 0;
 	w->nwv = 4;
 	if (w->fat) {
 		const int nreg = (256 - NTGW_ABASE) / (2 * epl);
-		w->nlds = FAT_NLDS;
-		w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl);
-		if (w->lds > 160 * 1024) { w->nlds = FAT_NLDS2; w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl); }
+		w->nlds = w->ppg ? PPG_NLDS : FAT_NLDS;
+		w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl, false, w->ppg != 0);
+		if (w->lds > 160 * 1024 && !w->ppg) { w->nlds = FAT_NLDS2; w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl); }
+		if (w->lds > 160 * 1024 && w->ppg) return false;
 		if (w->lds > 160 * 1024) w->fat = 0;
 		else {
 			w->hbm_slots = std::max(0, w->cap - nreg - w->nlds);
@@ -97,6 +100,12 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 		if (w.nwv == 8 && xl16) return launch_one<4, 2, 8, LEAN_MINW, 0, LEAN_NLDS, true, true, 16>(D, T, sp, a, w);
 		if (xl16) return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, true, 16>(D, T, sp, a, w);
 		return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, false, 16>(D, T, sp, a, w);
+	}
+	if (w.ppg) {   // per-problem grids
+		if (!w.fat || w.nlds != PPG_NLDS) return hipErrorInvalidValue;
+		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
+		return launch_one<6, 2, 4, 1, R6, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
 	}
 	if (w.fat && w.nlds == FAT_NLDS) {
 		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, FAT_NLDS, false>(D, T, sp, a, w);

@@ -876,7 +876,6 @@ static int plan_ncu(const ntg_plan *p)
 // The answer depends on the options as ntg_batch_solve will see them (the preconditioner may turn out singular: hessian 1 -> 0).
 static bool wave_takes(const ntg_plan *p, const SolveParams &sp, int batch, NtgWavePlan *w)
 {
-	if (p->grid_batch) return false;
 	if (sp.hessian == 1 && !p->precond_ready) return false;   // decided after the preconditioner exists (its block form is part of the test)
 	return ntg_wave_plan(p->D, p->T, sp, batch, plan_ncu(p), w);
 }
@@ -889,7 +888,6 @@ extern "C" const char *ntg_batch_solve_kernel(const ntg_plan *p, int batch, cons
 	resolve_params(p, o, &sp, &nt);
 	if (sp.hessian == 1 && p->precond_ready && p->precond_singular) sp.hessian = 0;
 	NtgWavePlan w;
-	if (p->grid_batch) return "sqp_kernel";
 	NtgTables T2 = p->T;
 	if (sp.hessian == 1 && !p->precond_ready) { T2.n0b = (const double *)1; T2.n0b_n = p->D.ncoef[0]; }   // not built yet: assume the block form
 	return ntg_wave_plan(p->D, T2, sp, batch, plan_ncu(p), &w) ? "sqp_wave_kernel" : "sqp_kernel";
@@ -908,7 +906,7 @@ extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, con
 	for (int h = 0; h < 2; h++) {
 		SolveParams s2 = sp; s2.hessian = h;
 		NtgWavePlan w;
-		if (!p->grid_batch && ntg_wave_plan(p->D, p->T, s2, batch, plan_ncu(p), &w)) dbl = std::max(dbl, w.hist_doubles);
+		if (ntg_wave_plan(p->D, p->T, s2, batch, plan_ncu(p), &w)) dbl = std::max(dbl, w.hist_doubles);
 		else if (h == 1 && !p->grid_batch && !p->precond_ready) {
 			// the preconditioner is not built yet: assume the wave kernel will take the solve (same shape test without the block form)
 			NtgTables T2 = p->T; T2.n0b = (const double *)1; T2.n0b_n = p->D.ncoef[0];

@@ -117,7 +117,9 @@ __host__ __device__ inline int wave_priv_doubles(int nC, int cap, int nlds, int 
 
 // XLDS: the preconditioner blocks W_b (zero padded to 64 x 64) and the sparse operator of the linear rows (A as CSR and CSC, (A A')^-1 as
 // CSR) are staged in the workgroup's LDS: the instance of short solves, where their L2 latency is a visible share of a problem
-template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false>
+// PPG: per-problem grids (ntg_plan_set_grids) -- every wave keeps its OWN copy of the value tables (basis values, node weights, projector
+// values) and restages it for each problem it takes; the index tables stay shared.  Without the preconditioner only (hessian != 1).
+template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false, bool PPG = false>
 __global__ void __launch_bounds__(64 * NWV, MINW)
 sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 {
@@ -131,11 +133,13 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int P = D.P, m = D.mE, cap = A.cap, capp = (cap + 3) & ~3, qw = D.q_w;
 	// ---- shared tables ----
-	double *s_bt = (double *)smem_raw;                      // [NCH][SMAX][K][NL] basis values of the CHM channels per interval slot; column NINT = 0
+	static_assert(!(PPG && (XLDS || HESS)), "per-problem grids: the instance without the preconditioner and with the linear operator in HBM");
+	const int tabw = NCH * SMAX * K * NL + 2 * SMAX * NL + D.q_nt * 6;   // doubles of one copy of the value tables (one per workgroup; PPG: one per wave)
+	double *s_bt = (double *)smem_raw + (PPG ? wave * tabw : 0);   // [NCH][SMAX][K][NL] basis values of the CHM channels per interval slot; column NINT = 0
 	double *s_wt = s_bt + NCH * SMAX * K * NL;              // [SMAX][NL] trapezoid node weights
 	double *s_dt = s_wt + SMAX * NL;                        // [SMAX][NL] interval lengths
 	double *s_qv = s_dt + SMAX * NL;                        // [q_nt][6] projector rows (ELL)
-	int *s_qc = (int *)(s_qv + D.q_nt * 6);                // [q_nt][8]
+	int *s_qc = (int *)((double *)smem_raw + (PPG ? NWV : 1) * tabw);   // [q_nt][8]
 	// XLDS extras: [nblk][64][64] preconditioner blocks; csr_ptr[m+1] csr_col[nnz] csc_ptr[nC+1] csc_row[nnz] sinv_ptr[m+1] sinv_col[snz] (ints),
 	// csr_val[nnz] csc_val[nnz] sinv_val[snz] (doubles)
 	double *s_w0 = (double *)(s_qc + D.q_nt * 8);
@@ -160,23 +164,27 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			for (int e = tid; e <= nC; e += 64 * NWV) s_li[(m + 1) + lnz + e] = T.csc_ptr[e];
 		}
 	}
-	for (int e = tid; e < NCH * SMAX * K * NL; e += 64 * NWV) {
-		const int t = e % NL, q = (e / NL) % K, s2 = (e / (NL * K)) % SMAX, ch = e / (NL * K * SMAX);
-		int r = 0, seen = -1;
-		for (int rr = 0; rr < DM; rr++) if ((CHM >> rr) & 1) { seen++; if (seen == ch) r = rr; }
-		const int i = t < NINT ? D.igb[t] + s2 : P;
-		s_bt[e] = (t < NINT && i < D.igb[t + 1]) ? T.rowv[D.ch_row0[r] + q * P + i] : 0.0;
-	}
-	for (int e = tid; e < SMAX * NL; e += 64 * NWV) {
-		const int t = e % NL, s2 = e / NL, i = t < NINT ? D.igb[t] + s2 : P;
-		double w = 0.0, dt = 0.0;
-		if (t < NINT && i < D.igb[t + 1]) {   // trapezoid weight of node i: integrator.c:21-24 regrouped per node
-			if (i > 0) w += (T.bps[i] - T.bps[i - 1]) / 2;
-			if (i < P - 1) { w += (T.bps[i + 1] - T.bps[i]) / 2; dt = T.bps[i + 1] - T.bps[i]; }
+	// the value tables of one grid: by the whole workgroup once (shared grid), or by a wave for the problem it is about to solve (PPG)
+	auto stage_values = [&](const double *rowv, const double *bps, const double *qval, int t0, int nth) {
+		for (int e = t0; e < NCH * SMAX * K * NL; e += nth) {
+			const int t = e % NL, q = (e / NL) % K, s2 = (e / (NL * K)) % SMAX, ch = e / (NL * K * SMAX);
+			int r = 0, seen = -1;
+			for (int rr = 0; rr < DM; rr++) if ((CHM >> rr) & 1) { seen++; if (seen == ch) r = rr; }
+			const int i = t < NINT ? D.igb[t] + s2 : P;
+			s_bt[e] = (t < NINT && i < D.igb[t + 1]) ? rowv[D.ch_row0[r] + q * P + i] : 0.0;
 		}
-		s_wt[e] = w; s_dt[e] = dt;
-	}
-	for (int e = tid; e < D.q_nt * 6; e += 64 * NWV) { const int r = e / 6, w2 = e - 6 * r; s_qv[e] = w2 < qw ? T.q_val[r * qw + w2] : 0.0; }   // rows padded to 6 entries
+		for (int e = t0; e < SMAX * NL; e += nth) {
+			const int t = e % NL, s2 = e / NL, i = t < NINT ? D.igb[t] + s2 : P;
+			double w = 0.0, dt = 0.0;
+			if (t < NINT && i < D.igb[t + 1]) {   // trapezoid weight of node i: integrator.c:21-24 regrouped per node
+				if (i > 0) w += (bps[i] - bps[i - 1]) / 2;
+				if (i < P - 1) { w += (bps[i + 1] - bps[i]) / 2; dt = bps[i + 1] - bps[i]; }
+			}
+			s_wt[e] = w; s_dt[e] = dt;
+		}
+		for (int e = t0; e < D.q_nt * 6; e += nth) { const int r = e / 6, w2 = e - 6 * r; s_qv[e] = w2 < qw ? qval[r * qw + w2] : 0.0; }   // rows padded to 6 entries
+	};
+	if (!PPG) stage_values(T.rowv, T.bps, T.q_val, tid, 64 * NWV);
 	for (int e = tid; e < D.q_nt * 8; e += 64 * NWV) { const int r = e / 8, w2 = e - 8 * r; s_qc[e] = w2 < qw ? T.q_col[r * qw + w2] : 0; }     // ... and to 8 indices
 	__syncthreads();   // the only workgroup barrier: from here on the waves are independent
 	// ---- this wave's private LDS ----
@@ -550,6 +558,12 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		b = __builtin_amdgcn_readfirstlane(b);
 		if (b >= A.batch) break;
 		const double *lo = A.lower + (size_t)b * D.nbounds, *up = A.upper + (size_t)b * D.nbounds;
+		if constexpr (PPG) {   // this problem's grid: values into the wave's own tables, the linear operator's values by pointer
+			stage_values(T.rowv + (size_t)b * T.pp_rowv, T.bps + (size_t)b * T.pp_bps, T.q_val + (size_t)b * T.pp_q, lane, 64);
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			__builtin_amdgcn_wave_barrier();
+			l_csr_val = T.csr_val + (size_t)b * T.pp_lin; l_csc_val = T.csc_val + (size_t)b * T.pp_lin; l_sinv_val = T.sinv_val + (size_t)b * T.pp_sinv;
+		}
 #ifdef NTGW_DEBUG
 		if (lane == 0) printf("wave %d takes problem %d of %d (cap %d)\n", wgid, b, A.batch, cap);
 #endif
@@ -883,7 +897,7 @@ static inline bool wave_match(const NtgDims &D, const NtgTables &T, const SolveP
 	if ((D.ig_n + 1) * (D.nout / opl) > 64) return false;
 	if (D.mE != D.nclin || D.mE > 64) return false;
 	if (D.mE > 0 && (!D.q_use || D.q_w > 6)) return false;
-	if (T.pp_rowv || T.pp_bps || T.pp_q) return false;   // per-problem grids: sqp_kernel
+	if ((T.pp_rowv || T.pp_bps || T.pp_q) && (sp.hessian == 1 || nint != 20)) return false;   // per-problem grids: the PPG instances (no preconditioner, 20 intervals), else sqp_kernel
 	if (sp.hessian == 1 && !(T.n0b && T.n0b_n == D.ncoef[0])) return false;
 	if (sp.hessian == 2) return false;
 	return true;
