@@ -546,6 +546,23 @@ def main():
         sms = s0.elapsed_time(s1) / 3
         res["per_problem_grids"]["solve_fixed_50_majors"] = {"batch": nbs, "ms_per_batch": sms, "value": nbs / (sms * 1e-3), "unit": "trajectories/s",
                                                              "kernel": pg.solve_kernel(nbs, og5), "iters_mean": float(osg["iters"].float().mean().item())}
+        # ... and to convergence with the per-problem preconditioner blocks (hessian = 1)
+        pg.clear_grids()
+        tg2 = time.perf_counter()
+        pg.set_grids(torch.tensor(np.ascontiguousarray(kn[:nbs]), device=dev), torch.tensor(np.ascontiguousarray(bpg[:nbs]), device=dev), with_precond=True)
+        setup2_s = time.perf_counter() - tg2
+        og1 = api.default_opts(hessian=1)
+        xs_g.fill_(1.0); pg.solve(lo_g, up_g, xs_g, og1); torch.cuda.synchronize()
+        s0.record()
+        for _ in range(3):
+            xs_g.fill_(1.0)
+            osg1 = pg.solve(lo_g, up_g, xs_g, og1)
+        s1.record(); torch.cuda.synchronize()
+        sms1 = s0.elapsed_time(s1) / 3
+        res["per_problem_grids"]["solve_to_convergence"] = {"batch": nbs, "ms_per_batch": sms1, "value": nbs / (sms1 * 1e-3), "unit": "trajectories/s",
+                                                            "kernel": pg.solve_kernel(nbs, og1), "iters_mean": float(osg1["iters"].float().mean().item()),
+                                                            "converged_frac": float((osg1["inform"] == 0).float().mean().item()),
+                                                            "set_grids_with_preconditioner_s": setup2_s}
         del og, xg, pg, xs_g
 
     if rank == 0 and world == 1 and not args.no_cpu:

@@ -60,7 +60,7 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 	const int epl = opl * 3;
 	w->cap = std::min(sp.memcap, sp.itlim) + 4;
 	w->ppg = (T.pp_rowv || T.pp_bps || T.pp_q) ? 1 : 0;   // per-problem grids: the FAT instance with wave-private tables (wave_match: no preconditioner)
-	w->fat = ((sp.hessian != 1 && !getenv("NTG_AMD_WAVE_LEAN")) || w->ppg) ? 1 : 0;
+	w->fat = (sp.hessian != 1 && (!getenv("NTG_AMD_WAVE_LEAN") || w->ppg)) ? 1 : 0;
 	w->nwv = 4;
 	if (w->fat) {
 		const int nreg = (256 - NTGW_ABASE) / (2 * epl);
@@ -74,7 +74,16 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 			w->grid = std::max(1, std::min((batch + 3) / 4, ncu));   // one workgroup per CU: four waves, one per SIMD
 		}
 	}
-	if (!w->fat) {
+	if (!w->fat && w->ppg) {
+		// per-problem grids with the preconditioner: four waves, each with its own value tables; linear operator and preconditioner blocks
+		// (per problem) read from HBM / L2
+		w->nlds = LEAN_NLDS; w->nwv = 4;
+		w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, LEAN_NLDS, epl, false, true);
+		if (w->lds > 160 * 1024) return false;
+		w->hbm_slots = std::max(0, w->cap - LEAN_NLDS);
+		const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>((4 * LEAN_MINW) / w->nwv, (160 * 1024) / w->lds));
+		w->grid = std::max(1, std::min((batch + w->nwv - 1) / w->nwv, ncu * wg_per_cu));
+	} else if (!w->fat) {
 		// eight waves sharing one copy of the tables, the preconditioner block and the linear operator in LDS; four when the scalars of
 		// a long quasi-Newton memory leave no room for eight
 		w->nlds = LEAN_NLDS; w->nwv = 8;
@@ -102,7 +111,12 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 		return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, false, 16>(D, T, sp, a, w);
 	}
 	if (w.ppg) {   // per-problem grids
-		if (!w.fat || w.nlds != PPG_NLDS) return hipErrorInvalidValue;
+		if (!w.fat) {   // with the preconditioner
+			if (D.nout == 2) return launch_one<2, 1, 4, LEAN_MINW, 0, LEAN_NLDS, true, false, 20, true>(D, T, sp, a, w);
+			if (D.nout == 4) return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, false, 20, true>(D, T, sp, a, w);
+			return launch_one<6, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, false, 20, true>(D, T, sp, a, w);
+		}
+		if (w.nlds != PPG_NLDS) return hipErrorInvalidValue;
 		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
 		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
 		return launch_one<6, 2, 4, 1, R6, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);

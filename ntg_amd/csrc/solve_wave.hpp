@@ -133,7 +133,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const int P = D.P, m = D.mE, cap = A.cap, capp = (cap + 3) & ~3, qw = D.q_w;
 	// ---- shared tables ----
-	static_assert(!(PPG && (XLDS || HESS)), "per-problem grids: the instance without the preconditioner and with the linear operator in HBM");
+	static_assert(!(PPG && XLDS), "per-problem grids: the linear operator and the preconditioner blocks stay in HBM (they are per problem)");
 	const int tabw = NCH * SMAX * K * NL + 2 * SMAX * NL + D.q_nt * 6;   // doubles of one copy of the value tables (one per workgroup; PPG: one per wave)
 	double *s_bt = (double *)smem_raw + (PPG ? wave * tabw : 0);   // [NCH][SMAX][K][NL] basis values of the CHM channels per interval slot; column NINT = 0
 	double *s_wt = s_bt + NCH * SMAX * K * NL;              // [SMAX][NL] trapezoid node weights
@@ -211,6 +211,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	const int wgid = blockIdx.x * NWV + wave;
 	double *hbm = A.hist + (size_t)wgid * A.hbm_slots * EPL * 64;
 
+	const double *w0_base = T.n0b;   // preconditioner blocks (PPG: of the problem being solved)
 	// ================= building blocks (all wave-uniform control flow) =================
 	// NPfunobj (ntg.c:274-335) at xt: gradient into g, returns this lane's shares of the quadrature and of |g|^2
 	auto evaluate = [&](const double (&xt)[EPL], double (&g)[EPL], double &Fq, double &g2) {
@@ -356,7 +357,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 #pragma unroll
 			for (int tl = 0; tl < TM; tl++) acc[tl] = ntg_d4{0.0, 0.0, 0.0, 0.0};
 			for (int b = 0; b < T.n0b_nblk; b++) {
-				const double *wbb = T.n0b + (size_t)b * spad * nco + li;
+				const double *wbb = w0_base + (size_t)b * spad * nco + li;
 				const double *wlb = s_w0 + (size_t)b * 64 * 64 + li;   // staged copy: rows and columns zero padded to 64
 				const bool mine = myblk == b;
 				for (int k0 = 0; k0 < spad; k0 += 16) {
@@ -563,6 +564,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			__builtin_amdgcn_wave_barrier();
 			l_csr_val = T.csr_val + (size_t)b * T.pp_lin; l_csc_val = T.csc_val + (size_t)b * T.pp_lin; l_sinv_val = T.sinv_val + (size_t)b * T.pp_sinv;
+			if (HESS && T.n0b) w0_base = T.n0b + (size_t)b * T.pp_n0b;
 		}
 #ifdef NTGW_DEBUG
 		if (lane == 0) printf("wave %d takes problem %d of %d (cap %d)\n", wgid, b, A.batch, cap);
@@ -897,7 +899,8 @@ static inline bool wave_match(const NtgDims &D, const NtgTables &T, const SolveP
 	if ((D.ig_n + 1) * (D.nout / opl) > 64) return false;
 	if (D.mE != D.nclin || D.mE > 64) return false;
 	if (D.mE > 0 && (!D.q_use || D.q_w > 6)) return false;
-	if ((T.pp_rowv || T.pp_bps || T.pp_q) && (sp.hessian == 1 || nint != 20)) return false;   // per-problem grids: the PPG instances (no preconditioner, 20 intervals), else sqp_kernel
+	if ((T.pp_rowv || T.pp_bps || T.pp_q) && nint != 20) return false;   // per-problem grids: the PPG instances (20 intervals), else sqp_kernel
+	if ((T.pp_rowv || T.pp_bps || T.pp_q) && sp.hessian == 1 && !T.pp_n0b) return false;
 	if (sp.hessian == 1 && !(T.n0b && T.n0b_n == D.ncoef[0])) return false;
 	if (sp.hessian == 2) return false;
 	return true;

@@ -81,9 +81,9 @@ def test_solve_on_per_problem_horizons(name, ncars, hessian):
     p = api.Plan(spec, 0)
     p.set_grids(dev(knots), dev(bps), with_precond=bool(hessian))
     x = dev(np.ones((nb, spec.nC)))
-    # which kernel: the wave kernel's per-problem-grid instance (wave-private value tables) for the identity cold start, the workgroup
-    # kernel with the per-problem preconditioner blocks
-    assert p.solve_kernel(nb, api.default_opts(hessian=hessian)) == ("sqp_wave_kernel" if hessian == 0 else "sqp_kernel")
+    # which kernel: the wave kernel's per-problem-grid instances (wave-private value tables; with the preconditioner: its per-problem
+    # blocks read from HBM)
+    assert p.solve_kernel(nb, api.default_opts(hessian=hessian)) == "sqp_wave_kernel"
     out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=hessian))
     torch.cuda.synchronize()
     xs = x.cpu().numpy(); obj = out["objective"].cpu().numpy(); inform = out["inform"].cpu().numpy(); iters = out["iters"].cpu().numpy()
