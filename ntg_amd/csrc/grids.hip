@@ -180,3 +180,138 @@ hipError_t ntg_launch_grid_lin(const NtgDims &D, int batch, const NtgGridLin &g,
 	hipLaunchKernelGGL(grid_lin_kernel, dim3(batch), dim3(64), lds, st, D, batch, A);
 	return hipGetLastError();
 }
+
+// ---- preconditioner blocks of every grid (hessian = 1 on per-problem grids) ----
+// W0 = Z (Z' H0 Z)^-1 Z' per distinct block (build_precond / precond_block of plan.cpp).  When the equality rows that touch a block pin whole
+// coefficients (a square invertible system: the usual end conditions), null(A) is the coordinate subspace of the free coefficients, Z can
+// be taken as their unit vectors -- an orthonormal basis like the Householder one of the host routine, and W0 with its regularisation
+// (c I in an orthonormal basis) does not depend on which -- so W0 is the inverse of the principal submatrix of H0 over the free
+// coefficients, embedded in zeros.  One wavefront per (problem, block): H0 on the free coefficients from the problem's basis blocks and
+// node weights (lane = row), the host's regularisation and its retry, Cholesky and inverse in LDS (as grid_lin_kernel does for A A'), the
+// host's drop rule for entries at rounding level.  err: 3 = not positive definite (host: NTG_E_UNSUPPORTED), as from the host path.
+struct GridPrecArgs {
+	const double *blk, *bps;   // [batch][P][k][d], [batch][P]
+	const int *plan_off;       // [P]
+	const int *fidx;           // [nblk][nb] index of a coefficient among the block's free ones, -1: pinned
+	const int *binfo;          // [nblk][4]: free count, derivative mask of the running / initial / final cost of the block's outputs
+	double *n0b;               // [batch][n0b_sz]
+	int *err;
+	int nblk, nb, spad, n0b_sz;
+};
+
+__global__ void __launch_bounds__(64)
+grid_prec_kernel(NtgDims D, int batch, GridPrecArgs A)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	const int b = blockIdx.x / A.nblk, q = blockIdx.x - b * A.nblk, lane = threadIdx.x;
+	if (b >= batch) return;
+	const int P = D.P, k = D.cls_k[0], d = D.cls_d[0], nb = A.nb;
+	const int nr = A.binfo[4 * q], tmask = A.binfo[4 * q + 1], imask = A.binfo[4 * q + 2], fmask = A.binfo[4 * q + 3], mp = nr + 1;
+	double *H = (double *)smem_raw;      // [nr][nr+1]
+	double *G = H + (size_t)nr * mp;      // [nr][nr+1] copy of H (retry), then the inverse
+	const int *fx = A.fidx + (size_t)q * nb;
+	const double *bk = A.blk + (size_t)b * P * k * d, *tb = A.bps + (size_t)b * P;
+	double *out = A.n0b + (size_t)b * A.n0b_sz + (size_t)q * A.spad * nb;
+	// 1. H0 on the free coefficients: lane = row a (coefficient c with fx[c] == a)
+	for (int idx = lane; idx < nr * mp; idx += 64) H[idx] = 0.0;
+	nwt_wave_sync();
+	for (int c = 0; c < nb; c++) {
+		const int a = fx[c];
+		if (a < 0 || (a & 63) != lane) continue;   // rows a, a + 64, ... belong to lane a % 64
+		for (int i = 0; i < P; i++) {
+			const int base = A.plan_off[i], q1 = c - base;
+			if (q1 < 0 || q1 >= k) continue;
+			double w = 0.0;
+			if (i > 0) w += (tb[i] - tb[i - 1]) / 2;
+			if (i < P - 1) w += (tb[i + 1] - tb[i]) / 2;
+			const double *bb = bk + (size_t)i * k * d;
+			for (int q2 = 0; q2 < k; q2++) {
+				const int a2 = fx[base + q2];
+				if (a2 < 0) continue;
+				double s = 0.0;
+				for (int r = 0; r < d; r++) {
+					const double pr = bb[q1 * d + r] * bb[q2 * d + r];
+					if ((tmask >> r) & 1) s += w * pr;
+					if (i == 0 && ((imask >> r) & 1)) s += pr;
+					if (i == P - 1 && ((fmask >> r) & 1)) s += pr;
+				}
+				H[a * mp + a2] += s;
+			}
+		}
+	}
+	nwt_wave_sync();
+	double tr = 0.0;
+	for (int a = 0; a < nr; a++) tr += H[a * mp + a];   // (every lane: nr reads of LDS broadcasts)
+	for (int idx = lane; idx < nr * mp; idx += 64) G[idx] = H[idx];
+	nwt_wave_sync();
+	bool ok = false;
+	for (int attempt = 0; attempt < 2 && !ok; attempt++) {
+		const double reg = attempt == 0 ? 1e-12 : 1e-6;
+		for (int idx = lane; idx < nr * mp; idx += 64) H[idx] = G[idx];
+		nwt_wave_sync();
+		for (int a = lane; a < nr; a += 64) H[a * mp + a] += reg * tr / nr + 1e-300;
+		nwt_wave_sync();
+		// Cholesky H = L L' in place (lane = row), right-looking
+		bool bad = false;
+		for (int j = 0; j < nr; j++) {
+			const double dj = H[j * mp + j];
+			if (!(dj > 0.0)) { bad = true; break; }
+			const double ld = sqrt(dj);
+			nwt_wave_sync();
+			for (int i = lane; i < nr; i += 64) {
+				if (i == j) H[i * mp + j] = ld;
+				else if (i > j) H[i * mp + j] = H[i * mp + j] / ld;
+			}
+			nwt_wave_sync();
+			for (int i = lane; i < nr; i += 64)
+				if (i > j) { const double lij = H[i * mp + j]; for (int k2 = j + 1; k2 <= i; k2++) H[i * mp + k2] -= lij * H[k2 * mp + j]; }
+			nwt_wave_sync();
+		}
+		ok = !bad;
+	}
+	if (ok) {   // H0 singular on null(A): the regularised inverse would scale those directions by 1e12 -- the host refuses, so do we
+		double lo = 1e300, hi = 0.0;
+		for (int a = 0; a < nr; a++) { const double dd = H[a * mp + a] * H[a * mp + a]; lo = fmin(lo, dd); hi = fmax(hi, dd); }
+		if (lo < 1e-9 * hi) ok = false;
+	}
+	if (!ok) { if (lane == 0 && atomicCAS(&A.err[0], 0, 3) == 0) { A.err[1] = b; A.err[2] = q; } return; }
+	// inverse column by column (lane = column): L y = e_c, L' x = y
+	for (int c = lane; c < nr; c += 64) {
+		for (int i = 0; i < nr; i++) {
+			double s = (i == c) ? 1.0 : 0.0;
+			for (int k2 = 0; k2 < i; k2++) s -= H[i * mp + k2] * G[k2 * mp + c];
+			G[i * mp + c] = s / H[i * mp + i];
+		}
+		for (int i = nr - 1; i >= 0; i--) {
+			double s = G[i * mp + c];
+			for (int k2 = i + 1; k2 < nr; k2++) s -= H[k2 * mp + i] * G[k2 * mp + c];
+			G[i * mp + c] = s / H[i * mp + i];
+		}
+	}
+	nwt_wave_sync();
+	// W0 [spad][nb]: the symmetrised inverse on the free coefficients, zeros elsewhere; entries at rounding level relative to the diagonal dropped
+	for (int idx = lane; idx < A.spad * nb; idx += 64) {
+		const int i = idx / nb, j = idx - i * nb;
+		double v = 0.0;
+		if (i < nb) {
+			const int a = fx[i], a2 = fx[j];
+			if (a >= 0 && a2 >= 0) {
+				v = 0.5 * (G[a * mp + a2] + G[a2 * mp + a]);
+				if (a != a2 && fabs(v) <= 1e-13 * sqrt(fabs(G[a * mp + a] * G[a2 * mp + a2]))) v = 0.0;
+			}
+		}
+		out[idx] = v;
+	}
+}
+
+hipError_t ntg_launch_grid_prec(const NtgDims &D, int batch, const NtgGridPrec &g, hipStream_t st)
+{
+	GridPrecArgs A;
+	A.blk = g.blk; A.bps = g.bps; A.plan_off = g.plan_off; A.fidx = g.fidx; A.binfo = g.binfo; A.n0b = g.n0b; A.err = g.err;
+	A.nblk = g.nblk; A.nb = g.nb; A.spad = g.spad; A.n0b_sz = g.n0b_sz;
+	const size_t lds = 2 * (size_t)g.nrmax * (g.nrmax + 1) * 8;
+	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)grid_prec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	hipLaunchKernelGGL(grid_prec_kernel, dim3(batch * g.nblk), dim3(64), lds, st, D, batch, A);
+	return hipGetLastError();
+}

@@ -1259,8 +1259,51 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 	if (herr[0] == 1) return fail_free(NTG_E_BADARG, "per-problem grid: a breakpoint lies in another knot interval than in the plan's grid (problem " + std::to_string(herr[1]) + ", breakpoint " + std::to_string(herr[2]) + ")");
 	if (herr[0] == 2) return fail_free(NTG_E_UNSUPPORTED, "per-problem grid: a linear-constraint entry outside the plan's sparsity pattern (problem " + std::to_string(herr[1]) + ", row " + std::to_string(herr[2]) + ")");
 	if (herr[0] == 3) return fail_free(NTG_E_BADARG, "per-problem grid: linear constraint rows are rank deficient (problem " + std::to_string(herr[1]) + ")");
-	// 4. the preconditioner blocks of every grid (hessian = 1): dense n_o x n_o algebra per problem, still on host threads
-	if (with_precond) {
+	// 4. the preconditioner blocks of every grid (hessian = 1).  On the device (grids.hip, grid_prec_kernel) when the equality rows that touch
+	//    a block pin whole coefficients -- null(A) is then spanned by unit vectors and W0 is the inverse of a principal submatrix of H0;
+	//    decided once per plan from the shared grid's A.  Otherwise: dense n_o x n_o algebra (Householder null space) on host threads.
+	if (with_precond && p->prec_dev < 0) {
+		const int nb = p->T.n0b_n, nq = p->T.n0b_nblk;
+		std::vector<int> fidx((size_t)nq * nb, -1), binfo((size_t)nq * 4, 0);
+		bool okdev = !getenv("NTG_AMD_HOST_PRECOND");
+		int nrmax = 0;
+		for (int q = 0; q < nq && okdev; q++) {
+			int o0 = -1;
+			for (int o = 0; o < D.nout; o++) if (D.n0_blk[o] == q) { o0 = o; break; }
+			if (o0 < 0 || D.ncoef[o0] != nb) { okdev = false; break; }
+			const int c0 = D.iC[o0];
+			std::vector<char> pin(nb, 0);
+			int mb = 0, npin = 0;
+			for (int r = 0; r < m; r++) {
+				double big = 0.0; bool hit = false;
+				for (int c = 0; c < n; c++) big = std::max(big, std::fabs(p->h_AE[(size_t)r * n + c]));
+				for (int j = 0; j < nb; j++) if (p->h_AE[(size_t)r * n + c0 + j] != 0.0) hit = true;
+				if (!hit) continue;
+				mb++;
+				for (int j = 0; j < nb; j++) if (std::fabs(p->h_AE[(size_t)r * n + c0 + j]) > 1e-10 * big && !pin[j]) { pin[j] = 1; npin++; }
+				// a row that also touches another block couples the blocks: not this structure
+				for (int c = 0; c < n; c++) if ((c < c0 || c >= c0 + nb) && std::fabs(p->h_AE[(size_t)r * n + c]) > 1e-10 * big) okdev = false;
+			}
+			if (npin != mb || nb - npin < 1) { okdev = false; break; }
+			int cnt = 0;
+			for (int j = 0; j < nb; j++) fidx[(size_t)q * nb + j] = pin[j] ? -1 : cnt++;
+			binfo[4 * q] = cnt; nrmax = std::max(nrmax, cnt);
+			auto mask_of = [&](const std::vector<ntg_av> &av) { int mk = 0; for (const ntg_av &a : av) if (a.output == o0) mk |= 1 << a.deriv; return mk; };
+			binfo[4 * q + 1] = D.nucf ? mask_of(p->tcostav) : 0; binfo[4 * q + 2] = D.nicf ? mask_of(p->icostav) : 0; binfo[4 * q + 3] = D.nfcf ? mask_of(p->fcostav) : 0;
+		}
+		if (okdev && 2 * (size_t)nrmax * (nrmax + 1) * 8 > 160 * 1024) okdev = false;
+		if (okdev && (dev_upload(&p->d_pfidx, fidx.data(), fidx.size(), p->owned) || dev_upload(&p->d_pbinfo, binfo.data(), binfo.size(), p->owned))) return fail_free(NTG_E_HIP, "upload (preconditioner tables)");
+		p->prec_dev = okdev ? 1 : 0; p->prec_nrmax = nrmax;
+	}
+	if (with_precond && p->prec_dev == 1) {
+		NtgGridPrec g{d_blk, d_bpsc, p->d_planoff, p->d_pfidx, p->d_pbinfo, d_n0b, d_err, p->T.n0b_nblk, p->T.n0b_n, p->T.n0b_sp, (int)n0b_sz, p->prec_nrmax};
+		hipError_t e3 = hipMemsetAsync(d_n0b, 0, (size_t)batch * n0b_sz * 8, st);
+		if (e3 == hipSuccess) e3 = ntg_launch_grid_prec(D, batch, g, st);
+		if (e3 == hipSuccess) e3 = hipMemcpyAsync(herr, d_err, 12, hipMemcpyDeviceToHost, st);
+		if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);
+		if (e3 != hipSuccess) return fail_free(NTG_E_HIP, hipGetErrorString(e3));
+		if (herr[0] == 3) return fail_free(NTG_E_UNSUPPORTED, "per-problem grid: preconditioner block not positive definite (problem " + std::to_string(herr[1]) + ")");
+	} else if (with_precond) {
 		std::vector<double> hblk((size_t)batch * nblk), hbps((size_t)batch * P), n0bv((size_t)batch * n0b_sz, 0.0);
 		if (hipMemcpy(hblk.data(), d_blk, hblk.size() * 8, hipMemcpyDeviceToHost) != hipSuccess ||
 		    hipMemcpy(hbps.data(), d_bps, hbps.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail_free(NTG_E_HIP, "reading the basis blocks back failed");

@@ -7,6 +7,7 @@
 
 struct ntg_plan {
 	int device = 0;
+	int *d_pfidx = nullptr, *d_pbinfo = nullptr; int prec_dev = -1, prec_nrmax = 0;   // device path of the per-problem preconditioner blocks: tables, applicability (-1: not decided)
 	double *d_grid_knots = nullptr;   // per-problem grids: device copy of the knots [grid_batch][ninterv + 1] (ntg_batch_interp)
 	mutable int ncu = 0;                        // compute units of the device (queried on first use)
 	NtgDims D;
@@ -74,5 +75,8 @@ struct NtgGridLin {
 };
 hipError_t ntg_launch_grid_rows(const NtgDims &D, int batch, const double *blk, const int *off, const int *plan_off, double *rowv, int *err, hipStream_t st);
 hipError_t ntg_launch_grid_lin(const NtgDims &D, int batch, const NtgGridLin &g, hipStream_t st);
+// preconditioner blocks of every grid on the device (grids.hip, grid_prec_kernel)
+struct NtgGridPrec { const double *blk, *bps; const int *plan_off, *fidx, *binfo; double *n0b; int *err; int nblk, nb, spad, n0b_sz, nrmax; };
+hipError_t ntg_launch_grid_prec(const NtgDims &D, int batch, const NtgGridPrec &g, hipStream_t st);
 hipError_t ntg_launch_mpc_shift(const NtgDims &D, const NtgTables &T, int batch, int sbp, int sknot, const double *lic,
                                 double *x, double *lower, double *upper, hipStream_t st);

@@ -105,6 +105,28 @@ def test_solve_on_per_problem_horizons(name, ncars, hessian):
     assert np.ptp(objs) > 1e-3
 
 
+def test_device_and_host_preconditioner_blocks_agree(monkeypatch):
+    """the per-problem preconditioner blocks built on the device (grid_prec_kernel: inverse of the free coefficients' principal submatrix)
+    and on host threads (Householder null space, NTG_AMD_HOST_PRECOND=1) are the same operator: identical major-iteration counts,
+    objectives to 1e-9 and optima to 1e-6 (the parity tolerances; measured 1e-11 relative) on 16 horizons of config M"""
+    spec = cf.config_M(); nb = 16
+    knots, bps = grids_for(spec, nb, warp=0.2, seed=11)
+    lo, up = cf.kincar_random_bounds(3, nb)
+    res = []
+    for host in (False, True):
+        if host: monkeypatch.setenv("NTG_AMD_HOST_PRECOND", "1")
+        p = api.Plan(spec, 0)
+        p.set_grids(dev(knots), dev(bps), with_precond=True)
+        x = dev(np.ones((nb, spec.nC)))
+        out = p.solve(dev(lo), dev(up), x, api.default_opts(hessian=1))
+        torch.cuda.synchronize()
+        res.append((out["iters"].cpu().numpy().copy(), out["objective"].cpu().numpy().copy(), x.cpu().numpy().copy(), out["inform"].cpu().numpy().copy()))
+    assert (res[0][3] == 0).all() and (res[1][3] == 0).all()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert (np.abs(res[0][1] - res[1][1]) <= 1e-9 * np.maximum(1.0, np.abs(res[1][1]))).all()          # both converged inside the same tolerance ball
+    assert np.abs(res[0][2] - res[1][2]).max() <= 1e-6 * max(1.0, np.abs(res[1][2]).max())
+
+
 def test_interp_on_per_problem_grids():
     """ntg_batch_interp after ntg_plan_set_grids: every problem at its own times on its own knots == SplineInterp (colloc.c:449-484,
     restated in the oracle) with that problem's knots; a shared time vector is refused (shape), a batch of another size too"""

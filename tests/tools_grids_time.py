@@ -20,7 +20,7 @@ for rep in range(3):
     pg.set_grids(knd, bpd, with_precond=False)
     torch.cuda.synchronize(); print(f"set_grids({nbg}, no preconditioner): {1e3 * (time.perf_counter() - t):.2f} ms", flush=True)
 t = time.perf_counter(); pg.set_grids(knd[:2048], bpd[:2048], with_precond=True); torch.cuda.synchronize()
-print(f"set_grids(2048, with preconditioner blocks on host threads): {1e3 * (time.perf_counter() - t):.1f} ms", flush=True)
+print(f"set_grids(2048, with preconditioner blocks (device: grid_prec_kernel; NTG_AMD_HOST_PRECOND=1: host threads)): {1e3 * (time.perf_counter() - t):.1f} ms", flush=True)
 pg.set_grids(knd, bpd, with_precond=False)
 xg = torch.randn((nbg, spec.nC), dtype=torch.float64, device=dev)
 og = pg.eval(xg, 2); pg.eval(xg, 2, out=og); torch.cuda.synchronize()
