@@ -161,8 +161,8 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
  * with obstacle / thrust / speed rows: their evaluation and the augmented-Lagrangian solve read the same per-problem tables); linear
  * inequality rows are not (NTG_E_UNSUPPORTED).
  * Afterwards ntg_batch_eval / ntg_batch_solve / ntg_batch_interp of exactly `batch` problems use these grids (hessian = 2 acts as 1;
- * ntg_batch_interp then takes d_times as [batch][ntimes]: every problem at its own times; ntg_batch_mpc_shift and ntg_batch_mpc_run refuse
- * with NTG_E_UNSUPPORTED: they work on the plan's shared grid) until ntg_plan_clear_grids(). */
+ * ntg_batch_interp then takes d_times as [batch][ntimes]: every problem at its own times; ntg_batch_mpc_shift and ntg_batch_mpc_run
+ * re-pin with every problem's own basis blocks) until ntg_plan_clear_grids(). */
 int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream);
 void ntg_plan_clear_grids(ntg_plan *p);
 
@@ -182,8 +182,8 @@ int ntg_batch_kincar_reverse(const ntg_plan *p, int batch, int ntimes, const dou
 /* Receding-horizon step (the warm-start use NPSOL's istate/clambda/R were meant for, ntg.h:64-68):
  * re-pin the linear initial-constraint bounds of every problem to the flat flag of its current
  * solution at breakpoint shift_bp, and shift the coefficients by shift_knots knot intervals
- * (tail = last coefficient) as the next initial guess.  d_x, d_lower, d_upper are updated in place.  Shared grid only
- * (NTG_E_UNSUPPORTED after ntg_plan_set_grids). */
+ * (tail = last coefficient) as the next initial guess.  d_x, d_lower, d_upper are updated in place.  After ntg_plan_set_grids: with
+ * every problem's own basis blocks (the batch must be the grids'). */
 int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, int shift_knots, double *d_x,
                         double *d_lower, double *d_upper, void *stream);
 

@@ -313,7 +313,7 @@ __global__ void mpc_shift_kernel(NtgDims D, NtgTables T, int batch, int sbp, int
 		int o = 0;
 		while (o + 1 < D.nout && D.iz[o + 1] <= v) o++;
 		const int r = v - D.iz[o], k = D.order[o], d = D.d[o], c = D.cls[o];
-		const double *bq = T.blk + D.cls_blk[c] + (size_t)sbp * k * d;
+		const double *bq = T.blk + (size_t)b * T.pp_blk + D.cls_blk[c] + (size_t)sbp * k * d;   // (per-problem grids: this problem's blocks)
 		const double *cx = sx + D.iC[o] + T.off[c * D.P + sbp];
 		double a = 0.0;
 		for (int q = 0; q < k; q++) a += bq[q * d + r] * cx[q];

@@ -91,6 +91,7 @@ struct NtgTables {
 	// rowv + b pp_rowv, bps + b pp_bps, csr_val + b pp_lin, csc_val + b pp_lin, sinv_val + b pp_sinv, q_val + b pp_q, n0b + b pp_n0b
 	// (strides in elements; all 0 = one shared grid).
 	long long pp_rowv, pp_bps, pp_lin, pp_sinv, pp_q, pp_n0b;
+	long long pp_blk;   // ... and blk + b pp_blk (the full basis blocks: the receding-horizon shift evaluates the whole flag)
 	// linear rows: erow[mE] = original row of equality e; rowmap[nclin] = e, or -(j+1) for inequality j; linflag[slot]
 	// = 1 for slots declared as inequalities; inequality rows as CSR (by row) and CSC (by coefficient)
 	const int *erow, *rowmap, *linflag, *irow;

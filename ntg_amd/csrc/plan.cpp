@@ -1025,7 +1025,7 @@ extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int s
 	if (batch <= 0 || nsteps <= 0) return 0;
 	if (!d_x || !d_lower || !d_upper || !d_inform) return fail(NTG_E_BADARG, "null argument");
 	if (shift_bp < 0 || shift_bp >= p->D.P || shift_knots < 0) return fail(NTG_E_BADARG, "shift out of range");
-	if (p->grid_batch) return fail(NTG_E_UNSUPPORTED, "the receding-horizon run works on the plan's shared grid");
+	if (p->grid_batch && batch != p->grid_batch) return fail(NTG_E_BADARG, "the plan carries per-problem grids for another batch size");
 	HIPCHK(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream, own = nullptr;
 	if (!st) { HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking)); st = own; }   // the legacy default stream cannot be captured
@@ -1326,13 +1326,14 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 		if (err.load()) return fail_free(NTG_E_UNSUPPORTED, "per-problem grid: preconditioner block not positive definite");
 		if (hipMemcpy(d_n0b, n0bv.data(), n0bv.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail_free(NTG_E_HIP, "uploading the preconditioner blocks failed");
 	}
-	hipFree(d_blk); hipFree(d_off); hipFree(d_err);
+	hipFree(d_off); hipFree(d_err);   // (d_blk is kept: the receding-horizon shift evaluates the whole flag at a breakpoint)
 	// 5. the kernels add b * stride to the value pointers (NtgTables::pp_*)
 	p->T_shared = p->T;
-	for (void *q : {(void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b, (void *)d_knc}) if (q) p->grid_owned.push_back(q);
+	for (void *q : {(void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b, (void *)d_knc, (void *)d_blk}) if (q) p->grid_owned.push_back(q);
 	p->d_grid_knots = d_knc;
 	NtgTables &T = p->T;
 	T.rowv = d_rowv; T.pp_rowv = row_total;
+	T.blk = d_blk; T.pp_blk = (long long)nblk;   // one basis class: cls_blk[0] == 0
 	T.bps = d_bpsc; T.pp_bps = P;
 	if (m > 0) { T.csr_val = d_csr; T.csc_val = d_csc; T.pp_lin = lin_nnz; T.sinv_val = d_sinv; T.pp_sinv = sinv_nnz; }
 	if (D.q_use) { T.q_val = d_q; T.pp_q = qn; }
@@ -1392,9 +1393,9 @@ extern "C" int ntg_batch_mpc_shift(const ntg_plan *p, int batch, int shift_bp, i
 	if (batch <= 0) return 0;
 	if (!d_x || !d_lower || !d_upper) return fail(NTG_E_BADARG, "null argument");
 	if (shift_bp < 0 || shift_bp >= p->D.P || shift_knots < 0) return fail(NTG_E_BADARG, "shift out of range");
-	// the shift re-pins the initial bounds with the basis blocks of the plan's SHARED grid (T.blk / T.off): with per-problem grids that would
-	// be the wrong grid's values, silently
-	if (p->grid_batch) return fail(NTG_E_UNSUPPORTED, "the receding-horizon shift works on the plan's shared grid: clear the per-problem grids first");
+	// the shift re-pins the initial bounds with the basis blocks of the grid in force (T.blk: the plan's, or every problem's own after
+	// ntg_plan_set_grids, which keeps them for this)
+	if (p->grid_batch && batch != p->grid_batch) return fail(NTG_E_BADARG, "the plan carries per-problem grids for another batch size");
 	HIPCHK(hipSetDevice(p->device));
 	HIPCHK(ntg_launch_mpc_shift(p->D, p->T, batch, shift_bp, shift_knots, p->d_lic, d_x, d_lower, d_upper, (hipStream_t)stream));
 	return 0;

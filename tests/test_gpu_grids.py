@@ -212,21 +212,38 @@ def test_nonlinear_rows_on_per_problem_horizons(name):
     assert np.ptp(objs) > 1e-3
 
 
-def test_mpc_shift_refuses_per_problem_grids():
-    """The receding-horizon shift re-pins the initial bounds with the basis blocks of the plan's shared grid: after
-    ntg_plan_set_grids it must refuse (like ntg_batch_interp and ntg_batch_mpc_run), not use the wrong grid silently."""
-    spec = cf.config_B()
-    nb = 4
-    knots, bps = grids_for(spec, nb)
-    p = api.Plan(spec, 0)
+def test_receding_horizon_on_per_problem_grids():
+    """solve, advance one knot interval, re-pin, shift, re-solve -- every problem on its own horizon: each re-solve against the oracle built
+    on that problem's grid, the shift against a numpy statement with that problem's basis blocks; then the same loop through
+    ntg_batch_mpc_run (hipGraph) gives the same iterates"""
+    from test_gpu_mpc import shift_numpy
+    spec = cf.config_B(); nb, nsteps = 5, 3
+    knots, bps = grids_for(spec, nb, warp=0.0, seed=13)      # uniform knots per problem (the coefficient shift assumes them), horizons differ
     lo, up = cf.kincar_random_bounds(1, nb)
-    x = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
-    lo_d, up_d = dev(lo), dev(up)
-    p.mpc_shift(x, lo_d, up_d, 5, 1)                       # shared grid: fine
-    p.set_grids(dev(knots), dev(bps), with_precond=False)
-    x0, lo0 = x.clone(), lo_d.clone()
-    with pytest.raises(api.NtgError, match="shared grid"):
+    p = api.Plan(spec, 0)
+    p.set_grids(dev(knots), dev(bps), with_precond=True)
+    specs = [spec_on(spec, knots[b], bps[b]) for b in range(nb)]
+    tabs = [orc.export_tables(sb) for sb in specs]
+    x = dev(np.ones((nb, spec.nC))); lo_d, up_d = dev(lo), dev(up)
+    x2 = x.clone(); lo2, up2 = lo_d.clone(), up_d.clone()
+    opts = api.default_opts(hessian=1)
+    for step in range(nsteps):
+        lo_h, up_h, x_h = lo_d.cpu().numpy(), up_d.cpu().numpy(), x.cpu().numpy()
+        out = p.solve(lo_d, up_d, x, opts)
+        torch.cuda.synchronize()
+        assert (out["inform"].cpu().numpy() == 0).all()
+        xg = x.cpu().numpy()
+        for b in range(nb):
+            ref = orc.solve_one(specs[b], lo_h[b], up_h[b], x_h[b], orc.default_opts(hessian=1))
+            assert ref["inform"] == 0
+            assert np.abs(xg[b] - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max()), (step, b)
+        exp = [shift_numpy(specs[b], tabs[b], xg[b], lo_h[b], up_h[b], 5, 1) for b in range(nb)]
         p.mpc_shift(x, lo_d, up_d, 5, 1)
-    assert torch.equal(x, x0) and torch.equal(lo_d, lo0)   # nothing was touched
-    p.clear_grids()
-    p.mpc_shift(x, lo_d, up_d, 5, 1)
+        np.testing.assert_allclose(x.cpu().numpy(), np.stack([e[0] for e in exp]), rtol=0, atol=0)
+        np.testing.assert_allclose(lo_d.cpu().numpy(), np.stack([e[1] for e in exp]), rtol=1e-13, atol=1e-12)
+    # the captured loop
+    res = p.mpc_run(x2, lo2, up2, nsteps, 5, 1, opts)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(x2.cpu().numpy(), x.cpu().numpy(), rtol=0, atol=1e-9 * max(1.0, float(x.abs().max())))
+    with pytest.raises(api.NtgError):
+        p.mpc_shift(x[:2].contiguous(), lo_d[:2].contiguous(), up_d[:2].contiguous(), 5, 1)
