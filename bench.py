@@ -171,7 +171,7 @@ def main():
         if i is not None:
             ev[i][1].record()
         if world > 1:  # the only collective: final gather of the results (RCCL over xGMI)
-            shard.gather_results(x, out["objective"], total, world)
+            shard.gather_results(x, out["objective"], total, world, inform=out["inform"], iters=out["iters"])
 
     for _ in range(args.warmup):
         step()
@@ -183,6 +183,12 @@ def main():
     dt = shard.max_over_ranks(time.perf_counter() - t0, world, dev)
 
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
+    kern_ms_ranks = [kern_ms]
+    if world > 1:   # after the timed region: every rank's own kernel time (HIP events on its launch stream), for the load-balance picture
+        kt = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+        kall = torch.empty(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(kall, kt)
+        kern_ms_ranks = [float(v) for v in kall.cpu()]
     nfev_total = int(out["nfev"].sum().item())
     iters_np = out["iters"].cpu().numpy()
     inform_np = out["inform"].cpu().numpy()
@@ -223,7 +229,7 @@ def main():
     except Exception:
         pass
     res["roofline"] = {"bound": "hbm", "kernel": solve_kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms,
+                       "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": kern_ms, "kernel_ms_per_rank": kern_ms_ranks,
                        "alg_bytes_per_launch": alg_bytes, "csrc_sha": sha,
                        "alg_bytes_def": f"{spec.eval_bytes()} B per funobj{'+funcon' if large else ''} evaluation (SURVEY 8d) x {nfev_total} evaluations"}
     if traffic_note:

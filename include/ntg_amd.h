@@ -171,6 +171,12 @@ void ntg_plan_clear_grids(ntg_plan *p);
  * D^r z_o(t).  This is the input of a flat-to-state map such as kincar_flat_reverse (kincar.c:68-92). */
 int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times, double *d_z,
                      void *stream);
+/* The same with the layout of d_times stated by the caller instead of implied by the plan's state: problem b reads its ntimes points at
+ * d_times + b * times_stride.  times_stride = 0: one time vector shared by the batch (allowed with and without per-problem grids);
+ * times_stride >= ntimes: per-problem times, only with per-problem grids (NTG_E_BADARG otherwise).  ntg_batch_interp() is this call with
+ * times_stride = 0 on the plan's grid and = ntimes after ntg_plan_set_grids(). */
+int ntg_batch_interp_strided(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times,
+                             long long times_stride, double *d_z, void *stream);
 
 /* The flat-to-state map of the kinematic car for a whole ntg_batch_interp result (examples/kincar.c:68-92 kincar_flat_reverse,
  * called per sample by the example's output loop, kincar.c:392-406): d_z [batch][ntimes][nz] -> d_state [batch][ntimes][ncars][5] =

@@ -73,6 +73,7 @@ def lib():
         L.ntg_batch_mpc_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_longlong, C.c_void_p]
         L.ntg_batch_mpc_shift_multipliers.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]
         L.ntg_batch_interp.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ntg_batch_interp_strided.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p]
         L.ntg_plan_set_grids.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ntg_plan_clear_grids.argtypes = [C.c_void_p]
         L.ntg_plan_clear_grids.restype = None
@@ -115,6 +116,7 @@ class Plan:
     def __init__(self, spec: Spec, device: int = 0):
         self.spec = spec
         self.device = device
+        self.grid_batch = 0   # batch of the per-problem grids in force (set_grids / clear_grids)
         k = self._keep = {}
         k["bps"] = np.ascontiguousarray(spec.bps, dtype=np.float64)
         for nm in ("kninterv", "order", "mult", "maxderiv"):
@@ -225,11 +227,18 @@ class Plan:
         After set_grids: times [batch, ntimes], every problem at its own times on its own knots."""
         import torch
         assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous() and times.is_cuda and times.dtype == torch.float64
-        if times.dim() == 2 and times.shape[0] != x.shape[0]:
-            raise NtgError("per-problem times must be [batch, ntimes]")
+        batch = x.shape[0]
+        if times.dim() == 1:
+            stride = 0                       # one time vector for the batch (with per-problem grids: every problem on its own knots)
+        elif times.dim() == 2 and self.grid_batch and times.shape[0] == batch:
+            stride = times.shape[1]
+        elif times.dim() == 2:
+            raise NtgError("per-problem times [batch, ntimes] need per-problem grids of that batch (set_grids); pass a 1-D time vector")
+        else:
+            raise NtgError("times must be [ntimes] or, after set_grids, [batch, ntimes]")
         ntimes = times.shape[-1]
-        z = torch.empty((x.shape[0], ntimes, self.spec.nz), dtype=torch.float64, device=x.device)
-        _check(lib().ntg_batch_interp(self.h, x.shape[0], _ptr(x), ntimes, _ptr(times.contiguous()), _ptr(z), self._stream()))
+        z = torch.empty((batch, ntimes, self.spec.nz), dtype=torch.float64, device=x.device)
+        _check(lib().ntg_batch_interp_strided(self.h, batch, _ptr(x), ntimes, _ptr(times.contiguous()), stride, _ptr(z), self._stream()))
         return z
 
     def set_grids(self, knots, bps, with_precond: bool = True):
@@ -238,9 +247,11 @@ class Plan:
         if knots.shape[0] != bps.shape[0] or knots.shape[1] != self.spec.kninterv[0] + 1 or bps.shape[1] != self.spec.nbps:
             raise NtgError("knots must be [batch, ninterv+1] and bps [batch, nbps]")
         _check(lib().ntg_plan_set_grids(self.h, knots.shape[0], _ptr(knots), _ptr(bps), int(with_precond), self._stream()))
+        self.grid_batch = int(knots.shape[0])
 
     def clear_grids(self):
         lib().ntg_plan_clear_grids(self.h)
+        self.grid_batch = 0
 
     def kincar_reverse(self, z, wheelbase: float = 3.0, reverse_gear: bool = False):
         """Flat flag -> (x, y, theta, v, delta) per car: z [batch, ntimes, nz] (from interp) -> [batch, ntimes, ncars, 5]."""

@@ -35,6 +35,8 @@ struct NtgDims {
 	int lin_nnz, lin_lds;               // sparse A_E (exact zeros dropped); 1: staged in LDS
 	int sinv_nnz;                       // sparse (A A')^-1 (block diagonal when the rows decouple)
 	int q_use, q_nt, q_w;               // projector Q = A'(AA')^-1 A kept as ELL over its non-zero rows
+	int q_pin;                          // 1: the equality rows pin whole coefficients (as many touched columns as rows: the usual initial / final
+	                                    // conditions) -- Q is then the identity on its non-zero rows, and g - Q g just zeroes those entries of g
 	// collocation matrix of every ACTIVE (class, derivative) channel, in two sparse forms
 	int row_total, col_total;           // doubles in rowv / entries in colv+coli
 	int cls_W[NTG_MAX_OUT];             // padded (multiple of 4) support width of the column form, per class

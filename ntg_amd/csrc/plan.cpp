@@ -417,6 +417,21 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 				    dev_upload(&d_qv, qval.data(), qval.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
 				T.q_idx = d_qi; T.q_col = d_qc; T.q_val = d_qv;
 				D.q_use = 1; D.q_nt = nt; D.q_w = w;
+				// Rows that pin whole coefficients (the usual initial / final conditions: a derivative at an end point touches the first /
+				// last r + 1 coefficients only): range(A') is spanned by m unit vectors and Q is the identity on those coefficients, zero
+				// elsewhere -- g - Q g just zeroes the pinned entries (NtgDims::q_pin, used by the wave kernel).  Decided on the computed Q
+				// itself, to 1e-9 (the accuracy (A A')^-1 gives it is ~1e-10): the reference's cumulative-add linspace (ntg.c:374-389) puts
+				// the last breakpoint an ulp or two off the last knot, so rows of ~1e-15 for the neighbouring coefficients exist too.
+				{
+					int npin = 0; double dev = 0.0;
+					for (int a = 0; a < nC; a++) if (qidx[a] >= 0) {
+						const bool pin = Q[(size_t)a * nC + a] > 0.5;
+						npin += pin ? 1 : 0;
+						for (int c = 0; c < nC; c++) dev = std::max(dev, std::fabs(Q[(size_t)a * nC + c] - ((pin && a == c) ? 1.0 : 0.0)));
+					}
+					D.q_pin = (npin == m && dev <= 1e-9) ? 1 : 0;
+					if (getenv("NTG_AMD_DEBUG_PLAN")) fprintf(stderr, "projector: %d non-zero rows, %d equality rows, width %d, %d pinned, max |Q - I_pinned| %.3e -> q_pin %d\n", nt, m, w, npin, dev, D.q_pin);
+				}
 				p->h_qidx = qidx; p->h_qcol = qcol; p->h_qval = qval;
 			}
 		}
@@ -1029,8 +1044,13 @@ extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int s
 	HIPCHK(hipSetDevice(p->device));
 	hipStream_t st = (hipStream_t)stream, own = nullptr;
 	if (!st) { HIPCHK(hipStreamCreateWithFlags(&own, hipStreamNonBlocking)); st = own; }   // the legacy default stream cannot be captured
-	auto step = [&]() -> int {
-		int rc = ntg_batch_solve(p, batch, d_lower, d_upper, d_x, o, nullptr, d_inform, nullptr, nullptr, nullptr, d_work, work_bytes, st);
+	// The FIRST solve is cold whatever the caller's options say: a warm start reads the multiplier estimates of the previous solve from
+	// d_work (solve_impl.hpp: `if (sp.warm) al_lam[j] = al_t[j]`), and before the first solve the workspace holds nothing of the kind.
+	// The estimates it leaves are shifted with the horizon, so the captured / replayed steps start warm as asked.
+	ntg_solve_opts cold;
+	if (o) { cold = *o; cold.warm_start = 0; }
+	auto step = [&](const ntg_solve_opts *so) -> int {
+		int rc = ntg_batch_solve(p, batch, d_lower, d_upper, d_x, so, nullptr, d_inform, nullptr, nullptr, nullptr, d_work, work_bytes, st);
 		if (rc) return rc;
 		if (d_notconv) { hipError_t e = ntg_launch_count_notconv(batch, d_inform, d_notconv, st); if (e != hipSuccess) return fail(NTG_E_HIP, hipGetErrorString(e)); }
 		rc = ntg_batch_mpc_shift(p, batch, shift_bp, shift_knots, d_x, d_lower, d_upper, st);
@@ -1040,12 +1060,12 @@ extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int s
 	};
 	int rc = 0;
 	if (own) rc = hipDeviceSynchronize() == hipSuccess ? 0 : NTG_E_HIP;   // order after work queued on the default stream
-	if (!rc) rc = step();
+	if (!rc) rc = step(o ? &cold : nullptr);
 	if (!rc && nsteps > 1) {
 		hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
 		hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
 		if (e == hipSuccess) {
-			rc = step();
+			rc = step(o);
 			hipError_t e2 = hipStreamEndCapture(st, &graph);
 			if (!rc && e2 != hipSuccess) rc = fail(NTG_E_HIP, hipGetErrorString(e2));
 			if (!rc && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) rc = fail(NTG_E_HIP, "hipGraphInstantiate failed");
@@ -1053,7 +1073,7 @@ extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int s
 			if (exec) (void)hipGraphExecDestroy(exec);
 			if (graph) (void)hipGraphDestroy(graph);
 		} else {
-			for (int s = 1; !rc && s < nsteps; s++) rc = step();   // capture unavailable: plain launches
+			for (int s = 1; !rc && s < nsteps; s++) rc = step(o);   // capture unavailable: plain launches
 		}
 	}
 	if (own) { if (hipStreamSynchronize(own) != hipSuccess && !rc) rc = NTG_E_HIP; (void)hipStreamDestroy(own); }
@@ -1063,20 +1083,30 @@ extern "C" int ntg_batch_mpc_run(const ntg_plan *p, int batch, int nsteps, int s
 extern "C" int ntg_batch_interp(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times, double *d_z,
                                 void *stream)
 {
+	// documented layout of d_times: [ntimes] on the plan's grid, [batch][ntimes] with per-problem grids
+	return ntg_batch_interp_strided(p, batch, d_x, ntimes, d_times, (p && p->grid_batch) ? (long long)ntimes : 0, d_z, stream);
+}
+
+extern "C" int ntg_batch_interp_strided(const ntg_plan *p, int batch, const double *d_x, int ntimes, const double *d_times,
+                                        long long times_stride, double *d_z, void *stream)
+{
 	if (!p) return fail(NTG_E_BADARG, "null plan");
 	if (batch <= 0 || ntimes <= 0) return 0;
 	if (!d_x || !d_times || !d_z) return fail(NTG_E_BADARG, "null argument");
 	if (p->grid_batch && batch != p->grid_batch) return fail(NTG_E_BADARG, "the plan carries per-problem grids for another batch size");
+	if (times_stride != 0 && times_stride < ntimes) return fail(NTG_E_BADARG, "times_stride must be 0 (one time vector for the batch) or >= ntimes");
+	if (times_stride != 0 && !p->grid_batch) return fail(NTG_E_BADARG, "per-problem times need per-problem grids (ntg_plan_set_grids); pass times_stride = 0");
 	HIPCHK(hipSetDevice(p->device));
 	const NtgDims &D = p->D;
 	hipStream_t st = (hipStream_t)stream;
 	if (p->grid_batch) {
-		// per-problem grids: d_times is [batch][ntimes] -- every problem at its own times, on its own knots (one basis class)
+		// per-problem grids: every problem on its own knots (one basis class), at its own times (row b of d_times at b * times_stride) or,
+		// times_stride == 0, all at the same times
 		double *d_tb = nullptr; int *d_to = nullptr;
 		const size_t per = (size_t)ntimes * D.cls_k[0] * D.cls_d[0];
 		hipError_t e2 = hipMallocAsync((void **)&d_tb, (size_t)batch * per * 8, st);
 		if (e2 == hipSuccess) e2 = hipMallocAsync((void **)&d_to, (size_t)batch * ntimes * 4, st);
-		if (e2 == hipSuccess) e2 = ntg_launch_basis(batch, D.cls_l[0], D.cls_k[0], D.cls_m[0], D.cls_d[0], ntimes, p->d_grid_knots, d_times, D.cls_l[0] + 1, ntimes, d_tb, d_to, st);
+		if (e2 == hipSuccess) e2 = ntg_launch_basis(batch, D.cls_l[0], D.cls_k[0], D.cls_m[0], D.cls_d[0], ntimes, p->d_grid_knots, d_times, D.cls_l[0] + 1, times_stride, d_tb, d_to, st);
 		if (e2 == hipSuccess) e2 = ntg_launch_interp(D, batch, ntimes, d_x, d_tb, d_to, nullptr, d_z, st, 1);
 		if (d_tb) (void)hipFreeAsync(d_tb, st);
 		if (d_to) (void)hipFreeAsync(d_to, st);

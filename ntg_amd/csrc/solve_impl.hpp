@@ -108,6 +108,23 @@ __device__ __forceinline__ double lane_xchg(double v)
 	return __shfl_xor(v, 32, 64);
 }
 
+// t(lane) + t(lane ^ 16) / t(lane) + t(lane ^ 32) in every lane, in the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// the odd rows (the upper half) of one register with the even rows (the lower half) of another -- applied to two copies of t they leave
+// "my half's value" in one and "the other half's" in the other, and the sum of the two is the same number in both partners (the earlier
+// form went through the LDS crossbar: ds_swizzle + ds_bpermute, two ~100-cycle round trips at the end of every butterfly).
+template <int BIT>
+__device__ __forceinline__ double xsum_rows(double t)
+{
+	const int lo = __double2loint(t), hi = __double2hiint(t);
+	if constexpr (BIT == 16) {
+		const auto r = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), s = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+		return __hiloint2double(s[0], r[0]) + __hiloint2double(s[1], r[1]);
+	} else {
+		const auto r = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), s = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+		return __hiloint2double(s[0], r[0]) + __hiloint2double(s[1], r[1]);
+	}
+}
+
 // Sum KV (<= 16) per-lane values over the 64 lanes with the "halving" butterfly: at the step of
 // bit b a lane keeps the half of its values whose index has bit b equal to its own lane bit and
 // hands the other half to its partner, so the number of live values halves every step (15 exchanges
@@ -134,8 +151,8 @@ __device__ __forceinline__ double wave_sum_many(const double *v, int lane)   // 
 	halve_step<KV, 4, 4>(b, c, lane);
 	halve_step<KV, 2, 8>(c, d, lane);
 	double t = d[0];
-	t += lane_xchg<16>(t);
-	t += lane_xchg<32>(t);
+	t = xsum_rows<16>(t);
+	t = xsum_rows<32>(t);
 	return t;
 }
 

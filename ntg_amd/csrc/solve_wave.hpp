@@ -208,6 +208,18 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 #pragma unroll
 		for (int q = 0; q < S; q++) qrow[o * S + q] = (lane_on && m > 0) ? (int)T.q_idx[cbase + o * nco + q] : -1;
 	constexpr int QW = 6;   // entries per projector row this kernel handles (wave_match checks q_w <= 6)
+	// NtgDims::q_pin: Q is the identity on the pinned coefficients and zero elsewhere -- which of this lane's coefficients are pinned (the
+	// rows of Q with a unit diagonal; per-problem grids share the pattern), one bit each
+	unsigned pinmask = 0;
+	if (D.q_pin) {
+#pragma unroll
+		for (int e = 0; e < EPL; e++) {
+			if (qrow[e] >= 0) {
+				const int c = cbase + (e / S) * nco + (e % S);
+				for (int w2 = 0; w2 < qw; w2++) if (T.q_col[qrow[e] * qw + w2] == c && T.q_val[qrow[e] * qw + w2] > 0.5) pinmask |= 1u << e;
+			}
+		}
+	}
 	const int wgid = blockIdx.x * NWV + wave;
 	double *hbm = A.hist + (size_t)wgid * A.hbm_slots * EPL * 64;
 
@@ -314,6 +326,11 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		if (m == 0) {
 #pragma unroll
 			for (int e = 0; e < EPL; e++) gp[e] = g[e];
+			return;
+		}
+		if (D.q_pin) {   // the rows pin whole coefficients: Q is the identity on them (NtgDims::q_pin) -- no staging, no LDS round trips
+#pragma unroll
+			for (int e = 0; e < EPL; e++) gp[e] = ((pinmask >> e) & 1u) ? 0.0 : g[e];
 			return;
 		}
 		stage_put(g);

@@ -156,9 +156,19 @@ def test_interp_on_per_problem_grids():
     assert rel(z, ref) <= 1e-13
     with pytest.raises(api.NtgError):
         p.interp(dev(x[:3]), dev(times[:3]))
+    # a 1-D time vector with grids in force is an explicit broadcast (times_stride = 0 of ntg_batch_interp_strided): every problem at the
+    # SAME times on its OWN knots -- not an ntimes-long buffer read as [batch][ntimes]
+    tshared = np.linspace(max(knots[:, 0]), min(knots[:, -1]), nt)
+    zs = p.interp(dev(x), dev(tshared)).cpu().numpy()
+    zr = p.interp(dev(x), dev(np.tile(tshared, (nb, 1)))).cpu().numpy()
+    assert np.array_equal(zs, zr)
     p.clear_grids()
     z0 = p.interp(dev(x), dev(times[0])).cpu().numpy()          # back on the plan's knots: one shared time vector
     assert z0.shape == (nb, nt, spec.nz)
+    with pytest.raises(api.NtgError):                            # per-problem times without per-problem grids: refused, not "row 0 for everyone"
+        p.interp(dev(x), dev(times))
+    bad = api.lib().ntg_batch_interp_strided(p.h, nb, api._ptr(dev(x)), nt, api._ptr(dev(times)), nt, api._ptr(torch.empty((nb, nt, spec.nz), dtype=torch.float64, device="cuda:0")), None)
+    assert bad != 0                                              # ... and by the C entry itself
 
 
 def test_grid_structure_mismatch_is_refused():

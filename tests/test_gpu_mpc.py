@@ -142,3 +142,31 @@ def test_obstacle_mpc_with_multiplier_carry_over():
     m_warm = loop(True)
     m_cold = loop(False)
     assert m_warm < m_cold, (m_warm, m_cold)
+
+
+def test_mpc_run_with_warm_start_is_the_host_loop_with_a_cold_first_step():
+    """ntg_batch_mpc_run with warm_start = 1 on a plan with nonlinear rows: the library solves the FIRST step cold (the workspace holds no
+    multiplier estimates yet -- here it is filled with NaN bytes on purpose) and every later step warm, exactly like the hand-written host
+    loop of three launches per step (solve, shift, multiplier shift)."""
+    spec = cf.config_O(20); p = api.Plan(spec, 0)
+    nb, nsteps, sknot = 6, 4, 1
+    sbp = 5 * sknot
+    lo, up = cf.obstacle_bounds(nb)
+    cold, warm = api.default_opts(hessian=1), api.default_opts(hessian=1, warm_start=1)
+    nbytes = p.workspace_bytes(nb, warm)
+    work1 = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    x1 = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    lo1, up1 = dev(lo), dev(up)
+    for step in range(nsteps):
+        out = p.solve(lo1, up1, x1, warm if step > 0 else cold, work=work1)
+        assert (out["inform"].cpu().numpy() == 0).all(), (step, out["inform"])
+        p.mpc_shift(x1, lo1, up1, sbp, sknot)
+        p.mpc_shift_multipliers(nb, sbp, warm, work1)
+    work2 = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device="cuda:0")   # every double a NaN: a warm first step would read these
+    x2 = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")
+    lo2, up2 = dev(lo), dev(up)
+    inform, bad = p.mpc_run(x2, lo2, up2, nsteps, sbp, sknot, warm, work=work2)
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0 and (inform == 0).all()
+    assert torch.isfinite(x2).all()
+    assert torch.equal(x1, x2) and torch.equal(lo1, lo2) and torch.equal(up1, up2)

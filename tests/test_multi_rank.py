@@ -26,10 +26,12 @@ def _worker(rank, world, port, total, ret):
     sl = sh.rank_slice(total, world, rank)
     n = sl.stop - sl.start
     r = orc.solve_batch(spec, lo_all[sl], up_all[sl], np.ones((n, spec.nC)), orc.default_opts())
-    gx, go = sh.gather_results(torch.tensor(r["x"]), torch.tensor(r["objective"]), total, world)   # the only collective of the path
+    gx, go, gi, gk = sh.gather_results(torch.tensor(r["x"]), torch.tensor(r["objective"]), total, world,
+                                       inform=torch.tensor(r["inform"], dtype=torch.int32), iters=torch.tensor(r["iters"], dtype=torch.int32))   # the only collective of the path
     tmax = sh.max_over_ranks(float(rank + 1), world)                  # max-over-ranks timing
     if rank == 0:
         ret["x"] = gx.numpy(); ret["obj"] = go.numpy(); ret["tmax"] = tmax
+        ret["inform"] = gi.numpy(); ret["iters"] = gk.numpy(); ret["int_dtype"] = str(gi.dtype)
     dist.barrier(); dist.destroy_process_group()
 
 
@@ -46,6 +48,8 @@ def test_two_rank_sharding_and_gather(total):
         lo, up = cf.kincar_random_bounds(1, total)
         ref = orc.solve_batch(spec, lo, up, np.ones((total, spec.nC)), orc.default_opts())
         assert np.array_equal(ret["x"], ref["x"]) and np.array_equal(ret["obj"], ref["objective"])
+        assert np.array_equal(ret["inform"], ref["inform"]) and np.array_equal(ret["iters"], ref["iters"]) and ret["int_dtype"] == "torch.int32"
+        assert ret["iters"].min() >= 1
         assert ret["tmax"] == 2.0
 
 
