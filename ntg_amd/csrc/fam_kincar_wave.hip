@@ -13,10 +13,15 @@ using namespace ntgw;
 
 namespace {
 
+// base of the hand-managed accumulator range of an instance (solve_wave.hpp): its class's macro, raised by ntg_amd/build.py when the
+// ISA audit finds compiler-generated code in the range; instances without register slots carry 0 (nothing to audit)
+constexpr int abase_of(int nint, bool ppg, int nreg) { return nreg == 0 ? 0 : ((nint != 20 || ppg) ? NTGW_ABASE_ALT : NTGW_ABASE); }
+constexpr int nreg_of(int nint, bool ppg, int epl) { return (256 - ((nint != 20 || ppg) ? NTGW_ABASE_ALT : NTGW_ABASE)) / (2 * epl); }
+
 template <int NOUT, int OPL, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false, int NINT = 20, bool PPG = false>
 hipError_t launch_one(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
 {
-	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, NINT, NWV, MINW, NREG, NLDS, HESS, XLDS, PPG>;
+	auto kfn = sqp_wave_kernel<NTG_FAM_KINCAR, NOUT, OPL, 6, 4, NINT, NWV, MINW, NREG, NLDS, HESS, XLDS, PPG, abase_of(NINT, PPG, NREG)>;
 	WaveArgs A;
 	A.batch = a.batch; A.cap = w.cap; A.lower = a.lo; A.upper = a.up; A.xio = a.x; A.objective = a.obj; A.inform = a.inf; A.iters = a.it;
 	A.nfev = a.nf; A.clambda = a.cl; A.hist = a.hist; A.counter = a.counter; A.hbm_slots = w.hbm_slots;
@@ -61,9 +66,12 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 	w->cap = std::min(sp.memcap, sp.itlim) + 4;
 	w->ppg = (T.pp_rowv || T.pp_bps || T.pp_q) ? 1 : 0;   // per-problem grids: the FAT instance with wave-private tables (wave_match: no preconditioner)
 	w->fat = (sp.hessian != 1 && (!getenv("NTG_AMD_WAVE_LEAN") || w->ppg)) ? 1 : 0;
-	w->nwv = 4;
+	w->nwv = 4; w->noagpr = 0;
 	if (w->fat) {
-		const int nreg = (256 - NTGW_ABASE) / (2 * epl);
+		// NTG_AMD_WAVE_NOAGPR=1: the fallback instance that keeps no chain slot in registers (nothing hand-managed: what a toolchain that
+		// breaks the accumulator scheme would still build and run) -- chain in LDS and HBM only
+		w->noagpr = (getenv("NTG_AMD_WAVE_NOAGPR") && !w->ppg && D.ig_n == 20) ? 1 : 0;
+		const int nreg = w->noagpr ? 0 : nreg_of(D.ig_n, w->ppg != 0, epl);
 		w->nlds = w->ppg ? PPG_NLDS : FAT_NLDS;
 		w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl, false, w->ppg != 0);
 		if (w->lds > 160 * 1024 && !w->ppg) { w->nlds = FAT_NLDS2; w->lds = wave_lds(D, T, sp.hessian, 4, w->cap, w->nlds, epl); }
@@ -101,10 +109,10 @@ bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, 
 hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w)
 {
 	if (!a.counter) return hipErrorInvalidValue;
-	constexpr int R3 = (256 - NTGW_ABASE) / 6, R6 = (256 - NTGW_ABASE) / 12;
+	constexpr int R3 = nreg_of(20, false, 3), R6 = nreg_of(20, false, 6), R3A = nreg_of(20, true, 3), R6A = nreg_of(20, true, 6);
 	if (D.ig_n == 16) {   // four outputs on 16 knot intervals
-		if (w.fat && w.nlds == FAT_NLDS) return launch_one<4, 2, 4, 1, R6, FAT_NLDS, false, false, 16>(D, T, sp, a, w);
-		if (w.fat) return launch_one<4, 2, 4, 1, R6, FAT_NLDS2, false, false, 16>(D, T, sp, a, w);
+		if (w.fat && w.nlds == FAT_NLDS) return launch_one<4, 2, 4, 1, R6A, FAT_NLDS, false, false, 16>(D, T, sp, a, w);
+		if (w.fat) return launch_one<4, 2, 4, 1, R6A, FAT_NLDS2, false, false, 16>(D, T, sp, a, w);
 		const bool xl16 = sp.hessian != 1 || T.n0b_sp <= 64;
 		if (w.nwv == 8 && xl16) return launch_one<4, 2, 8, LEAN_MINW, 0, LEAN_NLDS, true, true, 16>(D, T, sp, a, w);
 		if (xl16) return launch_one<4, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, true, 16>(D, T, sp, a, w);
@@ -117,9 +125,14 @@ hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const Solve
 			return launch_one<6, 2, 4, LEAN_MINW, 0, LEAN_NLDS, true, false, 20, true>(D, T, sp, a, w);
 		}
 		if (w.nlds != PPG_NLDS) return hipErrorInvalidValue;
-		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
-		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
-		return launch_one<6, 2, 4, 1, R6, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
+		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3A, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
+		if (D.nout == 4) return launch_one<4, 2, 4, 1, R6A, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
+		return launch_one<6, 2, 4, 1, R6A, PPG_NLDS, false, false, 20, true>(D, T, sp, a, w);
+	}
+	if (w.fat && w.noagpr) {   // no chain slot in registers (NTG_AMD_WAVE_NOAGPR, or a build whose accumulator base was raised to 256)
+		if (D.nout == 2) return w.nlds == FAT_NLDS ? launch_one<2, 1, 4, 1, 0, FAT_NLDS, false>(D, T, sp, a, w) : launch_one<2, 1, 4, 1, 0, FAT_NLDS2, false>(D, T, sp, a, w);
+		if (D.nout == 4) return w.nlds == FAT_NLDS ? launch_one<4, 2, 4, 1, 0, FAT_NLDS, false>(D, T, sp, a, w) : launch_one<4, 2, 4, 1, 0, FAT_NLDS2, false>(D, T, sp, a, w);
+		return w.nlds == FAT_NLDS ? launch_one<6, 2, 4, 1, 0, FAT_NLDS, false>(D, T, sp, a, w) : launch_one<6, 2, 4, 1, 0, FAT_NLDS2, false>(D, T, sp, a, w);
 	}
 	if (w.fat && w.nlds == FAT_NLDS) {
 		if (D.nout == 2) return launch_one<2, 1, 4, 1, R3, FAT_NLDS, false>(D, T, sp, a, w);

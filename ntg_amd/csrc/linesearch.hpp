@@ -42,6 +42,23 @@ struct LineSearch {
 		a_lo = a_hi = phi_lo = phi_hi = dphi_lo = dphi_hi = 0.0;
 		a = a1;
 	}
+#ifdef __HIPCC__
+	// The wave kernel keeps the state in registers: every lane runs the same scalar code on the same values.  Passing the fields that
+	// step() rewrites through v_readfirstlane tells the compiler so -- they then live in scalar registers (or their spill lanes), and
+	// every branch of step() is a scalar branch instead of an exec-mask region.
+	__device__ __forceinline__ static double uni_(double v)
+	{
+		return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+	}
+	__device__ __forceinline__ void make_uniform()
+	{
+		a_prev = uni_(a_prev); phi_prev = uni_(phi_prev); dphi_prev = uni_(dphi_prev);
+		a_lo = uni_(a_lo); phi_lo = uni_(phi_lo); dphi_lo = uni_(dphi_lo);
+		a_hi = uni_(a_hi); phi_hi = uni_(phi_hi); dphi_hi = uni_(dphi_hi);
+		a = uni_(a);
+		stage = __builtin_amdgcn_readfirstlane(stage); nfev = __builtin_amdgcn_readfirstlane(nfev);
+	}
+#endif
 	NTG_HD double zoom_trial() const
 	{
 		double lo = a_lo < a_hi ? a_lo : a_hi, hi = a_lo < a_hi ? a_hi : a_lo;

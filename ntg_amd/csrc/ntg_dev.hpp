@@ -103,6 +103,7 @@ struct NtgTables {
 	const int *nwt_map, *nwt_pos; const double *nwt_k0; const short *nwt_lo, *nwt_hi;
 	const double *nwt_lf;   // [nwt_nfo][nwt_ngf][nwt_hbf + 1]: band Cholesky factor (diagonal inverted) of the free outputs' cost model, built with the plan
 	const short *q_idx;    // [nC] row of coefficient c in the compact Q, or -1
+	const unsigned char *q_pinned;   // [nC] 1: coefficient c is pinned by the equality rows (NtgDims::q_pin plans only)
 	const int *q_col;      // [q_nt][q_w]
 	const double *q_val;   // [q_nt][q_w], zero padded
 };

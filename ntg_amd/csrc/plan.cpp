@@ -424,12 +424,16 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 				// the last breakpoint an ulp or two off the last knot, so rows of ~1e-15 for the neighbouring coefficients exist too.
 				{
 					int npin = 0; double dev = 0.0;
+					std::vector<unsigned char> pinned(nC, 0);
 					for (int a = 0; a < nC; a++) if (qidx[a] >= 0) {
 						const bool pin = Q[(size_t)a * nC + a] > 0.5;
-						npin += pin ? 1 : 0;
+						npin += pin ? 1 : 0; pinned[a] = pin ? 1 : 0;
 						for (int c = 0; c < nC; c++) dev = std::max(dev, std::fabs(Q[(size_t)a * nC + c] - ((pin && a == c) ? 1.0 : 0.0)));
 					}
 					D.q_pin = (npin == m && dev <= 1e-9) ? 1 : 0;
+					unsigned char *d_pin = nullptr;
+					if (D.q_pin && dev_upload(&d_pin, pinned.data(), pinned.size(), own)) { ntg_plan_destroy(p); return NTG_E_HIP; }
+					T.q_pinned = d_pin;
 					if (getenv("NTG_AMD_DEBUG_PLAN")) fprintf(stderr, "projector: %d non-zero rows, %d equality rows, width %d, %d pinned, max |Q - I_pinned| %.3e -> q_pin %d\n", nt, m, w, npin, dev, D.q_pin);
 				}
 				p->h_qidx = qidx; p->h_qcol = qcol; p->h_qval = qval;

@@ -47,7 +47,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x,
 hipError_t ntg_launch_eval(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a);
 hipError_t ntg_launch_sqp(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a);
 // one wavefront per problem (solve_wave.hpp, fam_kincar_wave.hip): does it take this solve, and its launch shape / HBM workspace
-struct NtgWavePlan { int fat, nwv, grid, cap, hbm_slots, nlds, ppg; size_t lds, hist_doubles; };   // ppg: per-problem grids (wave-private value tables)
+struct NtgWavePlan { int fat, nwv, grid, cap, hbm_slots, nlds, ppg, noagpr; size_t lds, hist_doubles; };   // ppg: per-problem grids (wave-private value tables)
 bool ntg_wave_plan(const NtgDims &D, const NtgTables &T, const SolveParams &sp, int batch, int ncu, NtgWavePlan *w);
 hipError_t ntg_launch_sqp_wave(const NtgDims &D, const NtgTables &T, const SolveParams &sp, const SqpArgs &a, const NtgWavePlan &w);
 hipError_t ntg_launch_basis(int ngrids, int l, int k, int m, int d, int P, const double *knots, const double *bps,

@@ -125,6 +125,41 @@ __device__ __forceinline__ double xsum_rows(double t)
 	}
 }
 
+// Sums of a FEW (1..3) per-lane values over the wavefront, every lane receives all of them.  Row stage by rotation (DPP row_ror 1, 2, 4,
+// 8: every lane of a row ends up with its row's total, no masked-out lanes and therefore no zero-initialised "old" operands), the two
+// cross-row stages on the permlane swaps, the stages of the KV values interleaved (independent chains: with one wave per SIMD nothing
+// else hides the DPP latency; the earlier form ran KV complete 6-stage row_shr / row_bcast chains one after the other, 36 instructions
+// each).  Lanes of a row add in different orders, so the result is taken from ONE lane (readfirstlane) -- a scalar, known uniform.
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot(double v)
+{
+	const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+	const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double uniform_of(double v)   // lane 0's value, as a scalar
+{
+	return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+template <int KV>
+__device__ __forceinline__ void wave_sums_few(double (&v)[KV])
+{
+#pragma unroll
+	for (int k = 0; k < KV; k++) v[k] += dpp_rot<0x121>(v[k]);   // row_ror:1
+#pragma unroll
+	for (int k = 0; k < KV; k++) v[k] += dpp_rot<0x122>(v[k]);   // row_ror:2
+#pragma unroll
+	for (int k = 0; k < KV; k++) v[k] += dpp_rot<0x124>(v[k]);   // row_ror:4
+#pragma unroll
+	for (int k = 0; k < KV; k++) v[k] += dpp_rot<0x128>(v[k]);   // row_ror:8
+#pragma unroll
+	for (int k = 0; k < KV; k++) v[k] = xsum_rows<16>(v[k]);
+#pragma unroll
+	for (int k = 0; k < KV; k++) v[k] = xsum_rows<32>(v[k]);
+#pragma unroll
+	for (int k = 0; k < KV; k++) v[k] = uniform_of(v[k]);
+}
+
 // Sum KV (<= 16) per-lane values over the 64 lanes with the "halving" butterfly: at the step of
 // bit b a lane keeps the half of its values whose index has bit b equal to its own lane bit and
 // hands the other half to its partner, so the number of live values halves every step (15 exchanges

@@ -48,23 +48,29 @@ __device__ __forceinline__ double from_next(double v)
 }
 
 // The register allocator hands out accumulator registers from a0 upwards when the 256 architectural VGPRs run short (AV-class values:
-// load results, copies).  It cannot be told to keep out, so the chain starts at a[NTGW_ABASE]: a0 .. a[NTGW_ABASE - 1] are the compiler's,
-// and ntg_amd/isa_audit.py fails the build if compiler-generated code touches anything from a[NTGW_ABASE] up.
+// load results, copies).  It cannot be told to keep out, so the chain starts at a[ABASE] -- a template parameter of the kernel, visible in
+// its mangled name: a0 .. a[ABASE - 1] are the compiler's, and ntg_amd/isa_audit.py rejects an object in which compiler-generated code
+// touches anything from a[ABASE] up.  ntg_amd/build.py then RAISES the base of the class of instances that failed (NTGW_ABASE: 20 knot
+// intervals on the plan's grid; NTGW_ABASE_ALT: the 16-interval and per-problem-grid instances) and compiles again -- fewer chain slots in
+// registers, never a broken build; at 256 the instance keeps no slot in registers at all (NREG = 0: nothing hand-managed is left).
 #ifndef NTGW_ABASE
 #define NTGW_ABASE 16
 #endif
+#ifndef NTGW_ABASE_ALT
+#define NTGW_ABASE_ALT 16
+#endif
 // accumulator registers a[ABASE + 2 IDX], a[ABASE + 2 IDX + 1] as one double.  The kernel lists a0..a255 as clobbers once (which makes
 // the kernel descriptor allocate them all).
-template <int IDX>
+template <int ABASE, int IDX>
 __device__ __forceinline__ void areg_write(double v)
 {
-	asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(__double2loint(v)), "v"(__double2hiint(v)), "i"(NTGW_ABASE + 2 * IDX), "i"(NTGW_ABASE + 2 * IDX + 1));
+	asm volatile("v_accvgpr_write_b32 a[%c2], %0\n\tv_accvgpr_write_b32 a[%c3], %1" ::"v"(__double2loint(v)), "v"(__double2hiint(v)), "i"(ABASE + 2 * IDX), "i"(ABASE + 2 * IDX + 1));
 }
-template <int IDX>
+template <int ABASE, int IDX>
 __device__ __forceinline__ double areg_read()
 {
 	int lo, hi;
-	asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]" : "=v"(lo), "=v"(hi) : "i"(NTGW_ABASE + 2 * IDX), "i"(NTGW_ABASE + 2 * IDX + 1));
+	asm volatile("v_accvgpr_read_b32 %0, a[%c2]\n\tv_accvgpr_read_b32 %1, a[%c3]" : "=v"(lo), "=v"(hi) : "i"(ABASE + 2 * IDX), "i"(ABASE + 2 * IDX + 1));
 	return __hiloint2double(hi, lo);
 }
 #define NTGW_C10(p) "a" #p "0", "a" #p "1", "a" #p "2", "a" #p "3", "a" #p "4", "a" #p "5", "a" #p "6", "a" #p "7", "a" #p "8", "a" #p "9"
@@ -84,8 +90,7 @@ template <int KV>
 __device__ __forceinline__ void wave_sums(double (&v)[KV], int lane)
 {
 	if constexpr (KV < 4) {
-#pragma unroll
-		for (int k = 0; k < KV; k++) v[k] = wave_sum(v[k]);
+		wave_sums_few<KV>(v);
 	} else {
 		double w[16];
 #pragma unroll
@@ -119,7 +124,7 @@ __host__ __device__ inline int wave_priv_doubles(int nC, int cap, int nlds, int 
 // CSR) are staged in the workgroup's LDS: the instance of short solves, where their L2 latency is a visible share of a problem
 // PPG: per-problem grids (ntg_plan_set_grids) -- every wave keeps its OWN copy of the value tables (basis values, node weights, projector
 // values) and restages it for each problem it takes; the index tables stay shared.  Without the preconditioner only (hessian != 1).
-template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false, bool PPG = false>
+template <int FAM, int NOUT, int OPL, int K, int CHM, int NINT, int NWV, int MINW, int NREG, int NLDS, bool HESS, bool XLDS = false, bool PPG = false, int ABASE = NTGW_ABASE>
 __global__ void __launch_bounds__(64 * NWV, MINW)
 sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 {
@@ -127,7 +132,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	if constexpr (NREG > 0) NTGW_CLAIM_AGPRS();
 	constexpr int DM = Fam::DM, NCH = chm_count(CHM), SMAX = 6, S = K / 2, NG = NOUT / OPL, EPL = OPL * S, NL = NINT + 1, LP = NL * NG;
 	constexpr int nco = S * NINT + S, nC = NOUT * nco, NZL = OPL * DM;
-	static_assert(LP <= 64 && NTGW_ABASE + NREG * 2 * EPL <= 256, "lanes / accumulator registers");
+	static_assert(LP <= 64 && (NREG == 0 || ABASE + NREG * 2 * EPL <= 256), "lanes / accumulator registers");
 	static_assert(OPL == NOUT || Fam::PER_OUTPUT_COST, "outputs may be split over lanes only when the cost is a sum over the outputs");
 	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,7 +199,6 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	double *s_kp = s_dl + capp;                // [capp] kappa_j
 	double *s_lk = s_kp + capp;                // [capp][2] links (e_i, f_i)
 	const int scal = 4 * capp > 128 ? 4 * capp : 128;
-	LineSearch *lsb = (LineSearch *)(s_tmp + scal);   // 2 copies (48 doubles reserved)
 	double *s_hl = s_tmp + scal + 48;          // [NLDS][lane][EPL]
 	// ---- lane roles ----
 	const int og = lane / NL, t = lane - og * NL, o0 = og * OPL;
@@ -211,14 +215,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 	// NtgDims::q_pin: Q is the identity on the pinned coefficients and zero elsewhere -- which of this lane's coefficients are pinned (the
 	// rows of Q with a unit diagonal; per-problem grids share the pattern), one bit each
 	unsigned pinmask = 0;
-	if (D.q_pin) {
+	if (D.q_pin && lane_on) {
 #pragma unroll
-		for (int e = 0; e < EPL; e++) {
-			if (qrow[e] >= 0) {
-				const int c = cbase + (e / S) * nco + (e % S);
-				for (int w2 = 0; w2 < qw; w2++) if (T.q_col[qrow[e] * qw + w2] == c && T.q_val[qrow[e] * qw + w2] > 0.5) pinmask |= 1u << e;
-			}
-		}
+		for (int e = 0; e < EPL; e++) pinmask |= (unsigned)T.q_pinned[cbase + (e / S) * nco + (e % S)] << e;
 	}
 	const int wgid = blockIdx.x * NWV + wave;
 	double *hbm = A.hist + (size_t)wgid * A.hbm_slots * EPL * 64;
@@ -416,7 +415,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			static_for<0, NREG>([&](auto Jc) __attribute__((always_inline)) {
 				constexpr int J = decltype(Jc)::value;
 				if (j == J) {
-					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; areg_write<J * EPL + E>(v[E]); });
+					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; areg_write<ABASE, J * EPL + E>(v[E]); });
 				}
 			});
 		} else if (j < NREG + NLDS) {
@@ -478,7 +477,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				constexpr int J = decltype(Jc)::value;
 				if (J < nso) {
 					double h[EPL];
-					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; h[E] = areg_read<J * EPL + E>(); });
+					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; h[E] = areg_read<ABASE, J * EPL + E>(); });
 					acc[J & 15] = dot(h, v);
 				}
 				if ((J & 15) == 15 || J == NREG - 1) { if (J - (J & 15) < nso) flush(J - (J & 15)); }
@@ -512,7 +511,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				constexpr int J = decltype(Jc)::value;
 				if (J < nso) {
 					const double kj = bcast(kap0, J);
-					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; tv[E] += kj * areg_read<J * EPL + E>(); });
+					static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; tv[E] += kj * areg_read<ABASE, J * EPL + E>(); });
 				}
 			});
 		}
@@ -531,7 +530,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			for (int e = 0; e < EPL; e++) dc[e] = 0.0;
 			if constexpr (H0 > 0) {
 				if constexpr (NLDS > 0) lds_get(H0 - 1, dc);
-				else static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; dc[E] = areg_read<(NREG > 0 ? NREG - 1 : 0) * EPL + E>(); });
+				else static_for<0, EPL>([&](auto Ec) __attribute__((always_inline)) { constexpr int E = decltype(Ec)::value; dc[E] = areg_read<ABASE, (NREG > 0 ? NREG - 1 : 0) * EPL + E>(); });
 				dcl = s_dl[H0 - 1];
 			}
 			auto consume = [&](int base, double (&h)[HG][EPL]) {
@@ -653,13 +652,28 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 #pragma unroll
 			for (int e = 0; e < EPL; e++) xt[e] = x[e];
 			NTGW_STAMP(0);
-			int lsi = 0;
+			// Line-search state.  One wave per SIMD (MINW == 1): in registers, uniform (linesearch.hpp: make_uniform) -- scalar branches, no LDS
+			// round trips.  Two waves per SIMD: the 256-register budget has no room for it (measured: 16-32 registers spilled to scratch,
+			// preconditioned solves 12 % slower), so those instances keep it in the wave's LDS, lane 0 writing it back.
+			constexpr bool LSREG = (MINW == 1);
+			LineSearch ls;
+			LineSearch *lsm = (LineSearch *)(s_tmp + scal);   // (48 doubles reserved in front of the chain's LDS tier)
+			ls.init(0.0, 0.0, 0.0, 0.0, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
 			double ls_a = 0.0;
 			double r4[4] = {0, 0, 0, 0};   // gp.d, d.d, x.x, gp.gp of the current iterate
 			for (;;) {
 				// ================= the one evaluation site =================
 				double part[3] = {0.0, 0.0, 0.0};
 				evaluate(xt, g, part[0], part[1]);
+#ifdef NTGW_DBL_EVAL   // ablation (variant builds): the phase runs twice, its second result is kept alive but unused -- the time difference is its cost in place
+				{ double g2_[EPL], pa_ = 0.0, pb_ = 0.0; double xq_[EPL];
+#pragma unroll
+				  for (int e = 0; e < EPL; e++) { xq_[e] = xt[e]; asm volatile("" : "+v"(xq_[e])); }
+				  evaluate(xq_, g2_, pa_, pb_);
+#pragma unroll
+				  for (int e = 0; e < EPL; e++) asm volatile("" ::"v"(g2_[e]));
+				  asm volatile("" ::"v"(pa_), "v"(pb_)); }
+#endif
 				NTGW_STAMPV(1, g[0] + part[0] + part[1]);
 				if (state != ST_FINAL) {
 					project(g, gpt);
@@ -667,6 +681,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 					for (int e = 0; e < EPL; e++) part[2] += gpt[e] * (-d[e]);
 					NTGW_STAMPV(2, part[2]);
 				}
+#ifdef NTGW_DBL_RED3
+				{ double q_[3] = {part[0], part[1], part[2]}; asm volatile("" : "+v"(q_[0]), "+v"(q_[1]), "+v"(q_[2])); wave_sums<3>(q_, lane); asm volatile("" ::"s"(q_[0]), "s"(q_[1]), "s"(q_[2])); }
+#endif
 				wave_sums<3>(part, lane);
 				NTGW_STAMPV(6, part[0] + part[1] + part[2]);
 				const double Fn = part[0], gn2n = part[1];
@@ -710,12 +727,22 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				} else {
 					int rc = 1;
 					if (state == ST_LS) {
-						LineSearch lsr = lsb[lsi];
-						rc = lsr.step(Fn, part[2]);
-						ls_a = lsr.a;
-						if (lane == 0) lsb[lsi ^ 1] = lsr;
-						lsi ^= 1;
-						nwt_wave_sync();
+#ifdef NTGW_DBL_LS
+						{ LineSearch l2_ = ls; double fq_ = Fn, sq_ = part[2]; asm volatile("" : "+v"(fq_), "+v"(sq_)); fq_ = LineSearch::uni_(fq_); sq_ = LineSearch::uni_(sq_);
+						  int rq_ = __builtin_amdgcn_readfirstlane(l2_.step(fq_, sq_)); l2_.make_uniform(); asm volatile("" ::"s"(rq_), "s"(l2_.a), "s"(l2_.a_lo), "s"(l2_.a_hi), "s"(l2_.phi_lo), "s"(l2_.phi_hi), "s"(l2_.a_prev)); }
+#endif
+						if constexpr (LSREG) {
+							rc = __builtin_amdgcn_readfirstlane(ls.step(Fn, part[2]));
+							ls.make_uniform();
+							ls_a = ls.a;
+						} else {
+							LineSearch lsr = *lsm;
+							rc = lsr.step(Fn, part[2]);
+							ls_a = lsr.a;
+							nwt_wave_sync();   // every lane has read the state before lane 0 rewrites it
+							if (lane == 0) *lsm = lsr;
+							nwt_wave_sync();
+						}
 						NTGW_STAMPV(7, ls_a);
 					}
 					if (rc == 0 || rc == 2) {
@@ -758,15 +785,26 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						NTGW_STAMP(5);
 						apply_w0(gpt, tv);
 						NTGW_STAMPV(4, tv[0]);
+#ifdef NTGW_DBL_SWEEP
+						{ double t2_[EPL], v2_[EPL];
+#pragma unroll
+						  for (int e = 0; e < EPL; e++) { t2_[e] = tv[e]; v2_[e] = gpt[e]; asm volatile("" : "+v"(v2_[e])); }
+						  sweep(ns, v2_, t2_);
+#pragma unroll
+						  for (int e = 0; e < EPL; e++) asm volatile("" ::"v"(t2_[e])); }
+#endif
 						sweep(ns, gpt, tv);
 						NTGW_STAMPV(3, tv[0]);
-						double r6[6] = {0, 0, 0, 0, 0, 0};
+						// one butterfly for everything that does not depend on the update's scalars: the six products of the BFGS formulas and the
+						// two norms of the next major's tests (|x|^2, |gp+|^2); the two that involve the new direction follow below
+						double r6[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
 						for (int e = 0; e < EPL; e++) {
 							const double s = sv[e], y = gpt[e] - gp[e], u = tv[e] - d[e], gq = gpt[e];
 							r6[0] += s * y; r6[1] += y * u; r6[2] += s * gq; r6[3] += u * gq; r6[4] += s * s; r6[5] += y * y;
+							r6[6] += x[e] * x[e]; r6[7] += gq * gq;
 						}
-						wave_sums<6>(r6, lane);
+						wave_sums<8>(r6, lane);
 						const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
 						const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
 						double dn[EPL];
@@ -802,14 +840,14 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						}
 						headpair = false;
 						nwt_wave_sync();
-#pragma unroll
-						for (int k = 0; k < 4; k++) r4[k] = 0.0;
+						double r2[2] = {0.0, 0.0};
 #pragma unroll
 						for (int e = 0; e < EPL; e++) {
 							gp[e] = gpt[e]; d[e] = dn[e];
-							r4[0] += gp[e] * d[e]; r4[1] += d[e] * d[e]; r4[2] += x[e] * x[e]; r4[3] += gp[e] * gp[e];
+							r2[0] += gp[e] * d[e]; r2[1] += d[e] * d[e];
 						}
-						wave_sums<4>(r4, lane);
+						wave_sums<2>(r2, lane);
+						r4[0] = r2[0]; r4[1] = r2[1]; r4[2] = r6[6]; r4[3] = r6[7];
 						F = Fn; gn2 = gn2n;
 						iter++;
 						if (!sp.fixed_iters && alpha * pnorm <= sp.sr * (1.0 + sqrt(r4[2])) &&
@@ -842,9 +880,12 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						if (!finished) {
 							const double amax = sp.steplimit * (1.0 + xnorm) / pnorm;
 							const double a = amax < 1.0 ? amax : 1.0;
-							if (lane == 0) lsb[lsi ^ 1].init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
-							lsi ^= 1; ls_a = a;
-							nwt_wave_sync();
+							if constexpr (LSREG) ls.init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
+							else {
+								if (lane == 0) lsm->init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
+								nwt_wave_sync();
+							}
+							ls_a = a;
 							state = ST_LS;
 #pragma unroll
 							for (int e = 0; e < EPL; e++) xt[e] = x[e] + a * (-d[e]);

@@ -34,7 +34,7 @@ def audit(hipcc: str, src: str, include: str, flags: list[str], reserve_from: in
             for mm in re.finditer(r"\ba\[?(\d+)(?::(\d+))?\]?", code):
                 hi = int(mm.group(2) or mm.group(1))
                 maxidx[cur] = max(maxidx.get(cur, -1), hi)
-                if hi >= reserve_from:
+                if hi >= kernel_base(cur, reserve_from):
                     problems.append((cur, ln, code.strip()))
         m = re.match(r"\s*\.name:\s*(\S+)", line)
         if m:
@@ -48,6 +48,21 @@ def audit(hipcc: str, src: str, include: str, flags: list[str], reserve_from: in
             out.append(f"{cur}: line {ln}: {code}")
         else:
             warnings.append(f"{cur}: line {ln}: {code}")
+    return out
+
+
+def kernel_base(mangled: str, default: int) -> int:
+    """first hand-managed accumulator register of a wave-kernel instance: its last template argument (ABASE, solve_wave.hpp)"""
+    m = re.search(r"sqp_wave_kernelI.*?ELi(\d+)EEEv", mangled or "")
+    return int(m.group(1)) if m else default
+
+
+def failing_classes(problems: list[str]) -> set[str]:
+    """which class of instances the audit's findings belong to: 'alt' = 16 knot intervals or per-problem grids (NTGW_ABASE_ALT), 'main' = the rest"""
+    out = set()
+    for pr in problems:
+        m = re.search(r"sqp_wave_kernelILi\d+ELi\d+ELi\d+ELi\d+ELi\d+ELi(\d+)ELi\d+ELi\d+ELi\d+ELi\d+ELb[01]ELb[01]ELb([01])E", pr)
+        out.add("alt" if (m and (m.group(1) != "20" or m.group(2) == "1")) else "main")
     return out
 
 

@@ -260,3 +260,21 @@ def test_wave_kernel_cold_start_to_convergence_and_outputs():
         assert np.all(lam[:spec.nC] == 0)
         # (first-order quantities of two solutions that agree to 1e-6 in x: the cost's curvature amplifies the difference)
         np.testing.assert_allclose(lam[spec.nC:], o["clambda"][spec.nC:], rtol=1e-3, atol=1e-4 * np.abs(o["clambda"]).max())
+
+
+def test_fallback_instance_without_register_slots():
+    """NTG_AMD_WAVE_NOAGPR=1 selects the instance that keeps no chain slot in the accumulator registers (what a build whose accumulator base
+    was raised to 256 by ntg_amd/build.py would run): same iterates -- the tier a slot lives in is storage, not arithmetic."""
+    import os
+    spec = plan_for("M").spec
+    nb = 9
+    lo, up = cf.kincar_random_bounds(3, nb)
+    kw = dict(itlim=50, fixed_iters=1)
+    x0, o0 = solve("M", lo, up, np.ones((nb, spec.nC)), **kw)
+    os.environ["NTG_AMD_WAVE_NOAGPR"] = "1"
+    try:
+        assert plan_for("M").solve_kernel(nb, api.default_opts(**kw)) == "sqp_wave_kernel"
+        x1, o1 = solve("M", lo, up, np.ones((nb, spec.nC)), **kw)
+    finally:
+        os.environ.pop("NTG_AMD_WAVE_NOAGPR", None)
+    assert np.array_equal(o0["nfev"], o1["nfev"]) and np.array_equal(x0, x1) and np.array_equal(o0["objective"], o1["objective"])
