@@ -264,7 +264,8 @@ def test_wave_kernel_cold_start_to_convergence_and_outputs():
 
 def test_fallback_instance_without_register_slots():
     """NTG_AMD_WAVE_NOAGPR=1 selects the instance that keeps no chain slot in the accumulator registers (what a build whose accumulator base
-    was raised to 256 by ntg_amd/build.py would run): same iterates -- the tier a slot lives in is storage, not arithmetic."""
+    was raised to 256 by ntg_amd/build.py would run): the same iteration (identical evaluation counts; the tiers add the chain's terms in
+    different orders, so objectives agree to rounding, like the wave kernel and the workgroup kernel do)."""
     import os
     spec = plan_for("M").spec
     nb = 9
@@ -277,4 +278,6 @@ def test_fallback_instance_without_register_slots():
         x1, o1 = solve("M", lo, up, np.ones((nb, spec.nC)), **kw)
     finally:
         os.environ.pop("NTG_AMD_WAVE_NOAGPR", None)
-    assert np.array_equal(o0["nfev"], o1["nfev"]) and np.array_equal(x0, x1) and np.array_equal(o0["objective"], o1["objective"])
+    assert np.array_equal(o0["nfev"], o1["nfev"]) and (o1["iters"] == 50).all()
+    assert rel(o0["objective"], o1["objective"]) <= 2e-7
+    assert np.abs(x0 - x1).max() <= 1e-5 * np.abs(x0).max()
