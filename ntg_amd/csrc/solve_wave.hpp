@@ -21,10 +21,6 @@
 #pragma once
 #include "solve_impl.hpp"
 
-#ifndef NTGW_HG
-#define NTGW_HG 2
-#endif
-
 namespace ntgw {
 
 template <int J, int N, class F>
@@ -335,20 +331,24 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		stage_put(g);
 		// every load is unconditional (a lane without a row reads row 0: one broadcast address) and the result is selected afterwards.
 		// Two LDS round trips: the rows' column indices (16-byte reads), then g at those columns and the rows' values.
-		int col[EPL][8];
+		// (the row numbers pass through an opaque copy: their LDS addresses are then formed here, not once per kernel and kept in a dozen
+		// registers across everything else)
+		int col[EPL][8], qr[EPL];
+#pragma unroll
+		for (int e = 0; e < EPL; e++) { qr[e] = qrow[e]; asm volatile("" : "+v"(qr[e])); }
 #pragma unroll
 		for (int e = 0; e < EPL; e++) {
-			const int4 *cp = (const int4 *)(s_qc + (qrow[e] >= 0 ? qrow[e] : 0) * 8);
+			const int4 *cp = (const int4 *)(s_qc + (qr[e] >= 0 ? qr[e] : 0) * 8);
 			const int4 c0 = cp[0], c1 = cp[1];
 			col[e][0] = c0.x; col[e][1] = c0.y; col[e][2] = c0.z; col[e][3] = c0.w; col[e][4] = c1.x; col[e][5] = c1.y; col[e][6] = 0; col[e][7] = 0;
 		}
 #pragma unroll
 		for (int e = 0; e < EPL; e++) {
-			const double2 *vp = (const double2 *)(s_qv + (qrow[e] >= 0 ? qrow[e] : 0) * 6);
+			const double2 *vp = (const double2 *)(s_qv + (qr[e] >= 0 ? qr[e] : 0) * 6);
 			const double2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
 			const double s = ((v0.x * s_st[col[e][0]] + v0.y * s_st[col[e][1]]) + (v1.x * s_st[col[e][2]] + v1.y * s_st[col[e][3]])) +
 			                 (v2.x * s_st[col[e][4]] + v2.y * s_st[col[e][5]]);
-			gp[e] = g[e] - (qrow[e] >= 0 ? s : 0.0);
+			gp[e] = g[e] - (qr[e] >= 0 ? s : 0.0);
 		}
 		nwt_wave_sync();
 	};
@@ -445,15 +445,19 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		return a0 + a1;
 	};
 	// tv += sum_j kappa_j d_j, kappa = (symmetric tridiagonal of the links) (d_j . v): DESIGN.md 4a.4, apply_dform of sqp_kernel.
-	// On-chip slots: pass 1 (all dot products, 16 per butterfly), the kappa of every slot, pass 2 (axpys).  Slots in HBM are read ONCE:
-	// rounds of HG vectors through two register buffers, link by link (t += d_i (e delta_{i+1} + f delta_i) + d_{i+1} e delta_i), the
-	// first round requested before the on-chip passes start -- its latency hides behind them.
-	constexpr int H0 = NREG + NLDS, HG = MINW == 1 ? NTGW_HG : 2;   // chain slots per round of the HBM tier (two register buffers of HG vectors)
+	// On-chip slots: pass 1 (all dot products, 16 per butterfly), the kappa of every slot by one lane each (kept in that lane: pass 2
+	// broadcasts it from there, no LDS read per slot), pass 2 (axpys).  Slots in HBM are read ONCE: rounds of HG vectors through two register
+	// buffers, link by link (t += d_i (e delta_{i+1} + f delta_i) + d_{i+1} e delta_i), the first round requested before the on-chip
+	// passes start -- its latency hides behind them.  (Round 4 tried the two-pass form for the HBM tier as well -- one FMA per element
+	// instead of two, 16 dot products per butterfly instead of a reduction per round: fewer instructions, but the tier is bound by its
+	// loads, and reading it twice made the headline 7 % and the cold start to convergence 32 % slower.  Measured, dropped.)
+	constexpr int H0 = NREG + NLDS, HG = 2;   // chain slots per round of the HBM tier (two register buffers of HG vectors; other round sizes were never
+	                                          // validated -- variant builds with 3 and 4 faulted on the GPU, profiles/r04_incidents -- so this is not a knob)
 	auto sweep = [&](int ns, const double (&v)[EPL], double (&tv)[EPL]) {
 		if (ns < 2) return;   // a chain of one vector carries no update yet
 		const int nso = min(ns, H0);   // on-chip slots; the links nso-1 .. ns-2 belong to the HBM rounds
 		double hA[HG][EPL], hB[HG][EPL];
-		auto hload = [&](int base, double (&h)[HG][EPL]) {   // unconditional: past the end the newest vector again (its links are masked)
+		auto hload = [&](int base, double (&h)[HG][EPL]) {   // unconditional: past the end the newest vector again (masked where it is used)
 #pragma unroll
 			for (int g2 = 0; g2 < HG; g2++) {
 				const double *p = hbm + (size_t)(min(base + g2, ns - 1) - H0) * EPL * 64 + lane;
@@ -494,17 +498,20 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			}
 		}
 		nwt_wave_sync();
-		// kappa_j = f_j delta_j + e_j delta_{j+1} + e_{j-1} delta_{j-1}; link i = (e_i, f_i) joins slots i and i + 1
+		// kappa_j = f_j delta_j + e_j delta_{j+1} + e_{j-1} delta_{j-1}; link i = (e_i, f_i) joins slots i and i + 1.  Lane j keeps kappa_j
+		// for the broadcasts of pass 2 (the on-chip tiers hold fewer than 64 slots)
+		static_assert(H0 <= 64, "kappa of the on-chip slots lives in one register");
 		double kap0 = 0.0;
 		for (int j = lane; j < nso; j += 64) {
 			const double dj = s_dl[j];
 			double k = 0.0;
 			if (j < nso - 1) k += s_lk[2 * j + 1] * dj + s_lk[2 * j] * s_dl[j + 1];
 			if (j > 0) k += s_lk[2 * j - 2] * s_dl[j - 1];
-			s_kp[j] = k;
 			if (j == lane) kap0 = k;
 		}
-		nwt_wave_sync();
+		auto kappa_of = [&](int j) -> double {   // uniform j < 64
+			return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(kap0), j), __builtin_amdgcn_readlane(__double2loint(kap0), j));
+		};
 		// pass 2: tv += kappa_j d_j
 		if constexpr (NREG > 0) {
 			static_for<0, NREG>([&](auto Jc) __attribute__((always_inline)) {
@@ -517,7 +524,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		}
 		if constexpr (NLDS > 0) {
 			for (int j = NREG; j < nso; j++) {
-				const double kj = s_kp[j];
+				const double kj = kappa_of(j);
 				double h[EPL]; lds_get(j, h);
 #pragma unroll
 				for (int e = 0; e < EPL; e++) tv[e] += kj * h[e];
@@ -586,11 +593,16 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		if (lane == 0) printf("wave %d takes problem %d of %d (cap %d)\n", wgid, b, A.batch, cap);
 #endif
 		double *xrow = A.xio + (size_t)b * nC;
-		double x[EPL], xt[EPL], gp[EPL], gpt[EPL], d[EPL], g[EPL];
+		// (per-problem copy of the lane's coefficient base, opaque to the optimiser: with the plain kernel-lifetime constant it hoisted the six
+		// CSC column pointers, the x addresses and more out of this loop and parked ~30 of them in accumulator registers for the whole
+		// kernel -- inside the range the chain's register tier needs)
+		int cb = cbase, ln = lane;
+		asm volatile("" : "+v"(cb), "+v"(ln));
+		double x[EPL], gp[EPL], gpt[EPL], d[EPL], g[EPL];
 #pragma unroll
 		for (int o = 0; o < OPL; o++)
 #pragma unroll
-			for (int q = 0; q < S; q++) x[o * S + q] = lane_on ? xrow[cbase + o * nco + q] : 0.0;
+			for (int q = 0; q < S; q++) x[o * S + q] = lane_on ? xrow[cb + o * nco + q] : 0.0;
 #pragma unroll
 		for (int e = 0; e < EPL; e++) { d[e] = 0.0; gp[e] = 0.0; gpt[e] = 0.0; g[e] = 0.0; }
 		enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3 };
@@ -613,7 +625,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		// ---- scope check: every linear row is an equality (lower == upper), see sqp_kernel ----
 		{
 			double bad[1] = {0.0};
-			for (int s = lane; s < D.nlic + D.nltc + D.nlfc; s += 64) if (lo[s] != up[s]) bad[0] += 1.0;
+			for (int s = ln; s < D.nlic + D.nltc + D.nlfc; s += 64) if (lo[s] != up[s]) bad[0] += 1.0;
 			wave_sums<1>(bad, lane);
 			if (bad[0] != 0.0) inform = 9;
 		}
@@ -624,13 +636,13 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			// ---- linear feasibility: x += A'(AA')^-1 (b - A x) ----
 			if (m > 0) {
 				stage_put(x);
-				for (int r = lane; r < m; r += 64) {
+				for (int r = ln; r < m; r += 64) {
 					double a = 0.0;
 					for (int e = l_csr_ptr[r]; e < l_csr_ptr[r + 1]; e++) a += l_csr_val[e] * s_st[l_csr_col[e]];
 					s_tmp[r] = lo[lin_slot(D, r)] - a;
 				}
 				nwt_wave_sync();
-				for (int r = lane; r < m; r += 64) {
+				for (int r = ln; r < m; r += 64) {
 					double a = 0.0;
 					for (int e = l_sinv_ptr[r]; e < l_sinv_ptr[r + 1]; e++) a += l_sinv_val[e] * s_tmp[l_sinv_col[e]];
 					s_tmp[64 + r] = a;
@@ -641,7 +653,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 					for (int o = 0; o < OPL; o++)
 #pragma unroll
 						for (int q = 0; q < S; q++) {
-							const int c = cbase + o * nco + q;
+							const int c = cb + o * nco + q;
 							double s = 0.0;
 							for (int e = l_csc_ptr[c]; e < l_csc_ptr[c + 1]; e++) s += l_csc_val[e] * s_tmp[64 + l_csc_row[e]];
 							x[o * S + q] += s;
@@ -649,8 +661,6 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				}
 				nwt_wave_sync();
 			}
-#pragma unroll
-			for (int e = 0; e < EPL; e++) xt[e] = x[e];
 			NTGW_STAMP(0);
 			// Line-search state.  One wave per SIMD (MINW == 1): in registers, uniform (linesearch.hpp: make_uniform) -- scalar branches, no LDS
 			// round trips.  Two waves per SIMD: the 256-register budget has no room for it (measured: 16-32 registers spilled to scratch,
@@ -660,20 +670,19 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 			LineSearch *lsm = (LineSearch *)(s_tmp + scal);   // (48 doubles reserved in front of the chain's LDS tier)
 			ls.init(0.0, 0.0, 0.0, 0.0, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
 			double ls_a = 0.0;
+			double tstep = 0.0;            // the point to evaluate is x + tstep (-d): a line-search trial, or x itself (first and final evaluation)
 			double r4[4] = {0, 0, 0, 0};   // gp.d, d.d, x.x, gp.gp of the current iterate
 			for (;;) {
 				// ================= the one evaluation site =================
 				double part[3] = {0.0, 0.0, 0.0};
-				evaluate(xt, g, part[0], part[1]);
-#ifdef NTGW_DBL_EVAL   // ablation (variant builds): the phase runs twice, its second result is kept alive but unused -- the time difference is its cost in place
-				{ double g2_[EPL], pa_ = 0.0, pb_ = 0.0; double xq_[EPL];
+				{
+					// the trial point is formed here and dies inside the evaluation (it is not kept across the line-search step: an accepted
+					// step recomputes x + alpha (-d), the same operation on the same operands)
+					double xt[EPL];
 #pragma unroll
-				  for (int e = 0; e < EPL; e++) { xq_[e] = xt[e]; asm volatile("" : "+v"(xq_[e])); }
-				  evaluate(xq_, g2_, pa_, pb_);
-#pragma unroll
-				  for (int e = 0; e < EPL; e++) asm volatile("" ::"v"(g2_[e]));
-				  asm volatile("" ::"v"(pa_), "v"(pb_)); }
-#endif
+					for (int e = 0; e < EPL; e++) xt[e] = x[e] + tstep * (-d[e]);
+					evaluate(xt, g, part[0], part[1]);
+				}
 				NTGW_STAMPV(1, g[0] + part[0] + part[1]);
 				if (state != ST_FINAL) {
 					project(g, gpt);
@@ -693,13 +702,13 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				if (state == ST_FINAL) {
 					// multipliers estimate lam = (AA')^-1 A g at the final point
 					stage_put(g);
-					for (int r = lane; r < m; r += 64) {
+					for (int r = ln; r < m; r += 64) {
 						double a = 0.0;
 						for (int e = l_csr_ptr[r]; e < l_csr_ptr[r + 1]; e++) a += l_csr_val[e] * s_st[l_csr_col[e]];
 						s_tmp[r] = a;
 					}
 					nwt_wave_sync();
-					for (int r = lane; r < m; r += 64) {
+					for (int r = ln; r < m; r += 64) {
 						double a = 0.0;
 						for (int e = l_sinv_ptr[r]; e < l_sinv_ptr[r + 1]; e++) a += l_sinv_val[e] * s_tmp[l_sinv_col[e]];
 						s_tmp[64 + r] = a;
@@ -747,8 +756,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 					}
 					if (rc == 0 || rc == 2) {
 						if (rc == 2) state = ST_FORCE;
-#pragma unroll
-						for (int e = 0; e < EPL; e++) xt[e] = x[e] + ls_a * (-d[e]);
+						tstep = ls_a;
 						NTGW_STAMP(5);
 						continue;
 					}
@@ -776,7 +784,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						// accept: s = alpha p, x = xt; t = W gp+ (W0, then the chain), u = t - d, BFGS update on the inverse
 						double sv[EPL], tv[EPL];
 #pragma unroll
-						for (int e = 0; e < EPL; e++) { sv[e] = alpha * (-d[e]); x[e] = xt[e]; }
+						for (int e = 0; e < EPL; e++) { sv[e] = alpha * (-d[e]); x[e] = x[e] + tstep * (-d[e]); }   // (tstep == alpha: the point just evaluated)
 						if (nupd == sp.memcap || ns + 3 > cap) {   // memory full: restart the approximation from W0 (oracle/sqp.c does the same at the same count)
 							nupd = 0; ns = 0; headpair = true;
 							apply_w0(gp, d);
@@ -885,10 +893,8 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 								if (lane == 0) lsm->init(F, dphi0, a, amax, sp.ls_mu, sp.ls_eta, sp.ls_maxfev);
 								nwt_wave_sync();
 							}
-							ls_a = a;
+							ls_a = a; tstep = a;
 							state = ST_LS;
-#pragma unroll
-							for (int e = 0; e < EPL; e++) xt[e] = x[e] + a * (-d[e]);
 						}
 					}
 				}
@@ -896,9 +902,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				if (finished) {
 					inform = (inner_inform == 0 && weak) ? 1 : inner_inform;
 					if (A.clambda && m > 0) {   // one more pass at x for the multipliers (the Q form does not produce them)
-						state = ST_FINAL;
-#pragma unroll
-						for (int e = 0; e < EPL; e++) xt[e] = x[e];
+						state = ST_FINAL; tstep = 0.0;
 						continue;
 					}
 					break;
@@ -912,7 +916,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 #pragma unroll
 			for (int o = 0; o < OPL; o++)
 #pragma unroll
-				for (int q = 0; q < S; q++) xrow[cbase + o * nco + q] = x[o * S + q];
+				for (int q = 0; q < S; q++) xrow[cb + o * nco + q] = x[o * S + q];
 		}
 #ifdef NTGW_DEBUG
 		if (lane == 0) printf("b %d x written\n", b);
@@ -920,7 +924,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		NTGW_STAMP(5);
 		if (A.clambda) {
 			const int ntot = nC + D.nclin;   // NPSOL's layout: coefficients, linear rows (no nonlinear rows in this class)
-			for (int i = lane; i < ntot; i += 64) {
+			int ln2 = lane;
+			asm volatile("" : "+v"(ln2));
+			for (int i = ln2; i < ntot; i += 64) {
 				double v = 0.0;
 				if (inform != 9 && i >= nC && m > 0) v = s_tmp[64 + (i - nC)];
 				A.clambda[(size_t)b * ntot + i] = v;

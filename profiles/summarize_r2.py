@@ -1,4 +1,4 @@
-"""Summarise gpurun_out/r2prof (made by tests/tools_prof_r2.sh on the GPU box) into profiles/r02_*.  python profiles/summarize_r2.py"""
+"""Summarise gpurun_out/r2prof (made by tools/prof_r2.sh on the GPU box) into profiles/r02_*.  python profiles/summarize_r2.py"""
 import csv, glob, json, os, re, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r2prof"); DST = os.path.join(ROOT, "profiles")
@@ -21,7 +21,7 @@ for r in tr:
     dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 bench = json.loads(open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(DST, "r02_bench.json"), "w"), indent=1)
-summ = {"how": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu (tests/tools_prof_r2.sh); durations in ms"}
+summ = {"how": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu (tools/prof_r2.sh); durations in ms"}
 label = {"sqp_kernel<0, 6, 6, 128, 4, false, false, 4, false>": "headline sqp_kernel: 4096 x config M, 50 fixed majors (identity cold start)",
          "sqp_kernel<0, 6, 6, 128, 4, false, true, 4, false>": "sqp_kernel config M to convergence (4096 and 65536 problems mixed)",
          "sqp_kernel<4, 4, 8, 256, 4, false, true, 0, true>": "sqp_kernel config D, 512 problems, structured Newton mode",
@@ -50,7 +50,7 @@ def counters(tag, kernel_sub):
                 out[n].append(v)
     return {n: sum(v) / len(v) for n, v in out.items()}, {n: len(v) for n, v in out.items()}
 
-traffic = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tests/tools_prof_r2.py (3 launches each, averaged per launch); "
+traffic = {"how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_r2.py (3 launches each, averaged per launch); "
                   "KiB units; FETCH_SIZE x 2 on gfx950 (128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as read"}
 for what, sub, key in (("sqp", "sqp_kernel", "sqp_kernel:M:4096:fixed50"), ("eval", "eval_interval_kernel", "eval_interval_kernel:M:262144"), ("newtonE", "sqp_kernel", "sqp_kernel:E:1024:newton")):
     fe, _ = counters(f"pmc_{what}_fetch", sub); wr, _ = counters(f"pmc_{what}_write", sub)
@@ -67,7 +67,7 @@ json.dump(traffic, open(os.path.join(DST, "traffic.json"), "w"), indent=1)
 lds, n = counters("pmc_eval_lds", "eval_interval_kernel")
 if lds:
     lds_s = {"how": "rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY over "
-                    "tests/tools_prof_r2.py eval (eval_interval_kernel, 2^18 evaluations of config M per launch, averaged per launch)", "raw": lds}
+                    "tools/prof_r2.py eval (eval_interval_kernel, 2^18 evaluations of config M per launch, averaged per launch)", "raw": lds}
     if lds.get("SQ_ACTIVE_INST_LDS"):
         lds_s["bank_conflict_share_of_lds_active"] = lds["SQ_LDS_BANK_CONFLICT"] / lds["SQ_ACTIVE_INST_LDS"]
     if lds.get("SQ_WAVE_CYCLES"):
@@ -78,7 +78,7 @@ if lds:
     lds_s["valu_instructions_per_evaluation"] = lds.get("SQ_INSTS_VALU", 0) / 262144
     json.dump(lds_s, open(os.path.join(DST, "r02_eval_lds.json"), "w"), indent=1)
 
-mf = {"how": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over tests/tools_prof_r2.py newtonD / newtonE "
+mf = {"how": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE over tools/prof_r2.py newtonD / newtonE "
              "(structured Newton solves at the bench batch, averaged per launch); MfmaFlopsF64 = MOPS_F64 x 512; MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)"}
 for what, key in (("newtonD", "D:512:newton"), ("newtonE", "E:1024:newton")):
     c, _ = counters(f"pmc_{what}_mfma", "sqp_kernel")

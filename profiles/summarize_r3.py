@@ -1,4 +1,4 @@
-"""Summarise gpurun_out/r3prof (made by tests/tools_prof_r3.sh on the GPU box) into profiles/r03_*.  python profiles/summarize_r3.py
+"""Summarise gpurun_out/r3prof (made by tools/prof_r3.sh on the GPU box) into profiles/r03_*.  python profiles/summarize_r3.py
 Remove gpurun_out/r3prof before the gpurun call: gpurun MERGES the box's output into the local directory, and run directories of an earlier
 call (other process ids) would be summarised instead of, or averaged with, the new ones."""
 import csv, glob, json, os, re, collections, sys
@@ -26,7 +26,7 @@ for r in tr:
     dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 bench = json.loads(open(os.path.join(SRC, "bench.json")).read().strip().splitlines()[-1])
 json.dump(bench, open(os.path.join(DST, "r03_bench.json"), "w"), indent=1)
-summ = {"how": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu (tests/tools_prof_r3.sh); durations in ms; device sources " + SHA}
+summ = {"how": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu (tools/prof_r3.sh); durations in ms; device sources " + SHA}
 for k, d in sorted(dur.items()):
     if any(s in k for s in ("sqp_", "eval_", "grid_")):
         d = sorted(d)
@@ -57,7 +57,7 @@ def counters(tag, kernel_sub):
 
 tpath = os.path.join(DST, "traffic.json")
 traffic = json.load(open(tpath))
-traffic["how_r3"] = ("round 3: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tests/tools_prof_r3.py (3 launches each, averaged per launch); "
+traffic["how_r3"] = ("round 3: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over tools/prof_r3.py (3 launches each, averaged per launch); "
                      "KiB units; FETCH_SIZE x 2 on gfx950 (128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section); WRITE_SIZE as read; every entry "
                      "carries the hash of the device sources it was measured on (bench.py attaches it only on a match)")
 cfgM_bytes = 6056

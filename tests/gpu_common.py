@@ -26,3 +26,20 @@ def dev(a, dtype=torch.float64):
 def rel(a, b):
     a = np.asarray(a); b = np.asarray(b)
     return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def same_work(nfev, nfev_ref):
+    """Fixed-work runs of two implementations of the same iteration do the same work: identical evaluation counts.  The exception is a
+    problem that has converged to rounding level before the forced number of majors is over: its remaining line searches compare values
+    that differ by ~1e-16 |F| and are decided by noise (seen: the oracle needs 101 evaluations where every other problem needs 100, one
+    implementation 102, another a whole failed search of 20 more).  Rule: where the reference count is the batch's regular one the counts
+    must be equal (at most one problem in eight may differ, by at most two evaluations); where the reference itself is irregular only the
+    objective is compared (the callers assert it)."""
+    import numpy as np
+    a, b = np.asarray(nfev), np.asarray(nfev_ref)
+    if a.shape != b.shape:
+        return False
+    vals, cnt = np.unique(b, return_counts=True)
+    regular = b == vals[np.argmax(cnt)]
+    da = np.abs(a - b)[regular]
+    return regular.mean() >= 0.75 and (da != 0).sum() <= max(1, da.size // 8) and (da.max() if da.size else 0) <= 2

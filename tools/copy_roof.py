@@ -1,5 +1,5 @@
 """Diagnostic (not a test): what a plain device-to-device copy reaches on this box with the evaluation kernel's traffic (read 0.8 GB, write
-0.8 GB per launch) -- the practical ceiling for a 1:1 read/write stream, next to the 8 TB/s spec.  python tests/tools_copy_roof.py"""
+0.8 GB per launch) -- the practical ceiling for a 1:1 read/write stream, next to the 8 TB/s spec.  python tools/copy_roof.py"""
 import torch
 n = (1 << 18) * 379
 a = torch.randn(n, dtype=torch.float64, device="cuda:0"); b = torch.empty_like(a)

@@ -1,7 +1,7 @@
 """one-off: inform histograms of the Newton parity cases on both sides (to set the explicit counts in test_gpu_newton.py)"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import orc
 from ntg_amd import api, configs as cf

@@ -1,4 +1,4 @@
-"""Diagnostic (not a test): KKT residuals of the structured Newton mode at BASELINE sizes.  python tests/tools_kkt.py [D|E] [batch]"""
+"""Diagnostic (not a test): KKT residuals of the structured Newton mode at BASELINE sizes.  python tools/kkt.py [D|E] [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

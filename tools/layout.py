@@ -1,4 +1,4 @@
-"""Diagnostic (not a test): LDS bytes per workgroup of the solve and evaluation kernels.  python tests/tools_layout.py M"""
+"""Diagnostic (not a test): LDS bytes per workgroup of the solve and evaluation kernels.  python tools/layout.py M"""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ntg_amd import api, configs as cf

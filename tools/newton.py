@@ -1,8 +1,8 @@
 """Diagnostic (not a test): structured Newton mode (hessian = 2) of sqp_kernel against the oracle.
-python tests/tools_newton.py [O|D2|E2|D|E] [batch] [nref]
+python tools/newton.py [O|D2|E2|D|E] [batch] [nref]
 The phase clock (NTG_AMD_STAMPS=1 or 4) needs a variant library built with -DNTG_CLOCK: tools/mkvariant2.sh clock "fam_quadrotor fam_manip fam_obstacle" -DNTG_CLOCK, then NTG_AMD_LIB=ntg_amd/variants/libntg_clock.so (the shipped kernels carry no clock: 18 registers)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np, torch
 import orc

@@ -1,5 +1,5 @@
 """Diagnostic driver for rocprofv3 (round 2): a few launches of the kernels the round-2 numbers are quoted on, nothing else.
-   python3 tests/tools_prof_r2.py [sqp|eval|newtonD|newtonE]"""
+   python3 tools/prof_r2.py [sqp|eval|newtonD|newtonE]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """Diagnostic driver for rocprofv3 (round 3): a few launches of the kernels the round-3 numbers are quoted on, nothing else.
-   python3 tests/tools_prof_r3.py [fixed50|conv_h1|conv_h0|eval]"""
+   python3 tools/prof_r3.py [fixed50|conv_h1|conv_h0|eval]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,7 +1,7 @@
 #!/bin/bash
 # (locally: rm -rf gpurun_out/r3prof first -- gpurun merges into it, and stale run directories would be picked up by the summariser)
 # Round-3 profiles on the GPU box (run from the repo root through gpurun): kernel-trace statistics of the bench command, then
-# counter passes (--pmc only, one group per pass) over tests/tools_prof_r3.py.  Raw output under gpurun_out/r3prof/.
+# counter passes (--pmc only, one group per pass) over tools/prof_r3.py.  Raw output under gpurun_out/r3prof/.
 set -o pipefail
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/r3prof
@@ -9,7 +9,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo stats done
-pmc() { name=$1; shift; what=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${what}_${name} -- python3 $ROOT/tests/tools_prof_r3.py $what > /dev/null 2> $OUT/pmc_${what}_${name}.err || exit 1; echo pmc $what $name done; }
+pmc() { name=$1; shift; what=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${what}_${name} -- python3 $ROOT/tools/prof_r3.py $what > /dev/null 2> $OUT/pmc_${what}_${name}.err || exit 1; echo pmc $what $name done; }
 pmc fetch fixed50 FETCH_SIZE
 pmc write fixed50 WRITE_SIZE
 pmc fetch conv_h1_big FETCH_SIZE

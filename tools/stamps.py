@@ -1,4 +1,4 @@
-"""Diagnostic (not a test): per-phase cycle shares of sqp_kernel.  NTG_AMD_STAMPS=1 python tests/tools_stamps.py
+"""Diagnostic (not a test): per-phase cycle shares of sqp_kernel.  NTG_AMD_STAMPS=1 python tools/stamps.py
 Needs a variant library built with -DNTG_CLOCK (tools/mkvariant2.sh), passed as NTG_AMD_LIB: the shipped kernels carry no clock."""
 import os, sys
 os.environ["NTG_AMD_STAMPS"] = "1"

@@ -1,6 +1,6 @@
 """Diagnostic (not a test): build tuning variants of one translation unit and time the headline solve with each.
-  here:        python tests/tools_variants.py build fam_kincar_chm.hip tag1="-DX=1 -DY=2" tag2="..."
-  on the box:  python tests/tools_variants.py run [M|D|E] [batch]      (one child process per variant library)"""
+  here:        python tools/variants.py build fam_kincar_chm.hip tag1="-DX=1 -DY=2" tag2="..."
+  on the box:  python tools/variants.py run [M|D|E] [batch]      (one child process per variant library)"""
 import os, subprocess, sys, glob
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VDIR = os.path.join(ROOT, "build", "variants")
