@@ -234,6 +234,25 @@ def main():
                        "alg_bytes_def": f"{spec.eval_bytes()} B per funobj{'+funcon' if large else ''} evaluation (SURVEY 8d) x {nfev_total} evaluations"}
     if traffic_note:
         res["roofline"]["traffic_note"] = traffic_note
+    # The roof that BINDS this kernel is not HBM: the wave kernel runs one wavefront per SIMD, its chain of search directions on chip, and
+    # is limited by fp64 vector-instruction issue.  From the SQ counters of a separate rocprofv3 --pmc pass over this launch
+    # (profiles/r04_sq_fixed50.json, attached only for the device sources it was measured on): VALU wave-instructions x 4 cycles of pipe
+    # occupancy each / cycles the waves were resident.  (A single wave per SIMD cannot issue fp64 back to back: tools/probes/mfma64.hip
+    # measures 6.5 ticks per independent v_fma_f64 alone and the same per wave with two waves per SIMD -- half the pipe is the ceiling of
+    # this residency, which the 512-register chain tier forces.)
+    if not large:
+        try:
+            sq = json.load(open(os.path.join(ROOT, "profiles", "r04_sq_fixed50.json")))
+            if sq.get("csrc_sha") == sha and B == 4096 and args.iters == 50 and args.config == "M":
+                ir = sq["issue_roof"]
+                res["roofline"]["issue"] = {"bound": "fp64 VALU issue (one wavefront per SIMD)", "achieved": ir["pipe_cycles_at_4_per_inst"], "peak": ir["wave_cycles"],
+                                            "unit": "cycles per launch (VALU wave-instructions x 4 / resident wave cycles)", "frac": ir["frac"],
+                                            "valu_wave_insts_per_problem": sq["per_problem"]["valu_wave_insts"], "valu_active_frac": ir.get("valu_active_frac"),
+                                            "single_wave_ceiling": 0.5, "source": "profiles/r04_sq_fixed50.json"}
+            else:
+                res["roofline"]["issue_note"] = "profiles/r04_sq_fixed50.json was measured on other device sources or another workload: not attached"
+        except Exception:
+            pass
     if traffic:
         res["roofline"]["traffic_over_alg"] = traffic / alg_bytes
 

@@ -82,11 +82,18 @@ __device__ __forceinline__ double bcast(double v, int lane)
 	return __hiloint2double(hi, lo);
 }
 // sums of KV per-lane values over the wavefront, every lane receives all of them
-template <int KV>
+// FEW: the interleaved rotation / permlane form for one to three values (solve_impl.hpp: wave_sums_few).  Measured: it pays on the instances
+// with one wave per SIMD (headline -0.5 %) and costs the two-waves-per-SIMD instances dearly (preconditioned solves 0.151 -> 0.178 ms per
+// 4096), so those keep the row_shr / row_bcast chains.
+template <int KV, bool FEW = false>
 __device__ __forceinline__ void wave_sums(double (&v)[KV], int lane)
 {
 	if constexpr (KV < 4) {
-		wave_sums_few<KV>(v);
+		if constexpr (FEW) wave_sums_few<KV>(v);
+		else {
+#pragma unroll
+			for (int k = 0; k < KV; k++) v[k] = wave_sum(v[k]);
+		}
 	} else {
 		double w[16];
 #pragma unroll
@@ -544,7 +551,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 				double ac[HG];
 #pragma unroll
 				for (int g2 = 0; g2 < HG; g2++) ac[g2] = dot(h[g2], v);
-				wave_sums<HG>(ac, lane);
+				wave_sums<HG, MINW == 1>(ac, lane);
 #pragma unroll
 				for (int g2 = 0; g2 < HG; g2++) {
 					const int i = base - 1 + g2;   // link i joins slot i (left) and slot i + 1 = base + g2 (right)
@@ -626,7 +633,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 		{
 			double bad[1] = {0.0};
 			for (int s = ln; s < D.nlic + D.nltc + D.nlfc; s += 64) if (lo[s] != up[s]) bad[0] += 1.0;
-			wave_sums<1>(bad, lane);
+			wave_sums<1, MINW == 1>(bad, lane);
 			if (bad[0] != 0.0) inform = 9;
 		}
 		double F = 0.0, gn2 = 0.0, alpha = 0.0, pnorm = 0.0;
@@ -691,9 +698,9 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 					NTGW_STAMPV(2, part[2]);
 				}
 #ifdef NTGW_DBL_RED3
-				{ double q_[3] = {part[0], part[1], part[2]}; asm volatile("" : "+v"(q_[0]), "+v"(q_[1]), "+v"(q_[2])); wave_sums<3>(q_, lane); asm volatile("" ::"s"(q_[0]), "s"(q_[1]), "s"(q_[2])); }
+				{ double q_[3] = {part[0], part[1], part[2]}; asm volatile("" : "+v"(q_[0]), "+v"(q_[1]), "+v"(q_[2])); wave_sums<3, MINW == 1>(q_, lane); asm volatile("" ::"s"(q_[0]), "s"(q_[1]), "s"(q_[2])); }
 #endif
-				wave_sums<3>(part, lane);
+				wave_sums<3, MINW == 1>(part, lane);
 				NTGW_STAMPV(6, part[0] + part[1] + part[2]);
 				const double Fn = part[0], gn2n = part[1];
 #ifdef NTGW_DEBUG
@@ -730,7 +737,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 					for (int k = 0; k < 4; k++) r4[k] = 0.0;
 #pragma unroll
 					for (int e = 0; e < EPL; e++) { r4[0] += gp[e] * d[e]; r4[1] += d[e] * d[e]; r4[2] += x[e] * x[e]; r4[3] += gp[e] * gp[e]; }
-					wave_sums<4>(r4, lane);
+					wave_sums<4, MINW == 1>(r4, lane);
 					NTGW_STAMP(4);
 					new_major = true;
 				} else {
@@ -769,7 +776,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 							double r2[2] = {0, 0};
 #pragma unroll
 							for (int e = 0; e < EPL; e++) { r2[0] += gp[e] * d[e]; r2[1] += d[e] * d[e]; }
-							wave_sums<2>(r2, lane);
+							wave_sums<2, MINW == 1>(r2, lane);
 							r4[0] = r2[0]; r4[1] = r2[1];
 							new_major = true;
 						} else {
@@ -812,7 +819,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 							r6[0] += s * y; r6[1] += y * u; r6[2] += s * gq; r6[3] += u * gq; r6[4] += s * s; r6[5] += y * y;
 							r6[6] += x[e] * x[e]; r6[7] += gq * gq;
 						}
-						wave_sums<8>(r6, lane);
+						wave_sums<8, MINW == 1>(r6, lane);
 						const bool upd = r6[0] > 1e-12 * sqrt(r6[4]) * sqrt(r6[5]);
 						const double rho = upd ? 1.0 / r6[0] : 0.0, c2 = upd ? rho * (1.0 + rho * r6[1]) : 0.0;
 						double dn[EPL];
@@ -854,7 +861,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 							gp[e] = gpt[e]; d[e] = dn[e];
 							r2[0] += gp[e] * d[e]; r2[1] += d[e] * d[e];
 						}
-						wave_sums<2>(r2, lane);
+						wave_sums<2, MINW == 1>(r2, lane);
 						r4[0] = r2[0]; r4[1] = r2[1]; r4[2] = r6[6]; r4[3] = r6[7];
 						F = Fn; gn2 = gn2n;
 						iter++;
@@ -878,7 +885,7 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 								double r2[2] = {0, 0};
 #pragma unroll
 								for (int e = 0; e < EPL; e++) { r2[0] += gp[e] * d[e]; r2[1] += d[e] * d[e]; }
-								wave_sums<2>(r2, lane);
+								wave_sums<2, MINW == 1>(r2, lane);
 								r4[0] = r2[0]; r4[1] = r2[1];
 								dphi0 = -r2[0]; pnorm = sqrt(r2[1]);
 							}

@@ -11,8 +11,9 @@ mkdir -p ../variants
 bases=$(cat fam_kincar_wave.abase 2>/dev/null || echo "16 16")
 set -- -DNTGW_ABASE=${bases% *} -DNTGW_ABASE_ALT=${bases#* } "$@"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -c fam_kincar_wave.hip -o ../variants/wave_$name.o -I ../../include -Wno-unused-result -Wno-unused-value -Wno-pass-failed -save-temps=obj -Wno-unused-command-line-argument "$@"
-asm=../variants/wave_$name-hip-amdgcn-amd-amdhsa-gfx950.s
-rm -f ../variants/wave_$name-hip-*.bc ../variants/wave_$name-hip-*.hipi ../variants/wave_$name-hip-*.o ../variants/wave_$name-hip-*.out ../variants/wave_$name-host-* ../variants/wave_$name.hip-*
+mv ../variants/fam_kincar_wave-hip-amdgcn-amd-amdhsa-gfx950.s ../variants/wave_$name.s
+asm=../variants/wave_$name.s
+rm -f ../variants/fam_kincar_wave-hip-* ../variants/fam_kincar_wave-host-* ../variants/fam_kincar_wave.hip-*
 cd /root/repo
 python - "$asm" <<'PY'
 import os, sys
