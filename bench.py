@@ -73,6 +73,22 @@ def physical_cores() -> int:
     return len(seen) or (os.cpu_count() or 1)
 
 
+def cpu_quota() -> float:
+    """CPUs this job may actually use: the cgroup's CPU quota (cpu.max / cfs_quota), 0 if unlimited.  The GPU boxes show all 256 hardware
+    threads of the host but give a one-GPU job 16 CPUs' worth of time: threads beyond the quota are throttled, not run (rounds 2-3 read the
+    resulting 11-12x "scaling" of 128 threads as a property of the oracle; it is the scheduler's)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return 0.0 if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 else 0.0
+    except (OSError, ValueError):
+        return 0.0
+
+
 def newton_mfma_entry(specL, key, cnt, nbL, dtl, MFMA_PEAK_TF):
     """matrix-core work of a structured-Newton launch from the kernel's own counters (factorisations, failed attempts)"""
     import numpy as np
@@ -105,7 +121,7 @@ def main():
                     help="M (headline) / B: kincar, fixed 50 majors; D (quadrotor) / E (manipulator): structured Newton mode to convergence, "
                          "BASELINE's batch of 4096 / 8192 problems sharded over the GPUs")
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="problems of the CPU baseline sample (0: 32 per physical core)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="problems of the CPU baseline sample (0: 96 per usable core)")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: --batch problems per GPU (default for M / B); strong: --batch problems in all, split over the GPUs (default for D / E)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -601,8 +617,10 @@ def main():
         import orc
         orc.set_scratch_reuse(True)
         nthreads_hw = os.cpu_count() or 1
-        ncore = min(physical_cores(), nthreads_hw)
-        ns = args.cpu_sample if args.cpu_sample > 0 else 32 * ncore
+        nphys = min(physical_cores(), nthreads_hw)
+        quota = cpu_quota()
+        ncore = max(1, min(nphys, int(quota))) if quota >= 1 else nphys   # threads = the cores this job can really run on
+        ns = args.cpu_sample if args.cpu_sample > 0 else 96 * ncore   # ~20 s of CPU work at config M (12 ms per problem and thread)
         ns = min(ns, lo_all.shape[0])
         if large:
             ns = min(ns, max(ncore // 8, 1) * 2)   # a D / E problem takes seconds to minutes of CPU time: a handful only
@@ -627,14 +645,29 @@ def main():
             dt1 = time.perf_counter() - t1
             flav[fl] = {"all_cores": ns / dta, "one_thread": n1 / dt1, "all_cores_problems": ns, "all_cores_wall_s": dta, "one_thread_problems": n1,
                         "one_thread_wall_s": dt1, "scaling_1_to_all_cores": (ns / dta) / (n1 / dt1)}
+            if not large and ncore >= 4:   # more points of the scaling curve (same problems per thread): half the usable cores, and (when a
+                # cgroup quota caps the job) four times as many threads as cores, to show the cap
+                for nth in sorted({max(ncore // 2, 1), min(4 * ncore, nphys)} - {ncore}):
+                    nsub = min(lo_all.shape[0], 32 * nth)
+                    t1 = time.perf_counter()
+                    orc.solve_batch(spec, lo_all[:nsub], up_all[:nsub], np.ones((nsub, spec.nC)), oo, nthreads=nth)
+                    flav[fl][f"threads_{nth}"] = nsub / (time.perf_counter() - t1)
             if fl == "ref":
                 r_ref = r
         res["cpu_baseline"] = {"value": flav["ref"]["all_cores"], "unit": "trajectories/s", "cores": ncore, "threads": ncore, "hardware_threads": nthreads_hw,
+                               "physical_cores_of_host": nphys, "cgroup_cpu_quota": quota or None,
                                "kind": "port",
-                               "sample": f"first {ns} problems of the same batch ({ns / ncore:.1f} per pinned thread, one thread per physical core), same solve mode, oracle/sqp.c with the "
+                               "sample": f"first {ns} problems of the same batch ({ns / ncore:.1f} per pinned thread, one thread per core the job may use), same solve mode, oracle/sqp.c with the "
                                          f"reference-faithful dense assembly, OpenMP, {flav['ref']['all_cores_wall_s']:.2f} s wall",
                                "flavours": flav, "cpu_model": model, "compiler": cflags,
-                               "malloc": "per-call dense temporaries from a reused per-thread buffer (orc_set_scratch_reuse): no mmap / munmap / page faults per call"}
+                               "malloc": "per-call dense temporaries and the dense quasi-Newton matrix from per-thread buffers that are reused from problem to problem and first "
+                                         "touched by their owner (orc_set_scratch_reuse): no mmap / munmap / page faults per call"}
+        try:
+            cpus = orc.thread_cpus(ncore)
+            res["cpu_baseline"]["affinity"] = {"distinct_cpus": len(set(cpus)), "min_cpu": min(cpus), "max_cpu": max(cpus), "first_8_threads_on": cpus[:8],
+                                               "OMP_PLACES": os.environ.get("OMP_PLACES"), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND")}
+        except Exception as e:   # noqa: BLE001
+            res["cpu_baseline"]["affinity"] = str(e)
         # same inputs -> same answers (oracle is the checker here, never the thing shipped)
         nchk = min(ns, B)
         gobj = out["objective"][:nchk].cpu().numpy()

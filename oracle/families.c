@@ -1,3 +1,5 @@
+#define _GNU_SOURCE
+#include <sched.h>
 /*
  * oracle/families.c -- TEST INFRASTRUCTURE ONLY (CPU oracle, see oracle.h).
  *
@@ -271,6 +273,16 @@ static orc_problem *make_from_spec(const orc_batch_spec *s, const double *lowerb
 	return p;
 }
 static int spec_nb(const orc_batch_spec *s) { return s->nlic + s->nltc + s->nlfc + s->nnlic + s->nnltc + s->nnlfc; }
+
+/* where the OpenMP threads of the batch drivers run: cpus[t] = the CPU thread t is on (sched_getcpu), for the bench line's affinity note */
+int orc_thread_cpus(int nthreads, int *cpus)
+{
+	int t;
+	if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+	for (t = 0; t < nthreads; t++) cpus[t] = sched_getcpu();
+	return 0;
+}
 
 int orc_solve_batch(const orc_batch_spec *s, int batch, const double *lowerb, const double *upperb,
                     double *x, const orc_sqp_opts *o, double *objective, int *inform, int *iters,

@@ -258,6 +258,7 @@ void orc_integrate_cols(double *I, const double *f, int rows, int cols, const do
 static int orc_scratch_reuse = 0;
 static __thread struct { char *base; size_t cap, top; } orc_arena;
 void orc_set_scratch_reuse(int on) { orc_scratch_reuse = on; }
+int orc_scratch_reuse_on(void) { return orc_scratch_reuse; }
 static void orc_tmp_reset(void) { orc_arena.top = 0; }
 static void *orc_tmp_malloc(size_t bytes)
 {

@@ -105,6 +105,8 @@ void orc_bounds(double *bbar, const double *b, int nc, int nlic, int nltc, int n
 /* NPSOL-facing callbacks (ntg.c:274-371) */
 /* timed CPU baseline only: serve the per-call dense temporaries from a reused per-thread buffer (see ntg_oracle.c) */
 void orc_set_scratch_reuse(int on);
+int orc_scratch_reuse_on(void);
+int orc_thread_cpus(int nthreads, int *cpus);
 void orc_funobj(orc_problem *p, int *mode, const double *x, double *f, double *g, int *nstate);
 void orc_funcon(orc_problem *p, int *mode, const double *x, double *c, double *cJac, int *nstate);
 void orc_linspace(double *v, double d0, double d1, int n);

@@ -37,6 +37,8 @@
 #include <stdio.h>
 #include "oracle.h"
 
+static __thread double *tl_W; static __thread size_t tl_Wcap;   /* see orc_sqp_solve: per-thread buffer of the dense W (timed CPU baseline only) */
+
 void orc_sqp_default_opts(orc_sqp_opts *o)
 {
 	o->itlim = 0; o->opttol = 0.0; o->steplimit = 2.0; o->ls_mu = 1e-4; o->ls_eta = 0.9;
@@ -696,7 +698,14 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 	newton = (o->hessian == 2) && nwt_applicable(p, nI, AE, m);
 	if (o->hessian == 2 && !newton) hess = 1;
 
-	W = newton ? NULL : malloc((size_t)n * n * sizeof(double));
+	/* the dense quasi-Newton matrix (NPSOL keeps R, n x n): 1.1 MB for config M.  Under orc_set_scratch_reuse (the timed multi-threaded CPU
+	 * baseline only) it comes from a buffer the THREAD keeps from problem to problem: first touched by its owner (NUMA-local), no mmap /
+	 * munmap / 280 page faults per problem under the process-wide address-space lock; the arithmetic is the same */
+	if (newton) W = NULL;
+	else if (orc_scratch_reuse_on()) {
+		if (tl_Wcap < (size_t)n * n) { free(tl_W); tl_W = malloc((size_t)n * n * sizeof(double)); tl_Wcap = tl_W ? (size_t)n * n : 0; }
+		W = tl_W;
+	} else W = malloc((size_t)n * n * sizeof(double));
 	t_x = calloc(nal + 1, sizeof(double));
 	g = malloc(n * sizeof(double)); gp = malloc(n * sizeof(double)); gn = malloc(n * sizeof(double));
 	gpn = malloc(n * sizeof(double)); d = malloc(n * sizeof(double)); pdir = malloc(n * sizeof(double));
@@ -944,7 +953,8 @@ done:
 	nwt_free(nw); free(t_x);
 #undef APPLY_W
 #undef RESET_W
-	free(W); free(W0); free(g); free(gp); free(gn); free(gpn); free(d); free(pdir); free(xt);
+	if (W != tl_W) free(W);
+	free(W0); free(g); free(gp); free(gn); free(gpn); free(d); free(pdir); free(xt);
 	free(s); free(y); free(u); free(t); free(lam); free(pj.S); free(pj.tmpm);
 	free(al.lam); free(al.tnew); free(al.c); free(erow); free(irow); free(AE); free(bE);
 }

@@ -187,3 +187,11 @@ def solve_one(spec, lowerb, upperb, x0, opts=None, trace_cap=0, want_R=False, wa
     return dict(x=x, objective=res.objective, inform=res.inform, iters=res.iters, nfev=res.nfev,
                 pg_norm=res.pg_norm, feas=res.feas, clambda=clam, istate=ist,
                 R=(R.T.copy() if want_R else None), trace=tr[:min(trace_cap, res.iters)])
+
+
+def thread_cpus(nthreads: int):
+    """CPU each OpenMP thread of the batch drivers runs on (sched_getcpu): the affinity note of bench.py's cpu_baseline"""
+    import ctypes as C
+    arr = (C.c_int * nthreads)()
+    lib().orc_thread_cpus(nthreads, arr)
+    return list(arr)
