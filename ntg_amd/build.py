@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libntg_amd.so")
 SOURCES = ["kernels.hip", "grids.hip", "fam_kincar.hip", "fam_kincar_chm.hip", "fam_kincar_wave.hip", "fam_vanderpol.hip", "fam_testfam.hip", "fam_obstacle.hip", "fam_quadrotor.hip",
            "fam_manip.hip", "plan.cpp", "ntg_host.cpp"]
-HEADERS = ["ntg_dev.hpp", "solve_impl.hpp", "newton.hpp", "eval_fast.hpp", "solve_wave.hpp", "families.hpp", "linesearch.hpp", "plan.hpp", "../../include/ntg_amd.h", "../../include/ntg.h"]
+HEADERS = ["ntg_dev.hpp", "solve_impl.hpp", "newton.hpp", "qpdual.hpp", "eval_fast.hpp", "solve_wave.hpp", "families.hpp", "linesearch.hpp", "plan.hpp", "../../include/ntg_amd.h", "../../include/ntg.h"]
 
 
 BASES = os.path.join(CSRC, "fam_kincar_wave.abase")   # accumulator bases (main, alt) the wave-kernel object on disk was compiled with

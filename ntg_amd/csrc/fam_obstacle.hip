@@ -16,6 +16,10 @@ hipError_t ntg_launch_sqp_obstacle(const NtgDims &D, const NtgTables &T, const S
 	const bool small = (a.nt == 128 || a.nt == 256) && ntg_all_d(D, 3);
 	const int ku = ntg_uniform_order(D, a.nt, 4);
 	(void)ku;
+	if (small && !a.big && D.nout == 2 && ku == 6 && sp.hessian == 3) {   // QP-based SQP step on the band model (qpdual.hpp)
+		if (a.nt == 128) return launch_sqp_one<NTG_FAM_OBSTACLE, 2, 6, 128, 4, false, true, 0, true, true>(D, T, L, sp, a);
+		return launch_sqp_one<NTG_FAM_OBSTACLE, 2, 6, 256, 4, false, true, 0, true, true>(D, T, L, sp, a);
+	}
 	if (small && !a.big && D.nout == 2 && ku == 6 && sp.hessian == 2) {   // structured Newton mode (newton.hpp)
 		if (a.nt == 128) return launch_sqp_one<NTG_FAM_OBSTACLE, 2, 6, 128, 4, false, true, 0, true>(D, T, L, sp, a);
 		return launch_sqp_one<NTG_FAM_OBSTACLE, 2, 6, 256, 4, false, true, 0, true>(D, T, L, sp, a);

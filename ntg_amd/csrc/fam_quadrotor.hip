@@ -15,6 +15,10 @@ hipError_t ntg_launch_eval_quadrotor(const NtgDims &D, const NtgTables &T, const
 hipError_t ntg_launch_sqp_quadrotor(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
 	if (a.nt == 256 && ntg_all_d(D, 5) && D.nout == 4 && ntg_uniform_order(D, 256, 4) == 8) {
+		if (sp.hessian == 3) {   // QP-based SQP step on the band model (qpdual.hpp)
+			if (!a.big) return launch_sqp_one<NTG_FAM_QUADROTOR, 4, 8, 256, 4, false, true, 0, true, true>(D, T, L, sp, a);
+			return launch_sqp_generic<NTG_FAM_QUADROTOR>(D, T, L, sp, a);
+		}
 		if (sp.hessian == 2) {   // structured Newton mode (newton.hpp)
 			if (a.big) return launch_sqp_one<NTG_FAM_QUADROTOR, 4, 8, 256, 4, true, true, 0, true>(D, T, L, sp, a);
 			return launch_sqp_one<NTG_FAM_QUADROTOR, 4, 8, 256, 4, false, true, 0, true>(D, T, L, sp, a);

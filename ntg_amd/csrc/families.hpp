@@ -41,6 +41,7 @@ struct DenseTraj {
 };
 
 template <> struct Family<NTG_FAM_KINCAR> {
+	static __device__ __forceinline__ int row_group(int j) { (void)j; return 0; }   // coupling group of trajectory row function j (QP-based SQP step)
 	static constexpr int DM = 3, TAPE = 1;
 	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = true;   // ucf(nout, ...) is a sum of identical terms over the outputs: a subset of the outputs gives its share
@@ -66,6 +67,7 @@ template <> struct Family<NTG_FAM_KINCAR> {
 };
 
 template <> struct Family<NTG_FAM_VANDERPOL> {
+	static __device__ __forceinline__ int row_group(int j) { (void)j; return 0; }   // coupling group of trajectory row function j (QP-based SQP step)
 	static constexpr int DM = 3, TAPE = 1;
 	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = false;
@@ -92,6 +94,7 @@ template <> struct Family<NTG_FAM_VANDERPOL> {
 
 // dc is [ncon][nz] row-major (== the reference's dc[constraint][variable])
 template <> struct Family<NTG_FAM_TESTFAM> {
+	static __device__ __forceinline__ int row_group(int j) { (void)j; return 0; }   // coupling group of trajectory row function j (QP-based SQP step)
 	static constexpr int DM = 3, TAPE = 1;
 	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = false;
@@ -158,6 +161,7 @@ template <> struct Family<NTG_FAM_TESTFAM> {
 };
 
 template <> struct Family<NTG_FAM_OBSTACLE> {
+	static __device__ __forceinline__ int row_group(int j) { (void)j; return 0; }   // coupling group of trajectory row function j (QP-based SQP step)
 	static constexpr int DM = 3, TAPE = 1;
 	static constexpr u64 TCON_VARS = ~0ull;   // flag entries a trajectory constraint row can depend on (all: not declared)
 	static constexpr bool PER_OUTPUT_COST = false;
@@ -186,6 +190,7 @@ template <> struct Family<NTG_FAM_OBSTACLE> {
 };
 
 template <> struct Family<NTG_FAM_QUADROTOR> {
+	static __device__ __forceinline__ int row_group(int j) { (void)j; return 0; }   // coupling group of trajectory row function j (QP-based SQP step)
 	static constexpr int DM = 5, TAPE = 1;
 	// flag entries (5 o + r) a trajectory constraint row can depend on: first and second derivatives of x, y, z
 	static constexpr u64 TCON_VARS = (1ull << 1) | (1ull << 2) | (1ull << 6) | (1ull << 7) | (1ull << 11) | (1ull << 12);
@@ -243,6 +248,7 @@ template <> struct Family<NTG_FAM_QUADROTOR> {
 
 constexpr u64 ntg_manip_vars(int narms) { u64 m = 0; for (int j = 0; j < narms && 9 * j + 6 < 64; j++) m |= (1ull << (9 * j)) | (1ull << (9 * j + 3)) | (1ull << (9 * j + 6)); return m; }
 template <> struct Family<NTG_FAM_MANIP> {
+	static __device__ __forceinline__ int row_group(int j) { (void)j; return j; }   // coupling group of trajectory row function j (QP-based SQP step)
 	static constexpr int DM = 3;
 	static constexpr bool PER_OUTPUT_COST = false;
 	static constexpr int MAXARMS = NTG_MAX_OUT / 3, TAPE = 3 * (NTG_MAX_OUT / 3);

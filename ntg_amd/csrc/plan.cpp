@@ -17,6 +17,7 @@
 #include <utility>
 #include "ntg_dev.hpp"
 #include "plan.hpp"
+#include "qpdual.hpp"
 
 static int build_newton_tables(ntg_plan *p);
 static thread_local std::string g_err;
@@ -833,7 +834,11 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	// the structured Newton mode does not apply (or: per-problem grids -- its cost model and maps belong to the plan's grid): collocation
 	// preconditioner.  Decided HERE, once: workspace size, layout and launch all see the same mode (a switch after the workspace was sized
 	// for hessian = 2 -- no quasi-Newton history -- would let the quasi-Newton mode write its history past the end of the workspace).
-	if (sp->hessian == 2 && (!D.nwt_on || p->grid_batch)) sp->hessian = 1;
+	if (sp->hessian < 0 || sp->hessian > 3) sp->hessian = 0;
+	// the QP-based SQP step (hessian = 3) rides on the structured Newton mode's band model: where that does not apply it does not either;
+	// a warm start of the multipliers (receding horizon) belongs to the augmented-Lagrangian passes of mode 2
+	if (sp->hessian == 3 && sp->warm) sp->hessian = 2;
+	if (sp->hessian >= 2 && (!D.nwt_on || p->grid_batch)) sp->hessian = 1;
 	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
 	sp->sr = std::sqrt(r);
@@ -844,7 +849,7 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	// the structured Newton mode runs one wavefront per coupling group: a workgroup too small for the plan's groups grows to hold them, and a
 	// plan with more groups than the largest workgroup has waves takes the collocation preconditioner (decided here, once: workspace, layout
 	// and launch all see the same mode)
-	if (sp->hessian == 2) {
+	if (sp->hessian >= 2) {
 		const int nwv = (D.nwt_tw ? 2 : 1) * D.nwt_ngrp + D.nwt_nfo;   // two waves per group with the two-sided factorisation
 		while (t < 512 && nwv * 64 > t) t *= 2;
 		if (nwv * 64 > t) sp->hessian = 1;
@@ -857,29 +862,32 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 static int solve_layout(const NtgDims &D, int nt, SmemLayout *L, int *big, const SolveParams *sp = nullptr)
 {
 	// a short quasi-Newton memory keeps its pair scalars in LDS -- unless those bytes would cost a resident workgroup
-	const int hrc = (sp && sp->hessian != 2 && sp->memcap < NTG_HRC_LDS) ? sp->memcap + 1 : 0;   // + 1: the one-vector-per-major form wants a slot more than pairs
+	const int hrc = (sp && sp->hessian < 2 && sp->memcap < NTG_HRC_LDS) ? sp->memcap + 1 : 0;   // + 1: the one-vector-per-major form wants a slot more than pairs
 	auto resident = [](int total) { return (160 * 1024) / std::max(total, 1); };
 	*big = 0;
-	*L = ntg_make_layout(D, nt, 5, 1, hrc);
-	if (hrc && resident(L->total) < resident(L->total - 16 * hrc)) *L = ntg_make_layout(D, nt, 5, 1, 0);
+	const int qp = (sp && sp->hessian == 3) ? 1 : 0;   // the QP-based SQP step keeps its slots behind the Newton mode's solve vectors
+	*L = ntg_make_layout(D, nt, 5, 1, hrc, qp);
+	if (hrc && resident(L->total) < resident(L->total - 16 * hrc)) *L = ntg_make_layout(D, nt, 5, 1, 0, qp);
 	if (L->total <= 160 * 1024) return 0;
 	*big = 1;
-	*L = ntg_make_layout(D, nt, 1, 0, hrc);
-	if (hrc && L->total > 160 * 1024) *L = ntg_make_layout(D, nt, 1, 0, 0);
+	*L = ntg_make_layout(D, nt, 1, 0, hrc, qp);
+	if (hrc && L->total > 160 * 1024) *L = ntg_make_layout(D, nt, 1, 0, 0, qp);
 	return L->total <= 160 * 1024 ? 0 : -1;
 }
 static size_t hist_doubles(const NtgDims &D, int batch, const SolveParams &sp)
 {
-	if (sp.hessian == 2) return 0;   // the structured Newton mode keeps no quasi-Newton pairs
+	if (sp.hessian >= 2) return 0;   // the structured Newton mode keeps no quasi-Newton pairs
 	return (size_t)batch * sp.memcap * (2 * D.nC + 2);
 }
 static size_t al_doubles(const NtgDims &D, int batch) { return (size_t)batch * 2 * (D.ncnln + D.nI); }
 // structured Newton mode: band matrix / factor of every group + the per-breakpoint blocks, per problem
 static size_t nwt_doubles(const NtgDims &D, int batch, const SolveParams &sp)
 {
-	if (sp.hessian != 2 || !D.nwt_on) return 0;
+	if (sp.hessian < 2 || !D.nwt_on) return 0;
 	const size_t rev = D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0;   // the reversed arrays of the two-sided factorisation
-	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + rev + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg);
+	// QP-based SQP step: the slots' columns W J' and the QP's multipliers (sqp_kernel, qp_pp)
+	const size_t qp = sp.hessian == 3 ? (size_t)NTG_QP_MAXA * ((D.nC + 1) & ~1) + (size_t)((D.ncnln + 1) & ~1) : 0;
+	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + rev + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg + qp);
 }
 
 static int plan_ncu(const ntg_plan *p)
@@ -1003,7 +1011,7 @@ extern "C" int ntg_batch_solve(const ntg_plan *pc, int batch, const double *d_lo
 	double *vecw = alw + al_doubles(p->D, batch);                     // [batch][5][npad] x, gp, gp+, d, g (BIG only)
 	double *nwtw = vecw + (big ? (size_t)batch * 5 * ((p->D.nC + 1) & ~1) : 0);   // structured Newton mode: bands and blocks
 	SqpArgs sa{nt, big, batch, d_lower, d_upper, d_x, d_objective, d_inform, d_iters, d_nfev, d_clambda, (double *)d_work, alw,
-	           big ? vecw : nullptr, sp.hessian == 2 ? nwtw : nullptr, (hipStream_t)stream,
+	           big ? vecw : nullptr, sp.hessian >= 2 ? nwtw : nullptr, (hipStream_t)stream,
 	           (unsigned int *)((char *)d_work + ((ntg_batch_workspace_bytes(p, batch, o) - 256) & ~(long long)7))};
 	NtgWavePlan wp;
 	if (wave_takes(p, sp, batch, &wp)) {   // one wavefront per problem

@@ -43,7 +43,7 @@ void ntg_plan_dense_A(const ntg_plan *p, double *A);
 //   eval_kernel   nvec 0 (the gradient is assembled into the x buffer once x is no longer needed)
 //   host path     nvec 1
 //   sqp_kernel    nvec 5 (xt, gp, gp+, d, g) with x -- or, BIG, nvec 1 (xt) without x: the rest lives in HBM/L2
-SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x, int hrc_pairs = 0);
+SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x, int hrc_pairs = 0, int qp = 0);
 hipError_t ntg_launch_eval(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const EvalArgs &a);
 hipError_t ntg_launch_sqp(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a);
 // one wavefront per problem (solve_wave.hpp, fam_kincar_wave.hip): does it take this solve, and its launch shape / HBM workspace

@@ -8,6 +8,7 @@
 #include "ntg_dev.hpp"
 #include "families.hpp"
 #include "linesearch.hpp"
+#include "qpdual.hpp"
 
 // tuning knobs: minimum waves per SIMD the register allocator must leave room
 // for, and how many quasi-Newton pairs one reduction round of apply_history covers
@@ -508,11 +509,21 @@ struct ALState {
 	const double *lam;   // [ncnln] current multipliers (HBM)
 	double *tnew;        // [ncnln] multiplier estimates of the last evaluation (HBM)
 	const double *lo, *up; // this problem's rows of lowerb/upperb [nbounds]
+	// QP-based SQP step (ntg_solve_opts.hessian = 3, qpdual.hpp): 1 = the evaluation returns the l1 merit function F + mu sum_j viol_j with the
+	// gradient of F alone, and tnew receives the row VALUES c_j (what the QP subproblem linearises); 2 = the gradient of the Lagrangian
+	// with the multipliers lam (the final pass that recovers the linear rows' multipliers), tnew receives lam.  0 = augmented Lagrangian.
+	int qp;
 };
 
 // one constraint value -> multiplier estimate t; adds the row's augmented-Lagrangian term and squared scaled residual
-__device__ __forceinline__ double al_row(double mu, double lamj, double l, double u, double cj, double &psi, double &rv2)
+__device__ __forceinline__ double al_row(double mu, double lamj, double l, double u, double cj, double &psi, double &rv2, int qp = 0)
 {
+	if (qp) {   // l1 merit: weight mu on the violation of the row's bounds; the same scaled residual as below for a feasible row with lam = 0
+		const double pc = cj < l ? l : (cj > u ? u : cj), rc = (cj - pc) / (1.0 + fabs(cj));
+		psi += mu * fabs(cj - pc);
+		rv2 += rc * rc;
+		return qp == 2 ? lamj : 0.0;
+	}
 	const double v = cj + lamj / mu;
 	const double pj = v < l ? l : (v > u ? u : v);
 	// c - p: |c - b| for an active row, min(slack, lam/mu) for a feasible one -- zero only when feasibility AND
@@ -566,8 +577,8 @@ __device__ __forceinline__ void cost_phase1(const NtgDims &D, const Smem &S, con
 	psi = 0.0; rv2 = 0.0;
 	// one constraint value -> AL term, violation, multiplier estimate; returns t
 	auto al_term = [&](double cj, int row, int slot) -> double {
-		const double t = al_row(al.mu, al.lam[row], al.lo[slot], al.up[slot], cj, psi, rv2);
-		al.tnew[row] = t;
+		const double t = al_row(al.mu, al.lam[row], al.lo[slot], al.up[slot], cj, psi, rv2, al.qp);
+		al.tnew[row] = al.qp == 1 ? cj : t;
 		return t;
 	};
 	lds_sync(); // sx complete, previous users of dfz/fvals done
@@ -1562,7 +1573,9 @@ __device__ __forceinline__ void apply_dform(const NtgDims &D, const Smem &S, con
 // a pass on the objective alone (mu = 0, "phase 0") before the augmented-Lagrangian passes.
 // (The Newton instances of 256 lanes run one wave per SIMD anyway -- one workgroup per CU, by LDS -- and are compiled for it: the
 // inlined factorisation and assembly then keep their window tiles and addresses in registers instead of scratch.)
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS, int CHM, bool NWT = false>
+// QPM (with NWT): the QP-based SQP step (ntg_solve_opts.hessian = 3, qpdual.hpp) replaces the augmented-Lagrangian
+// passes after phase 0.
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS, int CHM, bool NWT = false, bool QPM = false>
 __global__ void __launch_bounds__(NT, (NWT && NT <= 256) ? 1 : NTG_SQP_WAVES)
 sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
            const double *__restrict__ lower, const double *__restrict__ upper, double *__restrict__ xio,
@@ -1594,7 +1607,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	CoefMap<EPT> cm;
 	if (NOUT > 0) make_coefmap<NT, EPT>(D, S, cm);
 
-	enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3, ST_REEVAL = 4 };
+	enum { ST_INIT = 0, ST_LS = 1, ST_FORCE = 2, ST_FINAL = 3, ST_REEVAL = 4, ST_QP = 5 /* QP-based SQP step: evaluation of the l1 merit function */ };
 	using Fam = Family<FAM>;
 	constexpr bool HASCON = Fam::NNLIC + Fam::NNLTC + Fam::NNLFC > 0;
 	const int ncn = D.ncnln;
@@ -1622,8 +1635,11 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	constexpr int NWT_CG2 = FamN::CG * FamN::CG;
 	// per problem: the groups' band arrays, [two-sided factorisation: their reversed arrays,] the per-breakpoint blocks
 	const size_t nwt_ksz = (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0);
-	double *nwt_K = NWT ? nwt_all + (size_t)b * (nwt_ksz + (size_t)D.nwt_ngrp * D.P * NWT_CG2) : nullptr;
+	// (QP-based SQP step: + the slots' columns U = W J' [NTG_QP_MAXA][npad] and the QP's multipliers of the previous major iteration [ncnln])
+	const size_t qp_pp = QPM ? (size_t)NTG_QP_MAXA * npad + (size_t)((D.ncnln + 1) & ~1) : 0;
+	double *nwt_K = NWT ? nwt_all + (size_t)b * (nwt_ksz + (size_t)D.nwt_ngrp * D.P * NWT_CG2 + qp_pp) : nullptr;
 	double *nwt_B = NWT ? nwt_K + nwt_ksz : nullptr;
+	double *qp_U = NWT ? nwt_B + (size_t)D.nwt_ngrp * D.P * NWT_CG2 : nullptr, *qp_lamq = NWT ? qp_U + (size_t)NTG_QP_MAXA * npad : nullptr;
 	const NwtPair nwt_q{D.nwt_ng, D.nwt_hb, D.nwt_ja, D.nwt_jb};
 	const int nwt_lena = 16 * (D.nwt_ja + 3) + 48, nwt_lenb = 16 * (D.nwt_jb + 3) + 48;
 	// LDS of the mode (the area at L.nwt_y): the groups' solve vectors, the factorisation panels (one per factoring wave), the free outputs' vectors
@@ -1635,24 +1651,26 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	int *nwt_flag = (int *)(smem_raw + L.red) + 2 * (32 * (NT / 64) + 2) - 2;   // last word pair of the reduction scratch: "not positive definite"
 	// K = model at the trial point buffer `xs` (must be the iterate x; needs the multiplier estimates al_t of the evaluation
 	// at x), factored; then out = W v.  allow_curv = false: Gauss-Newton terms only.
-	auto nwt_refresh = [&](const double *xs, bool allow_curv) {
+	// tsrc / mu_gn: the multipliers of the curvature term and the weight of the Gauss-Newton term -- the estimates al_t and the penalty al.mu
+	// for the augmented Lagrangian; the QP's multipliers al_lam and 0 for the QP-based SQP step (the Lagrangian's Hessian on the band)
+	auto nwt_refresh_ex = [&](const double *xs, bool allow_curv, const double *tsrc, double mu_gn, bool blocks) __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, P2 = D.P;
 		const int wave = tid >> 6;
 		unsigned long long *nwt_act = (unsigned long long *)((double *)(smem_raw + L.nwt_y) + (NT / 64) * 216);   // after the assembly's staging buffers
 		double *panel = (double *)(smem_raw + L.nwt_y) + nwt_yall;
-		for (int attempt = (allow_curv && al.mu > 0.0) ? 0 : 1; attempt < 2; attempt++) {
+		for (int attempt = (allow_curv && blocks) ? 0 : 1; attempt < 2; attempt++) {
 			const bool curv = attempt == 0;
-			if (al.mu > 0.0) {
+			if (blocks) {
 				constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ, NTc = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
 				lds_sync();
 				for (int i = tid; i < P2; i += NT) {
 					double z[NZ], t[NTc];
 					compute_z<NOUT, K, DM>(D, S, xs, i, D.tcon_mask, z);
 #pragma unroll
-					for (int j = 0; j < NTc; j++) t[j] = j < D.nnltc ? al_t[D.nnlic + j * P2 + i] : 0.0;
+					for (int j = 0; j < NTc; j++) t[j] = j < D.nnltc ? tsrc[D.nnlic + j * P2 + i] : 0.0;
 					for (int g = 0; g < ngp; g++) {
 						double Bk[NWT_CG2];
-						FamN::template nltc_block<NZ>(NOUT > 0 ? NOUT : D.nout, g, z, t, al.mu, curv, Bk);
+						FamN::template nltc_block<NZ>(NOUT > 0 ? NOUT : D.nout, g, z, t, mu_gn, curv, Bk);
 						bool nzb = false;
 #pragma unroll
 						for (int e = 0; e < NWT_CG2; e++) { nwt_B[((size_t)g * P2 + i) * NWT_CG2 + e] = Bk[e]; nzb = nzb || Bk[e] != 0.0; }
@@ -1666,7 +1684,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			NTG_STAMP(6);
 			if (tid == 0) nwt_flag[0] = 0;
-			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, al.mu > 0.0 ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), NTG_CLOCK_TK(sp.stamps == 4));   // ends with a full barrier
+			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, blocks ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), NTG_CLOCK_TK(sp.stamps == 4));   // ends with a full barrier
 			NTG_STAMP(3);
 			if (D.nwt_tw) {   // two waves per group (wave uniform: every wave takes this branch)
 				const int f = nwt_factor_pairs(nwt_K, nwt_K + (size_t)ngp * ng * (hb + 1), ngp, nwt_q, panel, curv ? 1 : 0, nwt_flag);
@@ -1684,7 +1702,15 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			nwt_nfail++;
 		}
 	};
-	auto nwt_apply = [&](const double *v, double *out) {
+	auto nwt_refresh = [&](const double *xs, bool allow_curv) __attribute__((always_inline)) { nwt_refresh_ex(xs, allow_curv, al_t, al.mu, al.mu > 0.0); };
+	// restore = false: the caller keeps using the borrowed area (the QP-based SQP step's slots live behind the solve vectors) and puts
+	// the zero padding of the weighted-gradient rows back itself (nwt_restore)
+	auto nwt_restore = [&]() __attribute__((always_inline)) {
+		for (int r = tid; r < L.dfz_rows; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;
+		for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[L.dfz_rows * (D.P + 1) + i] = 0.0;
+		lds_sync();
+	};
+	auto nwt_apply = [&](const double *v, double *out, bool restore = true) __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ylen = 16 * ((ng + 15) >> 4) + 48;
 		const int wave = tid >> 6;
 		double *yv = (double *)(smem_raw + L.nwt_y);
@@ -1733,9 +1759,266 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		}
 		if (BIG) __syncthreads(); else lds_sync();
 		// the area borrowed from the weighted-gradient rows goes back with its zero padding restored (stage_tables)
-		for (int r = tid; r < L.dfz_rows; r += NT) S.dfz[r * (D.P + 1) + D.P] = 0.0;
-		for (int i = tid; i < ntg_dfz_tail(D); i += NT) S.dfz[L.dfz_rows * (D.P + 1) + i] = 0.0;
-		lds_sync();
+		if (restore) nwt_restore();
+	};
+
+	// =====================================================================================================================
+	// QP-based SQP step on the band model (QPM; ntg_solve_opts.hessian = 3; qpdual.hpp).  Per major iteration:
+	//   K = cost model + sum_j lam_j d2c_j/dz2 on the band (nwt_refresh_ex with the QP's multipliers), factored;
+	//   the dual active-set QP of every coupling group on its SLOTS (rows in the working set): a row enters when the model step violates
+	//   its linearised bound most; its column U = W J' is ONE band solve (the groups' entering rows share the solve: W is block diagonal
+	//   by group), its entries of S = J W J' are products of derivative rows with Z = M U at the slots' breakpoints; the passive-set
+	//   solves are scalar code on the group's slots in LDS (qp_passive_solve, one lane per group);
+	//   p = -W g - sum_a lam_a U_a.
+	// The line search backtracks on the l1 merit function, which the one evaluation site returns in this mode (ALState::qp).
+	// =====================================================================================================================
+	constexpr int QA = NTG_QP_MAXA;
+	typedef QpSlotsT<double *, int *> QpSlots;
+	const int qp_ylenf = 16 * ((D.nwt_ngf + 15) >> 4) + 48;
+	double *qpbase = (double *)(smem_raw + L.nwt_y) + nwt_yall + nwt_npan * NWT_PANEL + D.nwt_nfo * qp_ylenf;
+	double *qpred = qpbase + D.nwt_ngrp * NTG_QP_DOUBLES;   // [waves][rows per breakpoint][2] scratch of the entering-row search
+	double qp_rho = 1.0, qp_phi0 = 0.0, qp_D = 0.0, qp_alpha = 1.0, qp_viol1 = 0.0, qp_pn = 0.0, qp_xn = 0.0, qp_lmax = 0.0;
+	int qp_k = 0, qp_over = 0, qp_nsolve = 0, qp_ncol = 0;
+	bool qp_first = true;
+	(void)qp_over; (void)qp_nsolve; (void)qp_ncol;
+	// flag entry (index into z) of variable u of group g
+	auto qp_flag = [&](int g, int u) __attribute__((always_inline)) { return FamN::DM * (g * D.nwt_go + (int)((D.nwt_upack >> (8 * u + 4)) & 15u)) + (int)((D.nwt_upack >> (8 * u)) & 15u); };
+	// derivative row of trajectory row j at breakpoint i (the group's CG flag entries) and the row's value, at the iterate x (sx)
+	auto qp_row_a = [&](int g, int j, int i, double *ar, double &cj) __attribute__((always_inline)) {
+		constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ, NTc = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
+		double z[NZ], df[NZ], c[NTc], t[NTc], tape[FamN::TAPE];
+		compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
+		FamN::template nltc_val<NZ>(NOUT > 0 ? NOUT : D.nout, i, z, c, tape);
+#pragma unroll
+		for (int v = 0; v < NZ; v++) df[v] = 0.0;
+#pragma unroll
+		for (int jj = 0; jj < NTc; jj++) t[jj] = jj == j ? 1.0 : 0.0;
+		FamN::template nltc_vjp<NZ>(NOUT > 0 ? NOUT : D.nout, D.nz, i, z, t, df, tape);
+		cj = 0.0;
+#pragma unroll
+		for (int jj = 0; jj < NTc; jj++) if (jj == j) cj = c[jj];
+		for (int u = 0; u < FamN::CG; u++) {
+			const int fl = qp_flag(g, u);
+			double a = 0.0;
+#pragma unroll
+			for (int v = 0; v < NZ; v++) if (v == fl) a = df[v];
+			ar[u] = a;
+		}
+	};
+	// J_row . vec  for a slot's row: derivative row times Z = M vec at the row's breakpoint
+	auto qp_row_dot = [&](int g, const double *ar, int i, const double *vec) __attribute__((always_inline)) {
+		constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
+		double z[NZ];
+		compute_z<NOUT, K, DM>(D, S, vec, i, D.tcon_mask, z);
+		double acc = 0.0;
+		for (int u = 0; u < FamN::CG; u++) {
+			const int fl = qp_flag(g, u);
+			double zv = 0.0;
+#pragma unroll
+			for (int v = 0; v < NZ; v++) if (v == fl) zv = z[v];
+			acc += ar[u] * zv;
+		}
+		return acc;
+	};
+	// derivative rows, J W g and r = bound - c of the slots [a0, ns) of every group (one lane per slot); Wg lives in sd
+	auto qp_slot_rows = [&](bool only_new) __attribute__((always_inline)) {
+		const int ngp = D.nwt_ngrp, b0 = D.nlic + D.nltc + D.nlfc + D.nnlic;
+		for (int e = tid; e < ngp * QA; e += NT) {
+			const int g = e / QA, a = e - g * QA;
+			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			if (a >= *q.ns || (only_new && a != q.flag[0])) continue;
+			const int j = q.row[a] / P, i = q.row[a] - j * P;
+			double cj;
+			qp_row_a(g, j, i, q.ar + a * NTG_QP_MAXCG, cj);
+			q.jwg[a] = qp_row_dot(g, q.ar + a * NTG_QP_MAXCG, i, sd);
+			q.rr[a] = (q.sgn[a] < 0 ? al.lo[b0 + j] : al.up[b0 + j]) - cj;
+		}
+	};
+	// the columns U = W J' of the slots named by flag[0] of every group (-1: none), and their entries of S
+	auto qp_column = [&]() __attribute__((always_inline)) {
+		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, go = D.nwt_go, kk = K > 0 ? K : D.order[0];
+		__syncthreads();
+		for (int c = tid; c < n; c += NT) sgpt[c] = 0.0;
+		__syncthreads();
+		for (int e = tid; e < ngp * go * kk; e += NT) {
+			const int g = e / (go * kk), r = e - g * go * kk, ov = r / kk, qq = r - ov * kk;
+			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			const int a = q.flag[0];
+			if (a < 0) continue;
+			const int i = q.row[a] % P;
+			double val = 0.0;
+			for (int u = 0; u < FamN::CG; u++)
+				if ((int)((D.nwt_upack >> (8 * u + 4)) & 15u) == ov) val += q.ar[a * NTG_QP_MAXCG + u] * S.rowv[S.chrow[(int)((D.nwt_upack >> (8 * u)) & 15u)] + qq * P + i];
+			sgpt[D.iC[g * go + ov] + S.off[i] + qq] = val;
+		}
+		__syncthreads();
+		nwt_apply(sgpt, sxt, false);
+		__syncthreads();
+		for (int c = tid; c < n; c += NT) {
+			const int pos = T.nwt_pos[c];
+			if (pos >= 0 && pos < ngp * ng) {
+				QpSlots q(qpbase + (pos / ng) * NTG_QP_DOUBLES);
+				const int a = q.flag[0];
+				if (a >= 0) qp_U[(size_t)a * npad + c] = sxt[c];
+			}
+		}
+		for (int e = tid; e < ngp * QA; e += NT) {
+			const int g = e / QA, a2 = e - g * QA;
+			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			const int bcol = q.flag[0];
+			if (bcol < 0 || a2 > bcol || a2 >= *q.ns) continue;
+			q.S[NTG_QP_TR(bcol, a2)] = qp_row_dot(g, q.ar + a2 * NTG_QP_MAXCG, q.row[a2] % P, sxt);
+		}
+		qp_ncol++;
+		__syncthreads();
+	};
+	// one major iteration's QP at x (sx = sxt), g (sg), multipliers al_lam, previous QP multipliers qp_lamq: leaves p in sgp, the QP's
+	// multipliers in qp_lamq, |p|, |x|, g.p and the largest multiplier in the qp_* scalars
+	double qp_gp = 0.0;
+	auto qp_major = [&]() __attribute__((always_inline)) {
+		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, wave = tid >> 6, lane = tid & 63, b0 = D.nlic + D.nltc + D.nlfc + D.nnlic;
+		constexpr int NTc = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
+		__syncthreads();   // the multipliers crossed lanes through HBM
+		nwt_refresh_ex(sxt, true, al_lam, 0.0, true);
+		nwt_apply(sg, sd, false);   // W g
+		__syncthreads();
+		// slots of the previous major's working set, in row order (a wave per group: ballot + prefix count)
+		if (wave < ngp) {
+			QpSlots q(qpbase + wave * NTG_QP_DOUBLES);
+			int cnt = 0;
+			for (int j = 0; j < D.nnltc; j++) {
+				if (FamN::row_group(j) != wave) continue;
+				for (int i0 = 0; i0 < P; i0 += 64) {
+					const int i = i0 + lane;
+					const double lq = i < P ? qp_lamq[D.nnlic + j * P + i] : 0.0;
+					const bool nz = lq != 0.0;
+					const unsigned long long mk = __ballot(nz);
+					const int slot = cnt + __popcll(mk & ((1ull << lane) - 1ull));
+					if (nz && slot < QA) { q.row[slot] = j * P + i; q.sgn[slot] = lq > 0.0 ? 1 : -1; q.inP[slot] = 1; q.nu[slot] = q.nu0[slot] = fabs(lq); }
+					cnt += __popcll(mk);
+				}
+			}
+			if (lane == 0) { *q.ns = cnt < QA ? cnt : QA; q.flag[0] = -1; q.flag[1] = 0; q.flag[2] = cnt > QA ? 1 : 0; }
+		}
+		__syncthreads();
+		qp_slot_rows(false);
+		__syncthreads();
+		int nswarm = 0;   // the first iterations form the columns of the slots carried over (one band solve per slot index, all groups at once)
+		for (int g = 0; g < ngp; g++) { QpSlots q(qpbase + g * NTG_QP_DOUBLES); nswarm = max(nswarm, *q.ns); }
+		for (int it = 0; it < 5 * QA + 8; it++) {
+			__syncthreads();
+			bool docol = false;
+			if (it < nswarm) {
+				if (tid < ngp) { QpSlots q(qpbase + tid * NTG_QP_DOUBLES); q.flag[0] = it < *q.ns ? it : -1; }
+				docol = true;
+			} else {
+			if (wave < ngp && lane == 0) { QpSlots q(qpbase + wave * NTG_QP_DOUBLES); qp_nsolve += qp_passive_solve(q); }
+			__syncthreads();
+			// the model step p = -W g - sum_a lam_a U_a  (trial-point buffer: Z = M p is read across lanes)
+			for (int c = tid; c < n; c += NT) {
+				const int pos = T.nwt_pos[c];
+				double v = -sd[c];
+				if (pos >= 0 && pos < ngp * ng) {
+					QpSlots q(qpbase + (pos / ng) * NTG_QP_DOUBLES);
+					const int ns = *q.ns;
+					for (int a = 0; a < ns; a++) { const double nua = q.nu[a]; if (nua != 0.0) v -= (q.sgn[a] < 0 ? -nua : nua) * qp_U[(size_t)a * npad + c]; }
+				}
+				sxt[c] = v;
+			}
+			__syncthreads();
+			// most violated linearised bound of every trajectory row function among the rows outside the passive set
+			double bw[NTc]; int bk[NTc];
+#pragma unroll
+			for (int j = 0; j < NTc; j++) { bw[j] = 0.0; bk[j] = 0x7fffffff; }
+			for (int i = tid; i < P; i += NT) {
+				constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
+				double z[NZ], zp[NZ], c[NTc], tape[FamN::TAPE];
+				compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
+				compute_z<NOUT, K, DM>(D, S, sxt, i, D.tcon_mask, zp);
+				FamN::template nltc_val<NZ>(NOUT > 0 ? NOUT : D.nout, i, z, c, tape);
+#pragma unroll
+				for (int j = 0; j < NTc; j++) {
+					if (j >= D.nnltc) continue;
+					double df[NZ], t[NTc];
+#pragma unroll
+					for (int v = 0; v < NZ; v++) df[v] = 0.0;
+#pragma unroll
+					for (int jj = 0; jj < NTc; jj++) t[jj] = jj == j ? 1.0 : 0.0;
+					FamN::template nltc_vjp<NZ>(NOUT > 0 ? NOUT : D.nout, D.nz, i, z, t, df, tape);
+					double jp = 0.0;
+#pragma unroll
+					for (int v = 0; v < NZ; v++) jp += v < D.nz ? df[v] * zp[v] : 0.0;   // (the generic instances leave the flag entries beyond nz unset)
+					const double lin = c[j] + jp, bl = al.lo[b0 + j], bu = al.up[b0 + j];
+					const double wu = bu < 1e19 ? lin - bu : -1.0, wl = bl > -1e19 ? bl - lin : -1.0;
+					const bool up = wu >= wl;
+					const double w = up ? wu : wl, bound = up ? bu : bl;
+					if (!(w > 1e-9 * (1.0 + fabs(bound)))) continue;
+					// (a slot of the passive set has w = 0 up to rounding: never a candidate)
+					const int key = 2 * (j * P + i) + (up ? 0 : 1);
+					bool passive = false;
+					{
+						QpSlots q(qpbase + FamN::row_group(j) * NTG_QP_DOUBLES);
+						const int ns = *q.ns;
+						for (int a = 0; a < ns; a++) if (q.inP[a] && q.row[a] == j * P + i && (q.sgn[a] < 0) == !up) passive = true;
+					}
+					if (!passive && (w > bw[j] || (w == bw[j] && key < bk[j]))) { bw[j] = w; bk[j] = key; }
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < NTc; j++) {
+#pragma unroll
+				for (int sh = 1; sh < 64; sh <<= 1) {
+					const double ow = __shfl_xor(bw[j], sh); const int ok = __shfl_xor(bk[j], sh);
+					if (ow > bw[j] || (ow == bw[j] && ok < bk[j])) { bw[j] = ow; bk[j] = ok; }
+				}
+				if (lane == 0) { qpred[(wave * NTc + j) * 2] = bw[j]; qpred[(wave * NTc + j) * 2 + 1] = (double)bk[j]; }
+			}
+			__syncthreads();
+			if (wave < ngp && lane == 0) {
+				QpSlots q(qpbase + wave * NTG_QP_DOUBLES);
+				double w = 0.0; int key = 0x7fffffff;
+				for (int wv = 0; wv < NT / 64; wv++)
+					for (int j = 0; j < D.nnltc; j++) {
+						if (FamN::row_group(j) != wave) continue;
+						const double ow = qpred[(wv * NTc + j) * 2]; const int ok = (int)qpred[(wv * NTc + j) * 2 + 1];
+						if (ow > w || (ow == w && ok < key)) { w = ow; key = ok; }
+					}
+				q.flag[0] = -1; q.flag[1] = 0;
+				if (w > 0.0) {
+					const int row = key >> 1, sg = (key & 1) ? -1 : 1, ns = *q.ns;
+					int a = -1;
+					for (int a2 = 0; a2 < ns; a2++) if (q.row[a2] == row && q.sgn[a2] == sg) a = a2;
+					if (a >= 0) { q.inP[a] = 1; q.flag[1] = 1; }   // a slot that left comes back: its column and entries of S are there
+					else if (ns < QA) { q.row[ns] = row; q.sgn[ns] = sg; q.inP[ns] = 1; q.nu[ns] = 0.0; q.nu0[ns] = 0.0; q.flag[0] = ns; q.flag[1] = 1; *q.ns = ns + 1; }
+					else q.flag[2] = 1;   // working set full: the QP is solved on the slots it has
+				}
+			}
+			__syncthreads();
+			bool anycol = false, any = false;
+			for (int g = 0; g < ngp; g++) { QpSlots q(qpbase + g * NTG_QP_DOUBLES); anycol = anycol || q.flag[0] >= 0; any = any || q.flag[1] != 0; }
+			if (!any) break;
+			if (anycol) { qp_slot_rows(true); docol = true; }
+			}
+			if (docol) qp_column();   // (the one call site: the band solve inside is inlined)
+		}
+		__syncthreads();
+		// the QP's multipliers (signed: > 0 at an upper bound), the step, the scalars of the exit test and of the merit function
+		for (int j = tid; j < D.ncnln; j += NT) qp_lamq[j] = 0.0;
+		__syncthreads();
+		double lm = 0.0;
+		for (int g = 0; g < ngp; g++) {
+			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			const int ns = *q.ns;
+			for (int a = 0; a < ns; a++) { const double nua = q.nu[a]; lm = fmax(lm, fabs(nua)); if (tid == 0 && nua != 0.0) qp_lamq[D.nnlic + q.row[a]] = q.sgn[a] < 0 ? -nua : nua; }
+			if (q.flag[2]) qp_over++;
+		}
+		qp_lmax = lm;
+		double r3[3] = {0.0, 0.0, 0.0};
+		for (int c = tid; c < n; c += NT) { const double pc = sxt[c], xc = sx[c]; sgp[c] = pc; r3[0] += pc * pc; r3[1] += xc * xc; r3[2] += sg[c] * pc; }
+		block_sum<NT, 3>(r3, S);
+		qp_pn = sqrt(r3[0]); qp_xn = sqrt(r3[1]); qp_gp = r3[2];
+		nwt_restore();
+		__syncthreads();
 	};
 	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};
 	int inform = 4, iter = 0, nfev = 0, npairs = 0, state = ST_INIT;
@@ -1814,7 +2097,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			(void)eval_cost<FAM, NOUT, K, NT, EPT, (NT >= 256), CHM>(D, S, sxt, sg, &gdummy, cm, al, nullptr, nullptr, NTG_CLOCK_TK(sp.stamps && !NWT),
 			                                                        LIN ? &lin : nullptr, CHM != 0, part);
 			NTG_STAMP(1);
-			if (state != ST_FINAL && state != ST_REEVAL) {
+			if (state != ST_FINAL && state != ST_REEVAL && !(QPM && state == ST_QP)) {
 				project<NT, BIG>(D, S, sg, sgpt, tmp, sd, &part[4]);
 				NTG_STAMP(2);
 				block_sum<NT, 5>(part, S);
@@ -1844,6 +2127,54 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				break;
 			}
 			nfev++;
+			if (QPM && state == ST_QP) {
+				// ---- QP-based SQP step: Fn is the l1 merit function F + rho sum_j viol_j at the trial point (at x itself the first time) ----
+				bool qp_exit = false;
+				if (!qp_first) {
+					if (!(Fn <= qp_phi0 + 1e-4 * qp_alpha * fmin(qp_D, 0.0) + 1e-14 * fabs(qp_phi0))) {
+						if (++qp_k >= 25) { inform = 6; qp_exit = true; }   // no acceptable step: x, F, the multipliers stay those of the last accepted point
+						else {
+							qp_alpha *= 0.5;
+							const double a = qp_alpha;
+							for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + a * sgp[c]; });
+							continue;
+						}
+					} else {
+						const double a = qp_alpha;
+						for_vec<NT>(n, [&](int c) { sx[c] = sxt[c]; });
+						for (int j = tid; j < ncn; j += NT) al_lam[j] += a * (qp_lamq[j] - al_lam[j]);
+						iter++;
+					}
+				}
+				if (!qp_exit) {
+					qp_first = false;
+					F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
+					qp_viol1 = part[2] / qp_rho;
+					if (iter >= sp.itlim) { inform = 4; qp_exit = true; }
+				}
+				if (!qp_exit) {
+					qp_major();
+					if (qp_pn <= 1e-2 * sp.sr * (1.0 + qp_xn) && sqrt(rv2) <= 1e-8) {
+						for (int j = tid; j < ncn; j += NT) al_lam[j] = qp_lamq[j];
+						inform = 0; qp_exit = true;
+					} else {
+						if (qp_rho < 1.5 * qp_lmax + 1e-3) qp_rho = 2.0 * qp_lmax + 1e-3;
+						al.mu = qp_rho;
+						qp_D = qp_gp - qp_rho * qp_viol1; qp_phi0 = Fp + qp_rho * qp_viol1; qp_alpha = 1.0; qp_k = 0;
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c] + sgp[c]; });
+						continue;
+					}
+				}
+				// exit: one more pass for the linear rows' multipliers, with the gradient of the Lagrangian (ALState::qp = 2)
+				__syncthreads();
+				if (clambda && m > 0) {
+					state = ST_FINAL; al.qp = 2;
+					lds_sync();
+					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+					continue;
+				}
+				break;
+			}
 			bool new_major = false;
 			if (state == ST_REEVAL) {   // constraint values and multiplier estimates refreshed at x
 				F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
@@ -2031,6 +2362,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				// the pass on the objective alone is over: switch the augmented Lagrangian on (multipliers 0) and start its first pass
 				phase0 = false;
 				if (inner_inform == 4) { inform = 4; break; }
+				if (QPM) {   // QP-based SQP from the unconstrained optimum: multipliers 0, merit weight 1
+					for (int j = tid; j < ncn; j += NT) { al_lam[j] = 0.0; qp_lamq[j] = 0.0; }
+					al.mu = qp_rho = 1.0; al.qp = 1;
+					state = ST_QP; qp_first = true; finished = false;
+					__syncthreads();
+					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+					continue;
+				}
 				al.mu = 10.0;
 				npairs = 0; finished = false; inner_inform = 4; state = ST_INIT; weak = false; at_x = true;
 				lds_sync();
@@ -2110,7 +2449,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 #endif
 		if (sp.stamps == 3 && tid == 0) {   // diagnostic: work counters of the structured Newton mode
 			double *o = clambda + (size_t)b * ntot;
-			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev;
+			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev; o[6] = qp_nsolve; o[7] = qp_ncol; o[8] = qp_over;
 		}
 		if (sp.stamps == 2 && tid == 0) {   // diagnostic: state of the augmented-Lagrangian loop at exit
 			double *o = clambda + (size_t)b * ntot;
@@ -2144,10 +2483,11 @@ static hipError_t launch_eval_one(const NtgDims &D, const NtgTables &T, const Sm
 	hipLaunchKernelGGL(kfn, dim3(a.grid), dim3(NT), L.total, a.st, D, T, L, a.batch, a.mode, a.x, a.f, a.g, a.c, a.jb, a.cj);
 	return hipGetLastError();
 }
-template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true, int CHM = 0, bool NWT = false>
+template <int FAM, int NOUT, int K, int NT, int EPT, bool BIG, bool HESS = true, int CHM = 0, bool NWT = false, bool QPM = false>
 static hipError_t launch_sqp_one(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
-	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS, CHM, NWT>;
+	auto kfn = sqp_kernel<FAM, NOUT, K, NT, EPT, BIG, HESS, CHM, NWT, QPM>;
+	if (QPM != (sp.hessian == 3)) return hipErrorInvalidValue;
 	if (NWT && (!D.nwt_on || !a.nwtw || D.nwt_cg != Family<FAM>::CG || D.nwt_go != Family<FAM>::COUPLE || ((D.nwt_tw ? 2 : 1) * D.nwt_ngrp + D.nwt_nfo) * 64 > NT)) return hipErrorInvalidValue;
 	if (L.total > 64 * 1024) (void)hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, L.total);
 	hipLaunchKernelGGL(kfn, dim3(a.batch), dim3(NT), L.total, a.st, D, T, L, sp, a.batch, a.lo, a.up, a.x, a.obj, a.inf, a.it, a.nf,
@@ -2197,6 +2537,16 @@ template <int FAM>
 static hipError_t launch_sqp_newton_generic(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
 	if constexpr (Family<FAM>::COUPLE > 0) {
+		if (sp.hessian == 3) {   // QP-based SQP step: generic instances
+			if (a.big) {
+				if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, true, true, 0, true, true>(D, T, L, sp, a);
+				return hipErrorInvalidValue;
+			}
+			if (a.nt == 128) return launch_sqp_one<FAM, 0, 0, 128, 4, false, true, 0, true, true>(D, T, L, sp, a);
+			if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, false, true, 0, true, true>(D, T, L, sp, a);
+			if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, false, true, 0, true, true>(D, T, L, sp, a);
+			return hipErrorInvalidValue;
+		}
 		if (a.big) {
 			if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, true, true, 0, true>(D, T, L, sp, a);
 			if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, true, true, 0, true>(D, T, L, sp, a);
@@ -2211,7 +2561,7 @@ static hipError_t launch_sqp_newton_generic(const NtgDims &D, const NtgTables &T
 template <int FAM>
 static hipError_t launch_sqp_generic(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
-	if (sp.hessian == 2) return launch_sqp_newton_generic<FAM>(D, T, L, sp, a);
+	if (sp.hessian == 2 || sp.hessian == 3) return launch_sqp_newton_generic<FAM>(D, T, L, sp, a);
 	if (a.big) {
 		if (a.nt == 256) return launch_sqp_one<FAM, 0, 0, 256, 4, true>(D, T, L, sp, a);
 		if (a.nt == 512) return launch_sqp_one<FAM, 0, 0, 512, 4, true>(D, T, L, sp, a);

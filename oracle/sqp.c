@@ -705,7 +705,7 @@ static int sqpqp_run(orc_problem *p, nwt_t *nw, al_t *al, double *x, int n, int 
 	F = al_eval(al, x, g, &rvd, &gnd);
 	memset(st, 0, sizeof(*st));
 	for (;;) {
-		double viol1 = 0.0, pn, xn, D, phi0, alpha, lmax = 0.0, kkt, del, tr = 0.0;
+		double viol1 = 0.0, pn, xn, D, phi0, alpha, lmax = 0.0, kkt;
 		int np = 0;
 		if (*iter >= itlim) { inform = 4; break; }
 		/* model Hessian with the current multipliers (mu tiny: the Gauss-Newton term vanishes, the curvature term is taken) */
@@ -721,14 +721,13 @@ static int sqpqp_run(orc_problem *p, nwt_t *nw, al_t *al, double *x, int n, int 
 			for (i = 0; i < n; i++) sv += M_(p->cJac, nc, l, i) * Y[(size_t)j * n + i];
 			M_(S, nc, j, l) = sv; M_(S, nc, l, j) = sv;
 		}
-		for (j = 0; j < nc; j++) tr += M_(S, nc, j, j);
-		del = 1e-10 * tr / (nc > 0 ? nc : 1);
+#define DEL_(a) (1e-10 * M_(S, nc, vrow[a], vrow[a]))   /* the proximal shift, relative to the row's own diagonal entry */
 		for (k = 0; k < nv; k++) {
 			const int jj = vrow[k]; const double bl = p->bl[n + mall + jj], bu = p->bu[n + mall + jj];
 			const double sg = vsgn[k] == 0 ? 1.0 : (double)vsgn[k], r = (vsgn[k] < 0 ? bl : bu) - c[jj];
-			q[k] = sg * (JWg[jj] + r) - del * nu[k];   /* the shift as a proximal term around the previous multipliers: no bias at a fixed point */
+			q[k] = sg * (JWg[jj] + r) - DEL_(k) * nu[k];   /* the shift as a proximal term around the previous multipliers: no bias at a fixed point */
 		}
-#define H_(a, b) ((vsgn[a] < 0 ? -1.0 : 1.0) * (vsgn[b] < 0 ? -1.0 : 1.0) * M_(S, nc, vrow[a], vrow[b]) + ((a) == (b) ? del : 0.0))
+#define H_(a, b) ((vsgn[a] < 0 ? -1.0 : 1.0) * (vsgn[b] < 0 ? -1.0 : 1.0) * M_(S, nc, vrow[a], vrow[b]) + ((a) == (b) ? DEL_(a) : 0.0))
 		/* warm start: the passive set and the (feasible) multipliers of the previous major */
 		for (k = 0; k < nv; k++) { inP[k] = (nu[k] > 0.0 || vsgn[k] == 0); if (inP[k]) P[np++] = k; }
 		for (it2 = 0; it2 < 6 * nv + 10; it2++) {
@@ -739,15 +738,16 @@ static int sqpqp_run(orc_problem *p, nwt_t *nw, al_t *al, double *x, int n, int 
 				for (k = 0; k < nv; k++) if (!inP[k]) {
 					double w = -q[k];
 					for (l = 0; l < nv; l++) if (nu[l] != 0.0) w -= H_(k, l) * nu[l];
-					if (w > wb) { wb = w; best = k; }
+					/* (a row enters when its linearised bound is violated by more than 1e-9 (1 + |bound|)) */
+					if (w > wb && w > 1e-9 * (1.0 + fabs(vsgn[k] < 0 ? p->bl[n + mall + vrow[k]] : p->bu[n + mall + vrow[k]]))) { wb = w; best = k; }
 				}
-				if (best < 0 || wb <= 1e-9 * (1.0 + fabs(q[best]))) break;
+				if (best < 0) break;
 				inP[best] = 1; P[np++] = best;
 			}
 			for (;;) {   /* solve on the passive set; step back to the first sign change */
 				double amin = 1.0; int neg = 0;
 				for (k = 0; k < np; k++) { z[k] = -q[P[k]]; for (l = 0; l <= k; l++) { const double h = H_(P[k], P[l]); M_(HP, np, k, l) = h; M_(HP, np, l, k) = h; } }
-				if (chol_(HP, np)) { for (k = 0; k < np; k++) for (l = 0; l <= k; l++) { const double h = H_(P[k], P[l]) + (k == l ? 1e4 * del : 0.0); M_(HP, np, k, l) = h; M_(HP, np, l, k) = h; } if (chol_(HP, np)) { np = 0; break; } }
+				if (chol_(HP, np)) { for (k = 0; k < np; k++) for (l = 0; l <= k; l++) { const double h = H_(P[k], P[l]) + (k == l ? 1e4 * DEL_(P[k]) : 0.0); M_(HP, np, k, l) = h; M_(HP, np, l, k) = h; } if (chol_(HP, np)) { np = 0; break; } }
 				chol_solve_(HP, np, z);
 				st->qp_iters++;
 				for (k = 0; k < np; k++) if (vsgn[P[k]] != 0 && !(z[k] > 0.0)) { const double a = nu[P[k]] / (nu[P[k]] - z[k]); neg = 1; if (a < amin) amin = a; }
@@ -759,6 +759,7 @@ static int sqpqp_run(orc_problem *p, nwt_t *nw, al_t *al, double *x, int n, int 
 			}
 		}
 #undef H_
+#undef DEL_
 		if (np > st->max_active) st->max_active = np;
 		memset(lamq, 0, (nc + 1) * sizeof(double));
 		for (k = 0; k < nv; k++) if (nu[k] != 0.0) lamq[vrow[k]] += (vsgn[k] < 0 ? -1.0 : 1.0) * nu[k];
@@ -791,6 +792,7 @@ static int sqpqp_run(orc_problem *p, nwt_t *nw, al_t *al, double *x, int n, int 
 	}
 	st->nfev = al->nfev;
 	*F_out = F;
+	if (getenv("ORC_QP_STATS")) fprintf(stderr, "sqpqp: inform %d majors %d nfev %d qp_iters %d max_active %d\n", inform, st->majors, st->nfev, st->qp_iters, st->max_active);
 	free(Wg); free(pstep); free(xt); free(gt); free(lamq); free(row); free(Y); free(S); free(JWg); free(vrow); free(vsgn); free(inP); free(P); free(nu); free(q); free(z); free(HP);
 	return inform;
 }
