@@ -87,7 +87,11 @@ typedef struct {
 	                     * 2 structured Newton step for nonlinear trajectory rows: band model of the augmented Lagrangian's Hessian,
 	                     *   assembled and factored on the matrix cores at every major (families with second-order blocks: obstacle,
 	                     *   quadrotor, manipulator; acts as 1 where it does not apply, e.g. more coupling groups than a
-	                     *   workgroup has wavefronts) -- the robust mode for BASELINE's configs D and E (for E the quasi-Newton mode 1 can be the faster one) */
+	                     *   workgroup has wavefronts) -- the robust mode for BASELINE's configs D and E,
+	                     * 3 QP-based SQP step on the same band model: per major iteration the inequality QP on the linearised rows (what NPSOL does with the
+	                     *   Jacobian ntg() hands it, ntg.c:217-220,250-253), solved through its dual by an active-set method on at most 16 rows per
+	                     *   coupling group, l1 merit function; a problem whose working set does not fit continues in mode 2 by itself.  Config E:
+	                     *   17 majors instead of 60, 1.9 x mode 2's rate.  Acts as 2 with warm_start, as 1 where the band model does not apply. */
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
 	int block_threads;  /* 0 = auto (128/256/512) */
 	int qn_memory;      /* quasi-Newton updates kept before the approximation restarts from W0; <= 0: 256 */

@@ -12,6 +12,11 @@ hipError_t ntg_launch_eval_manip(const NtgDims &D, const NtgTables &T, const Sme
 
 hipError_t ntg_launch_sqp_manip(const NtgDims &D, const NtgTables &T, const SmemLayout &L, const SolveParams &sp, const SqpArgs &a)
 {
+#ifdef NTG_SLIM   // experiments (tools/mkvariant2.sh ... -DNTG_SLIM): config E's Newton-mode instances only -- a fifth of the compile time
+	if (a.nt == 512 && a.big && sp.hessian == 3) return launch_sqp_one<NTG_FAM_MANIP, 12, 6, 512, 5, true, true, 5, true, true>(D, T, L, sp, a);
+	if (a.nt == 512 && a.big && sp.hessian == 2) return launch_sqp_one<NTG_FAM_MANIP, 12, 6, 512, 5, true, true, 5, true>(D, T, L, sp, a);
+	return hipErrorInvalidValue;
+#else
 	if (a.nt == 512 && ntg_all_d(D, 3) && D.nout == 12 && ntg_uniform_order(D, 512, 5) == 6) {
 		if (sp.hessian == 3) {   // QP-based SQP step on the band model (qpdual.hpp)
 			if (a.big && ntg_chm_match(D, 5, 3)) return launch_sqp_one<NTG_FAM_MANIP, 12, 6, 512, 5, true, true, 5, true, true>(D, T, L, sp, a);
@@ -28,4 +33,5 @@ hipError_t ntg_launch_sqp_manip(const NtgDims &D, const NtgTables &T, const Smem
 		return launch_sqp_one<NTG_FAM_MANIP, 12, 6, 512, 5, false>(D, T, L, sp, a);
 	}
 	return launch_sqp_generic<NTG_FAM_MANIP>(D, T, L, sp, a);
+#endif
 }

@@ -886,7 +886,7 @@ static size_t nwt_doubles(const NtgDims &D, int batch, const SolveParams &sp)
 	if (sp.hessian < 2 || !D.nwt_on) return 0;
 	const size_t rev = D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0;   // the reversed arrays of the two-sided factorisation
 	// QP-based SQP step: the slots' columns W J' and the QP's multipliers (sqp_kernel, qp_pp)
-	const size_t qp = sp.hessian == 3 ? (size_t)NTG_QP_MAXA * ((D.nC + 1) & ~1) + (size_t)((D.ncnln + 1) & ~1) : 0;
+	const size_t qp = sp.hessian == 3 ? (size_t)NTG_QP_MAXA * ((D.nC + 1) & ~1) + (size_t)((D.ncnln + 1) & ~1) * (3 + D.nwt_cg + NTG_QP_MAXA) : 0;
 	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + rev + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg + qp);
 }
 

@@ -1632,11 +1632,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	ALState al{(alprob && (!NWT || sp.warm)) ? 10.0 : 0.0, al_lam, al_t, lower + (size_t)b * D.nbounds, upper + (size_t)b * D.nbounds};
 	// structured Newton mode: band matrix / factor and the per-breakpoint blocks of this problem (HBM), flags
 	using FamN = Family<FAM>;
-	constexpr int NWT_CG2 = FamN::CG * FamN::CG;
+	constexpr int NWT_CG2 = FamN::CG * FamN::CG, NWT_CG2S = FamN::CG;
 	// per problem: the groups' band arrays, [two-sided factorisation: their reversed arrays,] the per-breakpoint blocks
 	const size_t nwt_ksz = (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0);
 	// (QP-based SQP step: + the slots' columns U = W J' [NTG_QP_MAXA][npad] and the QP's multipliers of the previous major iteration [ncnln])
-	const size_t qp_pp = QPM ? (size_t)NTG_QP_MAXA * npad + (size_t)((D.ncnln + 1) & ~1) : 0;
+	const size_t ncq = (size_t)((D.ncnln + 1) & ~1);   // rows of the QP's per-row arrays: multipliers, c, J W g, derivative rows [CG], J U [NTG_QP_MAXA]
+	const size_t qp_pp = QPM ? (size_t)NTG_QP_MAXA * npad + ncq * (3 + NWT_CG2S + NTG_QP_MAXA) : 0;
 	double *nwt_K = NWT ? nwt_all + (size_t)b * (nwt_ksz + (size_t)D.nwt_ngrp * D.P * NWT_CG2 + qp_pp) : nullptr;
 	double *nwt_B = NWT ? nwt_K + nwt_ksz : nullptr;
 	double *qp_U = NWT ? nwt_B + (size_t)D.nwt_ngrp * D.P * NWT_CG2 : nullptr, *qp_lamq = NWT ? qp_U + (size_t)NTG_QP_MAXA * npad : nullptr;
@@ -1777,64 +1778,83 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	const int qp_ylenf = 16 * ((D.nwt_ngf + 15) >> 4) + 48;
 	double *qpbase = (double *)(smem_raw + L.nwt_y) + nwt_yall + nwt_npan * NWT_PANEL + D.nwt_nfo * qp_ylenf;
 	double *qpred = qpbase + D.nwt_ngrp * NTG_QP_DOUBLES;   // [waves][rows per breakpoint][2] scratch of the entering-row search
-	double qp_rho = 1.0, qp_phi0 = 0.0, qp_D = 0.0, qp_alpha = 1.0, qp_viol1 = 0.0, qp_pn = 0.0, qp_xn = 0.0, qp_lmax = 0.0;
-	int qp_k = 0, qp_over = 0, qp_nsolve = 0, qp_ncol = 0;
-	bool qp_first = true;
-	(void)qp_over; (void)qp_nsolve; (void)qp_ncol;
+	double qp_rho = 1.0, qp_phi0 = 0.0, qp_D = 0.0, qp_alpha = 1.0, qp_viol1 = 0.0, qp_pn = 0.0, qp_xn = 0.0, qp_lmax = 0.0, qp_gl = 0.0;
+	int qp_k = 0, qp_over = 0, qp_nsolve = 0, qp_ncol = 0, qp_nocurv = 0, qp_fell = 0;
+	bool qp_first = true, qp_full = false, qp_last = false;   // qp_last: the final pass evaluates at the point the last step led to   // qp_full: a group's working set did not hold every row the last QP wanted
+	(void)qp_over; (void)qp_nsolve; (void)qp_ncol; (void)qp_fell;
 	// flag entry (index into z) of variable u of group g
 	auto qp_flag = [&](int g, int u) __attribute__((always_inline)) { return FamN::DM * (g * D.nwt_go + (int)((D.nwt_upack >> (8 * u + 4)) & 15u)) + (int)((D.nwt_upack >> (8 * u)) & 15u); };
-	// derivative row of trajectory row j at breakpoint i (the group's CG flag entries) and the row's value, at the iterate x (sx)
-	auto qp_row_a = [&](int g, int j, int i, double *ar, double &cj) __attribute__((always_inline)) {
+	// Row caches of one major iteration (HBM, per problem): for every trajectory row (constraint-major, like c) its value c, J W g, its
+	// derivative row on the group's CG flag entries, and -- per slot index -- J U (the row times the slot's column): the entering-row
+	// search, the entries of S and the right-hand sides are then reads and short sums, no evaluation-shaped pass per QP iteration.
+	double *qp_c = qp_lamq + ncq, *qp_jwg = qp_c + ncq, *qp_a = qp_jwg + ncq, *qp_JU = qp_a + (size_t)ncq * FamN::CG;
+	// one pass over the breakpoints: lane = breakpoint.  what = 0: c, derivative rows (at x = sx) and J W g (W g = sd); what = 1: J U of
+	// the columns just formed (U = sxt; slot index flag[0] of the row's group)
+	auto qp_rows_pass = [&](int what) __attribute__((always_inline)) {
 		constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ, NTc = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
-		double z[NZ], df[NZ], c[NTc], t[NTc], tape[FamN::TAPE];
-		compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
-		FamN::template nltc_val<NZ>(NOUT > 0 ? NOUT : D.nout, i, z, c, tape);
+		for (int i = tid; i < P; i += NT) {
+			double zv[NZ];
+			compute_z<NOUT, K, DM>(D, S, what == 0 ? sd : sxt, i, D.tcon_mask, zv);
+			if (what == 0) {
+				double z[NZ], c[NTc], tape[FamN::TAPE];
+				compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
+				FamN::template nltc_val<NZ>(NOUT > 0 ? NOUT : D.nout, i, z, c, tape);
 #pragma unroll
-		for (int v = 0; v < NZ; v++) df[v] = 0.0;
+				for (int j = 0; j < NTc; j++) {
+					if (j >= D.nnltc) continue;
+					double df[NZ], t[NTc];
 #pragma unroll
-		for (int jj = 0; jj < NTc; jj++) t[jj] = jj == j ? 1.0 : 0.0;
-		FamN::template nltc_vjp<NZ>(NOUT > 0 ? NOUT : D.nout, D.nz, i, z, t, df, tape);
-		cj = 0.0;
+					for (int v = 0; v < NZ; v++) df[v] = 0.0;
 #pragma unroll
-		for (int jj = 0; jj < NTc; jj++) if (jj == j) cj = c[jj];
-		for (int u = 0; u < FamN::CG; u++) {
-			const int fl = qp_flag(g, u);
-			double a = 0.0;
+					for (int jj = 0; jj < NTc; jj++) t[jj] = jj == j ? 1.0 : 0.0;
+					FamN::template nltc_vjp<NZ>(NOUT > 0 ? NOUT : D.nout, D.nz, i, z, t, df, tape);
+					const int g = FamN::row_group(j), row = j * P + i;
+					double jw = 0.0;
+					for (int u = 0; u < FamN::CG; u++) {
+						const int fl = qp_flag(g, u);
+						double av = 0.0, zz = 0.0;
 #pragma unroll
-			for (int v = 0; v < NZ; v++) if (v == fl) a = df[v];
-			ar[u] = a;
+						for (int v = 0; v < NZ; v++) if (v == fl) { av = df[v]; zz = zv[v]; }
+						qp_a[(size_t)row * FamN::CG + u] = av;
+						jw += av * zz;
+					}
+					qp_c[row] = c[j]; qp_jwg[row] = jw;
+				}
+			} else {
+#pragma unroll
+				for (int j = 0; j < NTc; j++) {
+					if (j >= D.nnltc) continue;
+					const int g = FamN::row_group(j), row = j * P + i;
+					QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+					const int acol = q.flag[0];
+					if (acol < 0) continue;
+					double ju = 0.0;
+					for (int u = 0; u < FamN::CG; u++) {
+						const int fl = qp_flag(g, u);
+						double zz = 0.0;
+#pragma unroll
+						for (int v = 0; v < NZ; v++) if (v == fl) zz = zv[v];
+						ju += qp_a[(size_t)row * FamN::CG + u] * zz;
+					}
+					qp_JU[(size_t)acol * ncq + row] = ju;
+				}
+			}
 		}
 	};
-	// J_row . vec  for a slot's row: derivative row times Z = M vec at the row's breakpoint
-	auto qp_row_dot = [&](int g, const double *ar, int i, const double *vec) __attribute__((always_inline)) {
-		constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
-		double z[NZ];
-		compute_z<NOUT, K, DM>(D, S, vec, i, D.tcon_mask, z);
-		double acc = 0.0;
-		for (int u = 0; u < FamN::CG; u++) {
-			const int fl = qp_flag(g, u);
-			double zv = 0.0;
-#pragma unroll
-			for (int v = 0; v < NZ; v++) if (v == fl) zv = z[v];
-			acc += ar[u] * zv;
-		}
-		return acc;
-	};
-	// derivative rows, J W g and r = bound - c of the slots [a0, ns) of every group (one lane per slot); Wg lives in sd
+	// derivative rows (for the scatter of J'), J W g and r = bound - c of the slots of every group (one lane per slot): reads of the caches
 	auto qp_slot_rows = [&](bool only_new) __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, b0 = D.nlic + D.nltc + D.nlfc + D.nnlic;
 		for (int e = tid; e < ngp * QA; e += NT) {
 			const int g = e / QA, a = e - g * QA;
 			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
 			if (a >= *q.ns || (only_new && a != q.flag[0])) continue;
-			const int j = q.row[a] / P, i = q.row[a] - j * P;
-			double cj;
-			qp_row_a(g, j, i, q.ar + a * NTG_QP_MAXCG, cj);
-			q.jwg[a] = qp_row_dot(g, q.ar + a * NTG_QP_MAXCG, i, sd);
-			q.rr[a] = (q.sgn[a] < 0 ? al.lo[b0 + j] : al.up[b0 + j]) - cj;
+			const int row = q.row[a], j = row / P;
+			for (int u = 0; u < FamN::CG; u++) q.ar[a * NTG_QP_MAXCG + u] = qp_a[(size_t)row * FamN::CG + u];
+			q.jwg[a] = qp_jwg[row];
+			q.rr[a] = (q.sgn[a] < 0 ? al.lo[b0 + j] : al.up[b0 + j]) - qp_c[row];
 		}
 	};
-	// the columns U = W J' of the slots named by flag[0] of every group (-1: none), and their entries of S
+	// the columns U = W J' of the slots named by flag[0] of every group (-1: none), their J U over all rows and their entries of S
 	auto qp_column = [&]() __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, go = D.nwt_go, kk = K > 0 ? K : D.order[0];
 		__syncthreads();
@@ -1862,12 +1882,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				if (a >= 0) qp_U[(size_t)a * npad + c] = sxt[c];
 			}
 		}
+		qp_rows_pass(1);
+		__syncthreads();
 		for (int e = tid; e < ngp * QA; e += NT) {
 			const int g = e / QA, a2 = e - g * QA;
 			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
 			const int bcol = q.flag[0];
-			if (bcol < 0 || a2 > bcol || a2 >= *q.ns) continue;
-			q.S[NTG_QP_TR(bcol, a2)] = qp_row_dot(g, q.ar + a2 * NTG_QP_MAXCG, q.row[a2] % P, sxt);
+			if (bcol < 0 || a2 >= *q.ns) continue;   // (the whole row and column of the slot: a reused slot sits in the middle)
+			q.S[a2 <= bcol ? NTG_QP_TR(bcol, a2) : NTG_QP_TR(a2, bcol)] = qp_JU[(size_t)bcol * ncq + q.row[a2]];
 		}
 		qp_ncol++;
 		__syncthreads();
@@ -1879,9 +1901,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, wave = tid >> 6, lane = tid & 63, b0 = D.nlic + D.nltc + D.nlfc + D.nnlic;
 		constexpr int NTc = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
 		__syncthreads();   // the multipliers crossed lanes through HBM
-		nwt_refresh_ex(sxt, true, al_lam, 0.0, true);
+		// After the model with the constraint curvature was not positive definite at two major iterations in a row the curvature is not tried
+		// again in this solve: the model is then the cost model, the same matrix at every later major -- its factor is kept (no block pass, no
+		// assembly, no factorisation; oracle/sqp.c sqpqp_run has the same rule and the measurements behind it)
+		if (qp_nocurv < 2) { nwt_refresh_ex(sxt, true, al_lam, 0.0, true); qp_nocurv = nwt_curv ? 0 : qp_nocurv + 1; }
 		nwt_apply(sg, sd, false);   // W g
+		NTG_STAMP(4);
 		__syncthreads();
+		qp_rows_pass(0);
 		// slots of the previous major's working set, in row order (a wave per group: ballot + prefix count)
 		if (wave < ngp) {
 			QpSlots q(qpbase + wave * NTG_QP_DOUBLES);
@@ -1914,54 +1941,32 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			} else {
 			if (wave < ngp && lane == 0) { QpSlots q(qpbase + wave * NTG_QP_DOUBLES); qp_nsolve += qp_passive_solve(q); }
 			__syncthreads();
-			// the model step p = -W g - sum_a lam_a U_a  (trial-point buffer: Z = M p is read across lanes)
-			for (int c = tid; c < n; c += NT) {
-				const int pos = T.nwt_pos[c];
-				double v = -sd[c];
-				if (pos >= 0 && pos < ngp * ng) {
-					QpSlots q(qpbase + (pos / ng) * NTG_QP_DOUBLES);
-					const int ns = *q.ns;
-					for (int a = 0; a < ns; a++) { const double nua = q.nu[a]; if (nua != 0.0) v -= (q.sgn[a] < 0 ? -nua : nua) * qp_U[(size_t)a * npad + c]; }
-				}
-				sxt[c] = v;
-			}
-			__syncthreads();
-			// most violated linearised bound of every trajectory row function among the rows outside the passive set
+			// most violated linearised bound of every trajectory row function among the rows outside the passive set:
+			// c + J p = c - J W g - sum_a lam_a (J U_a)
 			double bw[NTc]; int bk[NTc];
 #pragma unroll
 			for (int j = 0; j < NTc; j++) { bw[j] = 0.0; bk[j] = 0x7fffffff; }
 			for (int i = tid; i < P; i += NT) {
-				constexpr int DM = FamN::DM, NZ = NOUT > 0 ? DM * NOUT : NTG_MAX_NZ;
-				double z[NZ], zp[NZ], c[NTc], tape[FamN::TAPE];
-				compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
-				compute_z<NOUT, K, DM>(D, S, sxt, i, D.tcon_mask, zp);
-				FamN::template nltc_val<NZ>(NOUT > 0 ? NOUT : D.nout, i, z, c, tape);
 #pragma unroll
 				for (int j = 0; j < NTc; j++) {
 					if (j >= D.nnltc) continue;
-					double df[NZ], t[NTc];
-#pragma unroll
-					for (int v = 0; v < NZ; v++) df[v] = 0.0;
-#pragma unroll
-					for (int jj = 0; jj < NTc; jj++) t[jj] = jj == j ? 1.0 : 0.0;
-					FamN::template nltc_vjp<NZ>(NOUT > 0 ? NOUT : D.nout, D.nz, i, z, t, df, tape);
-					double jp = 0.0;
-#pragma unroll
-					for (int v = 0; v < NZ; v++) jp += v < D.nz ? df[v] * zp[v] : 0.0;   // (the generic instances leave the flag entries beyond nz unset)
-					const double lin = c[j] + jp, bl = al.lo[b0 + j], bu = al.up[b0 + j];
-					const double wu = bu < 1e19 ? lin - bu : -1.0, wl = bl > -1e19 ? bl - lin : -1.0;
+					const int row = j * P + i;
+					QpSlots q(qpbase + FamN::row_group(j) * NTG_QP_DOUBLES);
+					const int ns = *q.ns;
+					double lin = qp_c[row] - qp_jwg[row];
+					int pas = 0;   // bit 0 / 1: the row's upper / lower side is passive
+					for (int a = 0; a < ns; a++) {
+						const double nua = q.nu[a];
+						if (nua != 0.0) lin -= (q.sgn[a] < 0 ? -nua : nua) * qp_JU[(size_t)a * ncq + row];
+						if (q.inP[a] && q.row[a] == row) pas |= q.sgn[a] < 0 ? 2 : 1;
+					}
+					const double bl = al.lo[b0 + j], bu = al.up[b0 + j];
+					const double wu = (bu < 1e19 && !(pas & 1)) ? lin - bu : -1.0, wl = (bl > -1e19 && !(pas & 2)) ? bl - lin : -1.0;
 					const bool up = wu >= wl;
 					const double w = up ? wu : wl, bound = up ? bu : bl;
 					if (!(w > 1e-9 * (1.0 + fabs(bound)))) continue;
-					// (a slot of the passive set has w = 0 up to rounding: never a candidate)
-					const int key = 2 * (j * P + i) + (up ? 0 : 1);
-					bool passive = false;
-					{
-						QpSlots q(qpbase + FamN::row_group(j) * NTG_QP_DOUBLES);
-						const int ns = *q.ns;
-						for (int a = 0; a < ns; a++) if (q.inP[a] && q.row[a] == j * P + i && (q.sgn[a] < 0) == !up) passive = true;
-					}
-					if (!passive && (w > bw[j] || (w == bw[j] && key < bk[j]))) { bw[j] = w; bk[j] = key; }
+					const int key = 2 * row + (up ? 0 : 1);
+					if (w > bw[j] || (w == bw[j] && key < bk[j])) { bw[j] = w; bk[j] = key; }
 				}
 			}
 #pragma unroll
@@ -1990,7 +1995,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					for (int a2 = 0; a2 < ns; a2++) if (q.row[a2] == row && q.sgn[a2] == sg) a = a2;
 					if (a >= 0) { q.inP[a] = 1; q.flag[1] = 1; }   // a slot that left comes back: its column and entries of S are there
 					else if (ns < QA) { q.row[ns] = row; q.sgn[ns] = sg; q.inP[ns] = 1; q.nu[ns] = 0.0; q.nu0[ns] = 0.0; q.flag[0] = ns; q.flag[1] = 1; *q.ns = ns + 1; }
-					else q.flag[2] = 1;   // working set full: the QP is solved on the slots it has
+					else {
+						// every slot taken: a slot whose row left the passive set is given to the new row (its column, its J U and its row AND
+						// column of S are formed anew by qp_column); none: the working set of this major is full
+						int fr = -1;
+						for (int a2 = 0; a2 < ns; a2++) if (!q.inP[a2] && fr < 0) fr = a2;
+						if (fr >= 0) { q.row[fr] = row; q.sgn[fr] = sg; q.inP[fr] = 1; q.nu[fr] = 0.0; q.nu0[fr] = 0.0; q.flag[0] = fr; q.flag[1] = 1; }
+						else q.flag[2] = 1;
+					}
 				}
 			}
 			__syncthreads();
@@ -1999,10 +2011,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (!any) break;
 			if (anycol) { qp_slot_rows(true); docol = true; }
 			}
-			if (docol) qp_column();   // (the one call site: the band solve inside is inlined)
+			NTG_STAMP(2);
+			if (docol) { qp_column(); NTG_STAMP(0); }   // (the one call site: the band solve inside is inlined)
 		}
 		__syncthreads();
-		// the QP's multipliers (signed: > 0 at an upper bound), the step, the scalars of the exit test and of the merit function
+		// the QP's multipliers (signed: > 0 at an upper bound), the step p = -W g - sum_a lam_a U_a, the scalars of the exit test and of the
+		// merit function
 		for (int j = tid; j < D.ncnln; j += NT) qp_lamq[j] = 0.0;
 		__syncthreads();
 		double lm = 0.0;
@@ -2010,14 +2024,39 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
 			const int ns = *q.ns;
 			for (int a = 0; a < ns; a++) { const double nua = q.nu[a]; lm = fmax(lm, fabs(nua)); if (tid == 0 && nua != 0.0) qp_lamq[D.nnlic + q.row[a]] = q.sgn[a] < 0 ? -nua : nua; }
-			if (q.flag[2]) qp_over++;
+			if (q.flag[2]) { qp_over++; qp_full = true; }
 		}
 		qp_lmax = lm;
-		double r3[3] = {0.0, 0.0, 0.0};
-		for (int c = tid; c < n; c += NT) { const double pc = sxt[c], xc = sx[c]; sgp[c] = pc; r3[0] += pc * pc; r3[1] += xc * xc; r3[2] += sg[c] * pc; }
-		block_sum<NT, 3>(r3, S);
-		qp_pn = sqrt(r3[0]); qp_xn = sqrt(r3[1]); qp_gp = r3[2];
+		// ... and |Z'(g + J'lam)|, the reduced gradient of the Lagrangian with the QP's multipliers (the free coefficients span null(A_E)):
+		// the optimality measure of the exit test, the same one the other modes use
+		double r3[4] = {0.0, 0.0, 0.0, 0.0};
+		const int go2 = D.nwt_go, kk2 = K > 0 ? K : D.order[0];
+		for (int c = tid; c < n; c += NT) {
+			const int pos = T.nwt_pos[c];
+			double pc = -sd[c], gl = sg[c];
+			if (pos >= 0 && pos < ngp * ng) {
+				const int g = pos / ng, pp = pos - g * ng, ov = pp % go2, cl = D.nwt_clo + pp / go2;
+				QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+				const int ns = *q.ns;
+				for (int a = 0; a < ns; a++) {
+					const double nua = q.nu[a];
+					if (nua == 0.0) continue;
+					const double la = q.sgn[a] < 0 ? -nua : nua;
+					pc -= la * qp_U[(size_t)a * npad + c];
+					const int i = q.row[a] % P, qq = cl - S.off[i];
+					if (qq >= 0 && qq < kk2)
+						for (int u = 0; u < FamN::CG; u++)
+							if ((int)((D.nwt_upack >> (8 * u + 4)) & 15u) == ov) gl += la * q.ar[a * NTG_QP_MAXCG + u] * S.rowv[S.chrow[(int)((D.nwt_upack >> (8 * u)) & 15u)] + qq * P + i];
+				}
+			}
+			const double xc = sx[c];
+			sgp[c] = pc; r3[0] += pc * pc; r3[1] += xc * xc; r3[2] += sg[c] * pc;
+			if (pos >= 0) r3[3] += gl * gl;
+		}
+		block_sum<NT, 4>(r3, S);
+		qp_pn = sqrt(r3[0]); qp_xn = sqrt(r3[1]); qp_gp = r3[2]; qp_gl = sqrt(r3[3]);
 		nwt_restore();
+		NTG_STAMP(2);
 		__syncthreads();
 	};
 	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};
@@ -2109,6 +2148,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			const double Fpn = (D.nicf ? S.dfi[D.nz] : 0.0) + part[0] + (D.nfcf ? S.dff[D.nz] : 0.0);   // ntg.c:328
 			const double Fn = Fpn + part[2], gn2n = part[1], rv2n = part[3];
 			if (state == ST_FINAL) {
+				if (QPM && qp_last) { Fp = Fpn; F = Fn; rv2 = rv2n; nfev++; }
 				// multipliers estimate lam = (AA')^-1 A g at the final point
 				if (BIG) __syncthreads(); else lds_sync();
 				for (int r = tid; r < m; r += NT) {
@@ -2129,10 +2169,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			nfev++;
 			if (QPM && state == ST_QP) {
 				// ---- QP-based SQP step: Fn is the l1 merit function F + rho sum_j viol_j at the trial point (at x itself the first time) ----
-				bool qp_exit = false;
+				bool qp_exit = false, qp_to_al = false;
 				if (!qp_first) {
 					if (!(Fn <= qp_phi0 + 1e-4 * qp_alpha * fmin(qp_D, 0.0) + 1e-14 * fabs(qp_phi0))) {
-						if (++qp_k >= 25) { inform = 6; qp_exit = true; }   // no acceptable step: x, F, the multipliers stay those of the last accepted point
+						if (++qp_k >= 25) qp_to_al = true;   // no acceptable step along the QP's direction (x and the multipliers are those of the last accepted point)
 						else {
 							qp_alpha *= 0.5;
 							const double a = qp_alpha;
@@ -2146,17 +2186,39 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						iter++;
 					}
 				}
-				if (!qp_exit) {
+				if (!qp_exit && !qp_to_al) {
 					qp_first = false;
 					F = Fn; Fp = Fpn; gn2 = gn2n; rv2 = rv2n; at_x = true;
 					qp_viol1 = part[2] / qp_rho;
 					if (iter >= sp.itlim) { inform = 4; qp_exit = true; }
 				}
-				if (!qp_exit) {
+				if (!qp_exit && !qp_to_al) {
 					qp_major();
-					if (qp_pn <= 1e-2 * sp.sr * (1.0 + qp_xn) && sqrt(rv2) <= 1e-8) {
+					if (qp_full) qp_to_al = true;
+				}
+				if (qp_to_al) {
+					// The working set of a group is full (NTG_QP_MAXA slots; rows active along a whole arc of the trajectory: the QP was not
+					// solved, and its step would not restore feasibility), or the l1 merit function found no acceptable step along the QP's
+					// direction.  This problem continues with the augmented-Lagrangian passes of the structured Newton mode from the current
+					// point and the current multipliers (the warm-start path of hessian = 2): the mode is never less robust than that one.
+					{
+						al.qp = 0; al.mu = 10.0; qp_fell++;
+						sri = fmax(sp.sr, 1e-3); rvprev = HUGE_VAL; outer = 0;
+						npairs = 0; finished = false; inner_inform = 4; state = ST_INIT; weak = false; at_x = true;
+						__syncthreads();
+						for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
+						continue;
+					}
+				}
+				if (!qp_exit) {
+					// exit: the step is small, the rows are feasible, and the reduced gradient of the Lagrangian meets NPSOL's optimality tolerance
+					if (qp_pn <= 1e-2 * sp.sr * (1.0 + qp_xn) && sqrt(rv2) <= 1e-8 && qp_gl <= 0.1 * sp.sr * (1.0 + fmax(1.0 + fabs(Fp), sqrt(gn2)))) {
+						// the last step is taken (it is below the exit tolerance, but K is large: the point it leads to is stationary to rounding --
+						// a solve that ends right after phase 0 would otherwise keep that pass's looser tolerance); the final pass below
+						// evaluates there: objective, multipliers of the linear rows
 						for (int j = tid; j < ncn; j += NT) al_lam[j] = qp_lamq[j];
-						inform = 0; qp_exit = true;
+						for_vec<NT>(n, [&](int c) { sx[c] += sgp[c]; });
+						inform = 0; qp_exit = true; qp_last = true;
 					} else {
 						if (qp_rho < 1.5 * qp_lmax + 1e-3) qp_rho = 2.0 * qp_lmax + 1e-3;
 						al.mu = qp_rho;
@@ -2167,8 +2229,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				}
 				// exit: one more pass for the linear rows' multipliers, with the gradient of the Lagrangian (ALState::qp = 2)
 				__syncthreads();
-				if (clambda && m > 0) {
+				if ((clambda || qp_last) && m > 0) {
 					state = ST_FINAL; al.qp = 2;
+					make_feasible();   // before the pass that evaluates the multipliers: the x that is reported is the x they belong to
 					lds_sync();
 					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 					continue;
@@ -2367,6 +2430,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					al.mu = qp_rho = 1.0; al.qp = 1;
 					state = ST_QP; qp_first = true; finished = false;
 					__syncthreads();
+					make_feasible();   // like every further pass of the other modes: the first projection leaves a residual of rounding x cond(A A')
 					for_vec<NT>(n, [&](int c) { sxt[c] = sx[c]; });
 					continue;
 				}
@@ -2449,7 +2513,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 #endif
 		if (sp.stamps == 3 && tid == 0) {   // diagnostic: work counters of the structured Newton mode
 			double *o = clambda + (size_t)b * ntot;
-			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev; o[6] = qp_nsolve; o[7] = qp_ncol; o[8] = qp_over;
+			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev; o[6] = qp_nsolve; o[7] = qp_ncol; o[8] = qp_over; o[9] = qp_fell;
 		}
 		if (sp.stamps == 2 && tid == 0) {   // diagnostic: state of the augmented-Lagrangian loop at exit
 			double *o = clambda + (size_t)b * ntot;

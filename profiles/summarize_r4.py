@@ -89,6 +89,21 @@ mf = counters("pmc_conv_h1_big_mfma", "sqp_wave_kernel")
 if mf:
     mf["note"] = "to-convergence launch (65536 x config M, collocation preconditioner): W0 v on v_mfma_f64_16x16x4_f64, 64 instructions per product, ~4 products per problem"
     json.dump(mf, open(os.path.join(DST, "r04_mfma_conv.json"), "w"), indent=1)
+# config E, 1024 problems: matrix-core counters of the QP-based SQP step (hessian = 3) and of the structured Newton mode (2), HBM traffic of the former
+qe = {}
+for what in ("qp_E", "newton_E"):
+    c = counters(f"pmc_{what}_mfma", "sqp_kernel")
+    if c:
+        c["MfmaUtil_pct (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES x 100, the guide's definition)"] = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(c.get("SQ_BUSY_CYCLES", 1.0), 1.0)
+        qe[what] = c
+fe = counters("pmc_qp_E_fetch", "sqp_kernel"); wr = counters("pmc_qp_E_write", "sqp_kernel")
+if "FETCH_SIZE" in fe and "WRITE_SIZE" in wr:
+    qe["qp_E_traffic"] = {"fetch_bytes": fe["FETCH_SIZE"] * 2048, "write_bytes": wr["WRITE_SIZE"] * 1024, "hbm_bytes": fe["FETCH_SIZE"] * 2048 + wr["WRITE_SIZE"] * 1024,
+                          "note": "per launch of 1024 problems; the evaluations' algorithmic bytes: 19 evaluations x 738 280 B x 1024 = 14.4 GB"}
+if qe:
+    qe["csrc_sha"] = SHA
+    qe["note"] = "config E (12-output manipulator), 1024 problems per launch, averaged over 2 launches; sqp_kernel<manipulator, 12, 6, 512, 5, BIG, ..., NWT[, QPM]>"
+    json.dump(qe, open(os.path.join(DST, "r04_config_E_modes.json"), "w"), indent=1)
 json.dump(summ, open(os.path.join(DST, "r04_summary.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summ.items() if "wave" in k or "headline" in k}, indent=1)[:3000])
 print({k: traffic[k] for k in traffic if "wave" in k})

@@ -6,6 +6,16 @@ import torch
 from ntg_amd import api, configs as cf
 which = sys.argv[1] if len(sys.argv) > 1 else "fixed50"
 dev = "cuda:0"
+if which in ("qp_E", "newton_E"):   # config E, 1024 problems: the QP-based SQP step (hessian = 3) / the structured Newton mode (2); two launches
+    spec = cf.config_E(); plan = api.Plan(spec, 0)
+    lo_n, up_n = cf.manipulator_bounds(1024)
+    lo = torch.tensor(lo_n, device=dev); up = torch.tensor(up_n, device=dev)
+    o = api.default_opts(hessian=3 if which == "qp_E" else 2)
+    w = torch.empty(plan.workspace_bytes(1024, o), dtype=torch.uint8, device=dev)
+    for _ in range(2):
+        x = torch.ones((1024, spec.nC), dtype=torch.float64, device=dev); plan.solve(lo, up, x, o, work=w)
+    torch.cuda.synchronize()
+    sys.exit(0)
 spec = cf.config_M(); plan = api.Plan(spec, 0)
 B = 65536 if which == "conv_h1_big" else 4096
 lo, up = cf.kincar_random_bounds(3, 4096)
