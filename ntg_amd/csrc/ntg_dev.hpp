@@ -61,6 +61,7 @@ struct NtgDims {
 	// groups overlap a coefficient (colours of the assembly), and the constraint flag entries of a group packed one byte
 	// each: (output within the group) << 4 | derivative
 	int nwt_nint, nwt_cover;
+	int nwt_tab;   // NtgTables::nwt_tu / nwt_g are there
 	u64 nwt_upack;
 	int nwt_clo, nwt_chi;               // the free local coefficients of every output: [clo, chi); free index p = (cl - clo) go + o
 };
@@ -101,6 +102,11 @@ struct NtgTables {
 	// structured Newton mode: nwt_map[g][p] = coefficient of free entry p of group g; nwt_pos[c] = g * nwt_ng + p, or -1 for a
 	// pinned coefficient; nwt_k0 = cost-model band [g][p][hb+1]; nwt_lo/hi[cl] = breakpoints [lo, hi) in whose block cl lies
 	const int *nwt_map, *nwt_pos; const double *nwt_k0; const short *nwt_lo, *nwt_hi;
+	// QP-based SQP step in the regime without constraint curvature (the model is the cost model K0, the same for every problem and major):
+	// nwt_tu[i][u][p] = (K0^-1 M_i' e_u)[p], the column of W for flag entry u of a group at breakpoint i; nwt_g[k][i][v][u] = e_v' M_k K0^-1 M_i' e_u.
+	// A slot's column W J' and its J U over all rows are then short combinations of table rows instead of a band solve and a breakpoint pass
+	// (NtgDims::nwt_tab = 1: every coupling group has the same cost model, tables built with the plan)
+	const double *nwt_tu, *nwt_g;
 	const double *nwt_lf;   // [nwt_nfo][nwt_ngf][nwt_hbf + 1]: band Cholesky factor (diagonal inverted) of the free outputs' cost model, built with the plan
 	const short *q_idx;    // [nC] row of coefficient c in the compact Q, or -1
 	const unsigned char *q_pinned;   // [nC] 1: coefficient c is pinned by the equality rows (NtgDims::q_pin plans only)

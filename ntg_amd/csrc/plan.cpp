@@ -468,7 +468,7 @@ extern "C" int ntg_plan_create(const ntg_spec *s, int device, ntg_plan **out)
 static int build_newton_tables(ntg_plan *p)
 {
 	NtgDims &D = p->D;
-	D.nwt_on = 0;
+	D.nwt_on = 0; D.nwt_tab = 0; p->T.nwt_tu = p->T.nwt_g = nullptr;
 	int go = 0, cg = 0;
 	u64 gmask = 0;   // constraint flag entries of group 0, relative to the group's first flag entry
 	const int dm = D.d[0];
@@ -585,6 +585,50 @@ static int build_newton_tables(ntg_plan *p)
 		for (int o = 0; o < D.nout; o++) for (int cl = 0; cl < nco; cl++) if ((bool)pinned[D.iC[o] + cl] != !(cl >= clo && cl < chi)) return 0;
 		D.nwt_clo = clo; D.nwt_chi = chi;
 	}
+	// ---- tables of the QP-based SQP step's regime without constraint curvature (NtgTables::nwt_tu, nwt_g): K0 is then the model of every
+	//      major iteration of every problem, so K0^-1 M_i' per breakpoint and M_k K0^-1 M_i' per pair of breakpoints are plan constants.
+	//      Built when all coupling groups share one cost model and the tables stay under 48 MB. ----
+	std::vector<double> tu, gt;
+	{
+		bool same = true;
+		for (int g = 1; g < ngrp && same; g++) for (size_t e = 0; e < (size_t)ng * ld; e++) if (k0[(size_t)g * ng * ld + e] != k0[e]) { same = false; break; }
+		const size_t ntu = (size_t)P * cg * ng, ngt2 = (size_t)P * P * cg * cg;
+		if (same && (ntu + ngt2) * 8 <= (size_t)48 << 20 && !getenv("NTG_AMD_NO_QPTAB")) {
+			// band Cholesky of K0 (group 0), compact lower band: L(i, j) at l[i * ld + (j - i + hb)]
+			std::vector<double> l(k0.begin(), k0.begin() + (size_t)ng * ld);
+			auto L = [&](int i, int j) -> double & { return l[(size_t)i * ld + (j - i + hb)]; };
+			bool ok = true;
+			for (int j = 0; j < ng && ok; j++) {
+				double d = L(j, j);
+				for (int t = std::max(0, j - hb); t < j; t++) d -= L(j, t) * L(j, t);
+				if (!(d > 0.0)) { ok = false; break; }
+				d = std::sqrt(d); L(j, j) = d;
+				for (int i = j + 1; i <= std::min(ng - 1, j + hb); i++) {
+					double sv = L(i, j);
+					for (int t = std::max(0, i - hb); t < j; t++) sv -= L(i, t) * L(j, t);
+					L(i, j) = sv / d;
+				}
+			}
+			if (ok) {
+				tu.assign(ntu, 0.0); gt.assign(ngt2, 0.0);
+				std::vector<int> uo(cg), ur(cg);
+				for (int u = 0; u < cg; u++) { uo[u] = (int)((upack >> (8 * u + 4)) & 15u); ur[u] = (int)((upack >> (8 * u)) & 15u); }
+				const int clo = D.nwt_clo, chi = D.nwt_chi;
+				for (int i = 0; i < P; i++) for (int u = 0; u < cg; u++) {
+					double *t = tu.data() + ((size_t)i * cg + u) * ng;
+					for (int q = 0; q < k; q++) { const int cl = off[i] + q; if (cl >= clo && cl < chi) t[(cl - clo) * go + uo[u]] = blk[((size_t)i * k + q) * dm + ur[u]]; }
+					for (int r = 0; r < ng; r++) { double sv = t[r]; for (int c2 = std::max(0, r - hb); c2 < r; c2++) sv -= L(r, c2) * t[c2]; t[r] = sv / L(r, r); }
+					for (int r = ng - 1; r >= 0; r--) { double sv = t[r]; for (int c2 = r + 1; c2 <= std::min(ng - 1, r + hb); c2++) sv -= L(c2, r) * t[c2]; t[r] = sv / L(r, r); }
+				}
+				for (int kb = 0; kb < P; kb++) for (int i = 0; i < P; i++) for (int v = 0; v < cg; v++) for (int u = 0; u < cg; u++) {
+					const double *t = tu.data() + ((size_t)i * cg + u) * ng;
+					double sv = 0.0;
+					for (int q = 0; q < k; q++) { const int cl = off[kb] + q; if (cl >= clo && cl < chi) sv += blk[((size_t)kb * k + q) * dm + ur[v]] * t[(cl - clo) * go + uo[v]]; }
+					gt[(((size_t)kb * P + i) * cg + v) * cg + u] = sv;
+				}
+			}
+		}
+	}
 	// two-sided factorisation: two waves per group when the band is long enough and the largest workgroup has the waves (newton.hpp).  The
 	// cost model is then split like the band: rows of the top part and the separator stay where they are, the entries of bottom rows move
 	// to the reversed array (entry (i, j) -> row n - 1 - j, same band offset), which follows the groups' top arrays in the table.
@@ -612,6 +656,12 @@ static int build_newton_tables(ntg_plan *p)
 		for (int i = 0; i < ngf; i++) for (int e = 0; e <= hbf; e++) { const int j = i - hbf + e; if (j >= 0) a[(size_t)i * ngf + j] = a[(size_t)j * ngf + i] = k0f[((size_t)f * ngf + i) * ldf + e]; }
 		if (!chol_lower(a, ngf)) return 0;   // a cost that leaves a free output without curvature: no structured Newton mode
 		for (int i = 0; i < ngf; i++) for (int e = 0; e <= hbf; e++) { const int j = i - hbf + e; if (j >= 0) lf[((size_t)f * ngf + i) * ldf + e] = (j == i) ? 1.0 / a[(size_t)i * ngf + i] : a[(size_t)i * ngf + j]; }
+	}
+	D.nwt_tab = 0; p->T.nwt_tu = p->T.nwt_g = nullptr;
+	if (!tu.empty()) {
+		double *d_tu = nullptr, *d_g = nullptr;
+		if (dev_upload(&d_tu, tu.data(), tu.size(), p->owned) || dev_upload(&d_g, gt.data(), gt.size(), p->owned)) return NTG_E_HIP;
+		p->T.nwt_tu = d_tu; p->T.nwt_g = d_g; D.nwt_tab = 1;
 	}
 	int *d_map = nullptr, *d_pos = nullptr; double *d_k0 = nullptr, *d_lf = nullptr; short *d_lo = nullptr, *d_hi = nullptr;
 	if (dev_upload(&d_lf, lf.data(), lf.size(), p->owned)) return NTG_E_HIP;

@@ -1779,9 +1779,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	double *qpbase = (double *)(smem_raw + L.nwt_y) + nwt_yall + nwt_npan * NWT_PANEL + D.nwt_nfo * qp_ylenf;
 	double *qpred = qpbase + D.nwt_ngrp * NTG_QP_DOUBLES;   // [waves][rows per breakpoint][2] scratch of the entering-row search
 	double qp_rho = 1.0, qp_phi0 = 0.0, qp_D = 0.0, qp_alpha = 1.0, qp_viol1 = 0.0, qp_pn = 0.0, qp_xn = 0.0, qp_lmax = 0.0, qp_gl = 0.0;
-	int qp_k = 0, qp_over = 0, qp_nsolve = 0, qp_ncol = 0, qp_nocurv = 0, qp_fell = 0;
+	int qp_k = 0, qp_over = 0, qp_nsolve = 0, qp_ncol = 0, qp_nocurv = 0, qp_fell = 0, qp_ntab = 0;
 	bool qp_first = true, qp_full = false, qp_last = false;   // qp_last: the final pass evaluates at the point the last step led to   // qp_full: a group's working set did not hold every row the last QP wanted
-	(void)qp_over; (void)qp_nsolve; (void)qp_ncol; (void)qp_fell;
+	(void)qp_over; (void)qp_nsolve; (void)qp_ncol; (void)qp_fell; (void)qp_ntab;
 	// flag entry (index into z) of variable u of group g
 	auto qp_flag = [&](int g, int u) __attribute__((always_inline)) { return FamN::DM * (g * D.nwt_go + (int)((D.nwt_upack >> (8 * u + 4)) & 15u)) + (int)((D.nwt_upack >> (8 * u)) & 15u); };
 	// Row caches of one major iteration (HBM, per problem): for every trajectory row (constraint-major, like c) its value c, J W g, its
@@ -1858,6 +1858,58 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	auto qp_column = [&]() __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, go = D.nwt_go, kk = K > 0 ? K : D.order[0];
 		__syncthreads();
+		if (D.nwt_tab && !nwt_curv) {   // (the current factor is the cost model's: K0)
+			// The model is the cost model K0 (no constraint curvature any more in this solve): W M_i' per breakpoint and M_k W M_i' per pair
+			// of breakpoints are the plan's tables (NtgTables::nwt_tu, nwt_g) -- the column and its J U are short combinations of table
+			// rows, no band solve, no breakpoint pass.
+			constexpr int CGc = FamN::CG, NTc2 = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
+			for (int c = tid; c < n; c += NT) {
+				const int pos = T.nwt_pos[c];
+				if (pos >= 0 && pos < ngp * ng) {
+					const int g = pos / ng, pp = pos - g * ng;
+					QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+					const int a = q.flag[0];
+					if (a < 0) continue;
+					const int i = q.row[a] % P;
+					double uv = 0.0;
+#pragma unroll
+					for (int u = 0; u < CGc; u++) uv += q.ar[a * NTG_QP_MAXCG + u] * T.nwt_tu[((size_t)i * CGc + u) * ng + pp];
+					qp_U[(size_t)a * npad + c] = uv;
+				}
+			}
+			for (int i2 = tid; i2 < P; i2 += NT) {
+#pragma unroll
+				for (int j = 0; j < NTc2; j++) {
+					if (j >= D.nnltc) continue;
+					const int g = FamN::row_group(j), row = j * P + i2;
+					QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+					const int a = q.flag[0];
+					if (a < 0) continue;
+					const int i = q.row[a] % P;
+					const double *gp2 = T.nwt_g + ((size_t)i2 * P + i) * CGc * CGc;
+					double ju = 0.0;
+#pragma unroll
+					for (int v = 0; v < CGc; v++) {
+						double sv = 0.0;
+#pragma unroll
+						for (int u = 0; u < CGc; u++) sv += gp2[v * CGc + u] * q.ar[a * NTG_QP_MAXCG + u];
+						ju += qp_a[(size_t)row * CGc + v] * sv;
+					}
+					qp_JU[(size_t)a * ncq + row] = ju;
+				}
+			}
+			__syncthreads();
+			for (int e = tid; e < ngp * QA; e += NT) {
+				const int g = e / QA, a2 = e - g * QA;
+				QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+				const int bcol = q.flag[0];
+				if (bcol < 0 || a2 >= *q.ns) continue;
+				q.S[a2 <= bcol ? NTG_QP_TR(bcol, a2) : NTG_QP_TR(a2, bcol)] = qp_JU[(size_t)bcol * ncq + q.row[a2]];
+			}
+			qp_ntab++;
+			__syncthreads();
+			return;
+		}
 		for (int c = tid; c < n; c += NT) sgpt[c] = 0.0;
 		__syncthreads();
 		for (int e = tid; e < ngp * go * kk; e += NT) {
@@ -2513,7 +2565,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 #endif
 		if (sp.stamps == 3 && tid == 0) {   // diagnostic: work counters of the structured Newton mode
 			double *o = clambda + (size_t)b * ntot;
-			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev; o[6] = qp_nsolve; o[7] = qp_ncol; o[8] = qp_over; o[9] = qp_fell;
+			o[0] = nwt_nfact; o[1] = nwt_nfail; o[2] = nwt_napply; o[3] = outer; o[4] = iter; o[5] = nfev; o[6] = qp_nsolve; o[7] = qp_ncol; o[8] = qp_over; o[9] = qp_fell; o[10] = qp_ntab;
 		}
 		if (sp.stamps == 2 && tid == 0) {   // diagnostic: state of the augmented-Lagrangian loop at exit
 			double *o = clambda + (size_t)b * ntot;

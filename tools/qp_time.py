@@ -25,8 +25,8 @@ for h in modes:
     inf = out["inform"].cpu().numpy(); it = out["iters"].cpu().numpy(); nf = out["nfev"].cpu().numpy()
     print(f"{which} hessian={h} batch {B}: {dt*1e3:.2f} ms -> {B/dt:.0f} traj/s; inform {np.bincount(inf).tolist()} majors mean {it.mean():.1f} max {it.max()} nfev mean {nf.mean():.1f}", flush=True)
     if st == "3":
-        d = out["clambda"][:, :9].cpu().numpy()
-        print("   per problem: factorisations %.1f (not PD %.1f) band solves %.1f | passive-set solves %.1f columns %.1f majors with a full working set %.2f (max %d)" % (d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 6].mean(), d[:, 7].mean(), d[:, 8].mean(), d[:, 8].max()))
+        d = out["clambda"][:, :11].cpu().numpy()
+        print("   per problem: factorisations %.1f (not PD %.1f) band solves %.1f | passive-set solves %.1f columns %.1f majors with a full working set %.2f (max %d)" % (d[:, 0].mean(), d[:, 1].mean(), d[:, 2].mean(), d[:, 6].mean(), d[:, 7].mean(), d[:, 8].mean(), d[:, 8].max()), "| columns from the tables %.1f, problems that fell back %d" % (d[:, 10].mean(), (d[:, 9] > 0).sum()))
     if st == "1":
         tk = out["clambda"][:, :8].cpu().numpy()
         names = ["qp column", "eval", "qp search/solve/step", "assemble", "W g", "rest", "Bpass", "factor"] if h == 3 else ["setup", "eval", "project", "assemble", "solve", "rest", "Bpass", "factor"]
