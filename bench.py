@@ -408,7 +408,20 @@ def main():
             xO.copy_(xO0); ooO = planO.solve(loO, upO, xO, oO, work=wO)
         torch.cuda.synchronize(); dto = (time.perf_counter() - t1) / 3
         infO = ooO["inform"].cpu().numpy()
-        res["constrained_obstacle"] = {"value": B / dto, "unit": "trajectories/s", "ms_per_batch": 1e3 * dto, "batch": B,
+        # (beside it, the QP-based SQP step, hessian = 3: a fifth of the majors; at this size the quasi-Newton passes are the faster ones per major)
+        oOq = api.default_opts(hessian=3)
+        wOq = torch.empty(planO.workspace_bytes(B, oOq), dtype=torch.uint8, device=dev)
+        for _ in range(2):
+            xO.copy_(xO0); ooOq = planO.solve(loO, upO, xO, oOq, work=wOq)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(3):
+            xO.copy_(xO0); ooOq = planO.solve(loO, upO, xO, oOq, work=wOq)
+        torch.cuda.synchronize(); dtoq = (time.perf_counter() - t1) / 3
+        infOq = ooOq["inform"].cpu().numpy()
+        obst_qp = {"value": B / dtoq, "unit": "trajectories/s", "ms_per_batch": 1e3 * dtoq, "inform_counts": {str(k): int((infOq == k).sum()) for k in np.unique(infOq)},
+                   "iters_mean": float(ooOq["iters"].float().mean().item()), "iters_max": int(ooOq["iters"].max().item()), "nfev_mean": float(ooOq["nfev"].float().mean().item())}
+        del wOq
+        res["constrained_obstacle"] = {"value": B / dto, "unit": "trajectories/s", "ms_per_batch": 1e3 * dto, "batch": B, "qp_sqp": obst_qp, "nfev_mean": float(ooO["nfev"].float().mean().item()),
                                        "workload": specO.name + ": 101 nonlinear trajectory inequalities per problem, augmented-Lagrangian outer loop",
                                        "inform_counts": {str(k): int((infO == k).sum()) for k in np.unique(infO)},
                                        "iters_mean": float(ooO["iters"].float().mean().item()), "iters_max": int(ooO["iters"].max().item())}
@@ -418,27 +431,43 @@ def main():
         nbM, nresM = 1024, 20
         loM, upM = cf.obstacle_bounds(nbM)
         mo = {}
-        for tag, ws in (("cold_every_step", 0), ("multipliers_carried_over", 1)):
-            oM = api.default_opts(hessian=1, warm_start=ws)
+        # (round 4: the QP-based SQP step, hessian = 3 -- its warm start IS the carried-over working set -- host loop and, last, the library's own
+        #  loop: (solve, count, shift, multiplier shift) captured once in a hipGraph and replayed, ntg_batch_mpc_run; the quasi-Newton
+        #  augmented-Lagrangian mode of round 3 stays beside it.  Majors and non-converged counts accumulate on the device: no sync per step.)
+        for tag, hM, ws in (("cold_every_step", 3, 0), ("multipliers_carried_over", 3, 1), ("quasi_newton_cold_every_step", 1, 0), ("quasi_newton_multipliers_carried_over", 1, 1)):
+            oM = api.default_opts(hessian=hM, warm_start=ws)
             wM = torch.empty(planO.workspace_bytes(nbM, oM), dtype=torch.uint8, device=dev)
             loM1 = torch.tensor(loM, device=dev); upM1 = torch.tensor(upM, device=dev)
             xM = torch.ones((nbM, specO.nC), dtype=torch.float64, device=dev)
-            o_first = api.default_opts(hessian=1)
+            o_first = api.default_opts(hessian=hM)
             planO.solve(loM1, upM1, xM, o_first, work=wM); planO.mpc_shift(xM, loM1, upM1, 5, 1)
             if ws:
                 planO.mpc_shift_multipliers(nbM, 5, oM, wM)
+            majd = torch.zeros((), dtype=torch.float64, device=dev); notd = torch.zeros((), dtype=torch.int64, device=dev)
             torch.cuda.synchronize(); t1 = time.perf_counter()
-            maj = 0; notc = 0
             for _ in range(nresM):
                 ooM = planO.solve(loM1, upM1, xM, oM, work=wM)
                 planO.mpc_shift(xM, loM1, upM1, 5, 1)
                 if ws:
                     planO.mpc_shift_multipliers(nbM, 5, oM, wM)
-                maj += float(ooM["iters"].float().mean().item()); notc += int((ooM["inform"] != 0).sum().item())
+                majd += ooM["iters"].double().mean(); notd += (ooM["inform"] != 0).sum()
             torch.cuda.synchronize(); dtM = time.perf_counter() - t1
-            mo[tag] = {"value": nbM * nresM / dtM, "unit": "re-solves/s", "ms_per_resolve_batch": 1e3 * dtM / nresM, "majors_per_resolve": maj / nresM, "not_converged": notc}
+            mo[tag] = {"value": nbM * nresM / dtM, "unit": "re-solves/s", "ms_per_resolve_batch": 1e3 * dtM / nresM, "majors_per_resolve": float(majd.item()) / nresM,
+                       "not_converged": int(notd.item()), "mode": "QP-based SQP step (hessian = 3)" if hM == 3 else "quasi-Newton augmented Lagrangian (hessian = 1)"}
             del wM
-        mo["workload"] = specO.name + f": {nresM} re-solves x {nbM}, advance one knot interval per re-solve (host loop: solve, shift, multiplier shift)"
+        if True:
+            oM = api.default_opts(hessian=3, warm_start=1)
+            wM = torch.empty(planO.workspace_bytes(nbM, oM), dtype=torch.uint8, device=dev)
+            loM1 = torch.tensor(loM, device=dev); upM1 = torch.tensor(upM, device=dev)
+            xM = torch.ones((nbM, specO.nC), dtype=torch.float64, device=dev)
+            planO.mpc_run(xM, loM1, upM1, 2, 5, 1, oM, work=wM)   # first (cold) step and graph code paths warm
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            _, badM = planO.mpc_run(xM, loM1, upM1, nresM + 1, 5, 1, oM, work=wM)   # one cold step + nresM warm ones inside the library
+            torch.cuda.synchronize(); dtM = time.perf_counter() - t1
+            mo["multipliers_carried_over_hipgraph"] = {"value": nbM * (nresM + 1) / dtM, "unit": "re-solves/s", "ms_per_resolve_batch": 1e3 * dtM / (nresM + 1),
+                                                       "not_converged": int(badM.item()), "mode": "ntg_batch_mpc_run: QP-based SQP step, warm, hipGraph replay (the first of the %d steps is cold)" % (nresM + 1)}
+            del wM
+        mo["workload"] = specO.name + f": {nresM} re-solves x {nbM}, advance one knot interval per re-solve (host loop: solve, shift, multiplier shift; _hipgraph: the library's captured loop)"
         res["mpc_obstacle"] = mo
         # ---- BASELINE configs D and E at their full sizes, to convergence (per-GPU share of the 8-GPU batch): the structured
         #      Newton mode (hessian = 2) and, beside it, the quasi-Newton mode of round 1.  (`bench.py --config D|E
@@ -474,6 +503,15 @@ def main():
                     del os.environ["NTG_AMD_STAMPS"]
                     cntL = od["clambda"][:, :10].cpu().numpy()
                     e["mfma"] = newton_mfma_entry(specL, key, cntL[:, :3], nbL, dtl, MFMA_PEAK_TF)
+                    if key == "config_E":   # matrix-core counters of the same launch (rocprofv3 --pmc pass, profiles/r04_config_E_modes.json), for these device sources only
+                        try:
+                            cj = json.load(open(os.path.join(ROOT, "profiles", "r04_config_E_modes.json")))
+                            ck = cj.get("qp_E" if mode == "qp_sqp" else "newton_E")
+                            if ck and cj.get("csrc_sha") == csrc_sha():
+                                e["mfma"]["counters"] = {"SQ_INSTS_MFMA": ck["SQ_INSTS_MFMA"], "MfmaUtil_pct": ck["MfmaUtil_pct"], "mfma_flops": ck["mfma_flops"],
+                                                         "achieved_tflops": ck["mfma_flops"] / dtl / 1e12}
+                        except Exception:
+                            pass
                     e["band_solves_per_problem"] = float(cntL[:, 2].mean())
                     if mode == "qp_sqp":
                         # the dual active-set QP: passive-set solves, columns W J' formed (one band solve each, all coupling groups at once),

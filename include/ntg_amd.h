@@ -91,7 +91,8 @@ typedef struct {
 	                     * 3 QP-based SQP step on the same band model: per major iteration the inequality QP on the linearised rows (what NPSOL does with the
 	                     *   Jacobian ntg() hands it, ntg.c:217-220,250-253), solved through its dual by an active-set method on at most 16 rows per
 	                     *   coupling group, l1 merit function; a problem whose working set does not fit continues in mode 2 by itself.  Config E:
-	                     *   17 majors instead of 60, 1.9 x mode 2's rate.  Acts as 2 with warm_start, as 1 where the band model does not apply. */
+	                     *   17 majors instead of 60, 2.9 x mode 2's rate.  With warm_start the QP's first working set is the rows the carried-over
+	                     *   multipliers name (no pass on the objective alone).  Acts as 1 where the band model does not apply. */
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */
 	int block_threads;  /* 0 = auto (128/256/512) */
 	int qn_memory;      /* quasi-Newton updates kept before the approximation restarts from W0; <= 0: 256 */

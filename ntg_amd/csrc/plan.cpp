@@ -885,9 +885,7 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	// preconditioner.  Decided HERE, once: workspace size, layout and launch all see the same mode (a switch after the workspace was sized
 	// for hessian = 2 -- no quasi-Newton history -- would let the quasi-Newton mode write its history past the end of the workspace).
 	if (sp->hessian < 0 || sp->hessian > 3) sp->hessian = 0;
-	// the QP-based SQP step (hessian = 3) rides on the structured Newton mode's band model: where that does not apply it does not either;
-	// a warm start of the multipliers (receding horizon) belongs to the augmented-Lagrangian passes of mode 2
-	if (sp->hessian == 3 && sp->warm) sp->hessian = 2;
+	// the QP-based SQP step (hessian = 3) rides on the structured Newton mode's band model: where that does not apply it does not either
 	if (sp->hessian >= 2 && (!D.nwt_on || p->grid_batch)) sp->hessian = 1;
 	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);

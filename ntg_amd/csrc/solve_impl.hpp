@@ -2168,6 +2168,13 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			sri = fmax(sp.sr, 1e-3);
 			__syncthreads();   // multipliers cross lanes through HBM: full barrier
+			if (QPM && sp.warm) {
+				// warm start of the QP-based SQP step (receding horizon): no pass on the objective alone -- the QP's first working set is the rows
+				// the shifted multipliers of the previous solve name (ntg.h:64-68: what istate / clambda were meant to carry)
+				for (int j = tid; j < ncn; j += NT) qp_lamq[j] = al_lam[j];
+				al.mu = qp_rho = 1.0; al.qp = 1; state = ST_QP; qp_first = true;
+				__syncthreads();
+			}
 		}
 		NTG_STAMP(0);
 
@@ -2281,7 +2288,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				}
 				// exit: one more pass for the linear rows' multipliers, with the gradient of the Lagrangian (ALState::qp = 2)
 				__syncthreads();
-				if ((clambda || qp_last) && m > 0) {
+				if (m > 0) {   // (always: the pass also leaves the multipliers in the workspace, where a warm start of the next solve finds them)
 					state = ST_FINAL; al.qp = 2;
 					make_feasible();   // before the pass that evaluates the multipliers: the x that is reported is the x they belong to
 					lds_sync();

@@ -792,7 +792,12 @@ sqp_wave_kernel(NtgDims D, NtgTables T, SolveParams sp, WaveArgs A)
 						double sv[EPL], tv[EPL];
 #pragma unroll
 						for (int e = 0; e < EPL; e++) { sv[e] = alpha * (-d[e]); x[e] = x[e] + tstep * (-d[e]); }   // (tstep == alpha: the point just evaluated)
-						if (nupd == sp.memcap || ns + 3 > cap) {   // memory full: restart the approximation from W0 (oracle/sqp.c does the same at the same count)
+						// memory full: restart the approximation from W0.  oracle/sqp.c restarts when the number of UPDATES reaches the memory; here a
+						// skipped update (s'y <= 1e-12 |s||y|: a null link) still takes a chain slot, so after skipped updates the slots can run out
+						// before the update count does and this kernel restarts a few majors EARLIER than the oracle and sqp_kernel -- a different (still
+						// valid) quasi-Newton operator from there on.  On the strictly convex problems of this kernel's class s'y > 0 at every accepted
+						// step (no update is ever skipped: the fixed-iteration parity tests compare evaluation counts), so the two conditions coincide.
+						if (nupd == sp.memcap || ns + 3 > cap) {
 							nupd = 0; ns = 0; headpair = true;
 							apply_w0(gp, d);
 						}

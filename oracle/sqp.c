@@ -684,7 +684,7 @@ static double al_eval(al_t *a, const double *x, double *g, double *rv_out, doubl
  * Returns 0 converged, 4 iteration limit, 6 no acceptable step. */
 typedef struct { int majors, nfev, qp_iters, max_active; } sqpqp_stats;
 static int sqpqp_run(orc_problem *p, nwt_t *nw, al_t *al, const proj_t *pj, double *x, int n, int nc, int m_lin, const orc_sqp_opts *o, double sr, double ftol,
-                     int *iter, int itlim, double *lam, double *g, double *F_out, sqpqp_stats *st)
+                     int *iter, int itlim, double *lam, double *g, double *F_out, sqpqp_stats *st, int warm)
 {
 	const int mall = m_lin;
 	double *c = al->c, *Wg = malloc(n * sizeof(double)), *pstep = malloc(n * sizeof(double)), *xt = malloc(n * sizeof(double)), *gt = malloc(n * sizeof(double));
@@ -702,6 +702,7 @@ static int sqpqp_run(orc_problem *p, nwt_t *nw, al_t *al, const proj_t *pj, doub
 		if (bu < 1e19) { vrow[nv] = j; vsgn[nv++] = 1; }
 		if (bl > -1e19) { vrow[nv] = j; vsgn[nv++] = -1; }
 	}
+	if (warm) for (k = 0; k < nv; k++) { const double lj = lam[vrow[k]]; nu[k] = vsgn[k] == 0 ? lj : (vsgn[k] > 0 ? (lj > 0.0 ? lj : 0.0) : (lj < 0.0 ? -lj : 0.0)); }
 	al->mu = 0.0;   /* al_eval: objective and gradient alone, c and the dense Jacobian (p->cJac) as by-products */
 	F = al_eval(al, x, g, &rvd, &gnd);
 	memset(st, 0, sizeof(*st));
@@ -885,6 +886,17 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 #define RESET_W() do { nupd = 0; if (nw) nwt_refresh(nw, x, al.mu, t_x, 0); else if (W0) memcpy(W, W0, (size_t)n * n * sizeof(double)); \
 	else { memset(W, 0, (size_t)n * n * sizeof(double)); for (i = 0; i < n; i++) M_(W, n, i, i) = 1.0; } } while (0)
 
+#define QP_RUN(WARM) do { \
+	sqpqp_stats st; \
+	inform = sqpqp_run(p, nw, &al, &pj, x, n, nc, mall, o, sr, ftol, &iter, itlim, al.lam, g, &F, &st, (WARM)); \
+	{ int jj, ii; for (jj = 0; jj < nc; jj++) if (al.lam[jj] != 0.0) for (ii = 0; ii < n; ii++) g[ii] += al.lam[jj] * M_(p->cJac, nc, jj, ii); }   /* gradient of the Lagrangian: the linear rows' multipliers */ \
+	project(&pj, g, gp, lam); \
+	rv = 0.0; { int jj; for (jj = 0; jj < nc; jj++) { const double bl = p->bl[n + mall + jj], bu = p->bu[n + mall + jj], cj = al.c[jj], pjv = cj < bl ? bl : (cj > bu ? bu : cj), rj = (cj - pjv) / (1.0 + fabs(cj)); rv += rj * rj; } rv = sqrt(rv); } \
+	if (o->verbose) fprintf(stderr, "  sqp-qp: %d majors, %d evaluations, %d passive-set solves, at most %d active rows\n", st.majors, st.nfev, st.qp_iters, st.max_active); \
+} while (0)
+	/* warm start of the QP-based SQP step (receding horizon): no pass on the objective alone, the QP's first working set is the rows the
+	 * carried-over multipliers name */
+	if (o->hessian == 3 && newton && o->warm_lam && nal > 0) { QP_RUN(1); goto qp_done; }
 	/* outer loop: one pass when there are no nonlinear constraints; otherwise the multiplier /
 	 * penalty iteration of the augmented Lagrangian (at most 30 passes) */
 	for (outer = outer0; outer < (nal > 0 ? 30 : 1); outer++) {
@@ -1027,13 +1039,8 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 			/* phase 0 of the structured Newton mode (the objective alone, from the caller's start) is done: switch the
 			 * augmented Lagrangian on */
 			if (stop) { inform = 4; break; }
-			if (o->hessian == 3) {   /* QP-based SQP from the unconstrained optimum (prototype: see sqpqp_run) */
-				sqpqp_stats st;
-				inform = sqpqp_run(p, nw, &al, &pj, x, n, nc, mall, o, sr, ftol, &iter, itlim, al.lam, g, &F, &st);
-				{ int jj, ii; for (jj = 0; jj < nc; jj++) if (al.lam[jj] != 0.0) for (ii = 0; ii < n; ii++) g[ii] += al.lam[jj] * M_(p->cJac, nc, jj, ii); }   /* gradient of the Lagrangian: the linear rows' multipliers */
-				project(&pj, g, gp, lam);
-				rv = 0.0; { int jj; for (jj = 0; jj < nc; jj++) { const double bl = p->bl[n + mall + jj], bu = p->bu[n + mall + jj], cj = al.c[jj], pjv = cj < bl ? bl : (cj > bu ? bu : cj), rj = (cj - pjv) / (1.0 + fabs(cj)); rv += rj * rj; } rv = sqrt(rv); }
-				if (o->verbose) fprintf(stderr, "  sqp-qp: %d majors, %d evaluations, %d passive-set solves, at most %d active rows\n", st.majors, st.nfev, st.qp_iters, st.max_active);
+			if (o->hessian == 3) {   /* QP-based SQP step from the unconstrained optimum (sqpqp_run) */
+				QP_RUN(0);
 				break;
 			}
 			al.mu = NWT_MU0;
@@ -1050,6 +1057,7 @@ void orc_sqp_solve(orc_problem *p, double *x, const orc_sqp_opts *o, orc_sqp_res
 		else al.mu *= (nw ? NWT_MUFAC : 10.0);
 		if (outer == 29) inform = 3;   /* nonlinear constraints not satisfied to tolerance */
 	}
+qp_done:
 	if (nal > 0 && m > 0 && inform != 9) {
 		/* many hundreds of majors under a large penalty let x drift off A x = b by rounding: restore it */
 		for (i = 0; i < m; i++) { double sum = 0.0; for (j = 0; j < n; j++) sum += M_(AE, m, i, j) * x[j]; pj.tmpm[i] = bE[i] - sum; }

@@ -94,7 +94,12 @@ qe = {}
 for what in ("qp_E", "newton_E"):
     c = counters(f"pmc_{what}_mfma", "sqp_kernel")
     if c:
-        c["MfmaUtil_pct (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES x 100, the guide's definition)"] = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(c.get("SQ_BUSY_CYCLES", 1.0), 1.0)
+        # SQ_VALU_MFMA_BUSY_CYCLES: matrix-pipe cycles summed over the chip's 1024 SIMDs (64 per v_mfma_f64_16x16x4_f64: checked against SQ_INSTS_MFMA);
+        # GRBM_GUI_ACTIVE: active cycles summed over the 8 XCDs.  MfmaUtil = busy / (elapsed x SIMDs), the gfx94x formula of rocprof's derived metrics.
+        el = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        c["elapsed_cycles"] = el
+        c["MfmaUtil_pct"] = 100.0 * c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(el * 1024.0, 1.0)
+        c["mfma_flops"] = 2048.0 * c.get("SQ_INSTS_MFMA", 0.0)
         qe[what] = c
 fe = counters("pmc_qp_E_fetch", "sqp_kernel"); wr = counters("pmc_qp_E_write", "sqp_kernel")
 if "FETCH_SIZE" in fe and "WRITE_SIZE" in wr:

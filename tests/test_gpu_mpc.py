@@ -102,16 +102,19 @@ def test_mpc_run_graph_replay_is_the_host_loop():
     assert torch.equal(x1, x2) and torch.equal(lo1, lo2) and torch.equal(up1, up2)
 
 
-def test_obstacle_mpc_with_multiplier_carry_over():
+@pytest.mark.parametrize("hess", [1, 3])
+def test_obstacle_mpc_with_multiplier_carry_over(hess):
     """Receding horizon with a nonlinear inequality row (kincar + circular obstacle): the multiplier estimates travel with the horizon
     (ntg_solve_opts.warm_start + ntg_batch_mpc_shift_multipliers -- the use NPSOL's clambda was meant for, ntg.h:64-68).  Every re-solve
-    is compared with the oracle started from the SAME multipliers, and the carry-over has to pay: fewer majors than re-solving cold."""
+    is compared with the oracle started from the SAME multipliers, and the carry-over has to pay: fewer majors than re-solving cold.
+    hess = 1: augmented-Lagrangian passes from the carried-over estimates; hess = 3: the QP-based SQP step, whose first working set is the
+    rows the carried-over multipliers name (no pass on the objective alone)."""
     spec = cf.config_O(20); p = api.Plan(spec, 0)
     nb, nsteps, sknot = 6, 4, 1
     sbp = 5 * sknot
     P, n0 = spec.nbps, spec.nC + spec.nclin
     lo, up = cf.obstacle_bounds(nb)
-    cold, warm = api.default_opts(hessian=1), api.default_opts(hessian=1, warm_start=1)
+    cold, warm = api.default_opts(hessian=hess), api.default_opts(hessian=hess, warm_start=1)
     work = torch.empty(p.workspace_bytes(nb, warm), dtype=torch.uint8, device="cuda:0")
 
     def loop(carry):
@@ -127,7 +130,7 @@ def test_obstacle_mpc_with_multiplier_carry_over():
             majors += int(out["iters"].sum().item())
             if carry:
                 for i in range(nb):   # the oracle on exactly this re-solve: same bounds, same start, same starting multipliers
-                    ref = orc.solve_one(spec, lo_h[i], up_h[i], x_h[i], orc.default_opts(hessian=1), warm_lam=None if lam_prev is None else lam_prev[i])
+                    ref = orc.solve_one(spec, lo_h[i], up_h[i], x_h[i], orc.default_opts(hessian=hess), warm_lam=None if lam_prev is None else lam_prev[i])
                     assert ref["inform"] == 0
                     assert abs(out["objective"][i].item() - ref["objective"]) <= 1e-9 * max(1.0, abs(ref["objective"])), (step, i)
                     assert np.abs(x[i].cpu().numpy() - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max()), (step, i)
@@ -144,7 +147,8 @@ def test_obstacle_mpc_with_multiplier_carry_over():
     assert m_warm < m_cold, (m_warm, m_cold)
 
 
-def test_mpc_run_with_warm_start_is_the_host_loop_with_a_cold_first_step():
+@pytest.mark.parametrize("hess", [1, 3])
+def test_mpc_run_with_warm_start_is_the_host_loop_with_a_cold_first_step(hess):
     """ntg_batch_mpc_run with warm_start = 1 on a plan with nonlinear rows: the library solves the FIRST step cold (the workspace holds no
     multiplier estimates yet -- here it is filled with NaN bytes on purpose) and every later step warm, exactly like the hand-written host
     loop of three launches per step (solve, shift, multiplier shift)."""
@@ -152,7 +156,7 @@ def test_mpc_run_with_warm_start_is_the_host_loop_with_a_cold_first_step():
     nb, nsteps, sknot = 6, 4, 1
     sbp = 5 * sknot
     lo, up = cf.obstacle_bounds(nb)
-    cold, warm = api.default_opts(hessian=1), api.default_opts(hessian=1, warm_start=1)
+    cold, warm = api.default_opts(hessian=hess), api.default_opts(hessian=hess, warm_start=1)
     nbytes = p.workspace_bytes(nb, warm)
     work1 = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
     x1 = torch.ones((nb, spec.nC), dtype=torch.float64, device="cuda:0")

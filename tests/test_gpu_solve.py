@@ -281,3 +281,25 @@ def test_fallback_instance_without_register_slots():
     assert same_work(o0["nfev"], o1["nfev"]) and (o1["iters"] == 50).all()
     assert rel(o0["objective"], o1["objective"]) <= 2e-7
     assert np.abs(x0 - x1).max() <= 1e-5 * np.abs(x0).max()
+
+
+@pytest.mark.parametrize("kw", [dict(itlim=50, fixed_iters=1, hessian=0), dict(itlim=60, fixed_iters=1, hessian=0, qn_memory=20), dict(hessian=0)],
+                         ids=["fixed50", "fixed60_memory20_restarts", "to_convergence"])
+def test_fat_wave_instance_takes_a_second_problem_per_wave(kw):
+    """The headline instance (identity cold start: chain tiers in accumulator registers, LDS and HBM) with more problems than resident waves
+    (4 per CU): a persistent wave pops a SECOND and third problem from the queue and must leave nothing of the first behind (chain slots,
+    links, head pair, line-search buffers; the queue pop is where round 3's first GPU run hung).  A problem's result may not depend on
+    which wave solved it after what: bit-identical to the same problems in a batch of 8, and under a permutation of the batch.
+    (the suite's wave-kernel batches were all smaller than the resident waves.)"""
+    spec = plan_for("M").spec
+    nb = 1536
+    lo, up = cf.kincar_random_bounds(3, nb)
+    assert plan_for("M").solve_kernel(nb, api.default_opts(**kw)) == "sqp_wave_kernel"
+    xb, ob = solve("M", lo, up, np.ones((nb, spec.nC)), **kw)
+    xs, os_ = solve("M", lo[:8], up[:8], np.ones((8, spec.nC)), **kw)
+    assert np.array_equal(xb[:8], xs) and np.array_equal(ob["nfev"][:8], os_["nfev"]) and np.array_equal(ob["objective"][:8], os_["objective"])
+    perm = np.random.default_rng(5).permutation(nb)
+    xp, op = solve("M", lo[perm], up[perm], np.ones((nb, spec.nC)), **kw)
+    assert np.array_equal(xp, xb[perm]) and np.array_equal(op["iters"], ob["iters"][perm]) and np.array_equal(op["inform"], ob["inform"][perm])
+    if not kw.get("fixed_iters"):
+        assert (ob["inform"] == 0).all()
