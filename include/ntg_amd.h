@@ -165,7 +165,7 @@ int ntg_basis_batch(int ngrids, int ninterv, int order, int mult, int maxderiv, 
  * (A A')^-1, projector, with_precond != 0: the preconditioner blocks) become per problem.  Nonlinear rows are allowed (free final time
  * with obstacle / thrust / speed rows: their evaluation and the augmented-Lagrangian solve read the same per-problem tables); linear
  * inequality rows are not (NTG_E_UNSUPPORTED).
- * Afterwards ntg_batch_eval / ntg_batch_solve / ntg_batch_interp of exactly `batch` problems use these grids (hessian = 2 acts as 1;
+ * Afterwards ntg_batch_eval / ntg_batch_solve / ntg_batch_interp of exactly `batch` problems use these grids (hessian = 2 / 3 included: the band model's cost part is built per grid;
  * ntg_batch_interp then takes d_times as [batch][ntimes]: every problem at its own times; ntg_batch_mpc_shift and ntg_batch_mpc_run
  * re-pin with every problem's own basis blocks) until ntg_plan_clear_grids(). */
 int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots, const double *d_bps, int with_precond, void *stream);

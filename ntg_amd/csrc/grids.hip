@@ -13,6 +13,7 @@
 // A row of A_E has support nout * k (the k basis functions of its breakpoint, for every output): the kernel keeps the m supports in
 // LDS and never forms the dense m x nC matrix.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "ntg_dev.hpp"
 #include "plan.hpp"
 
@@ -313,5 +314,91 @@ hipError_t ntg_launch_grid_prec(const NtgDims &D, int batch, const NtgGridPrec &
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
 	if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)grid_prec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	hipLaunchKernelGGL(grid_prec_kernel, dim3(batch * g.nblk), dim3(64), lds, st, D, batch, A);
+	return hipGetLastError();
+}
+
+
+// ---- structured Newton mode (hessian = 2 / 3) on per-problem grids: the cost model of every grid ----
+// What build_newton_tables() (plan.cpp) does once for the plan's grid, per problem: K0 = sum_i 2 w_i sum_{cost variables (o, r)} m_i m_i'
+// on the compact lower band of every coupling group (free coefficients interleaved by output, p = (cl - clo) go + ov; two-sided plans:
+// the rows below the separator in the reversed array), and the band Cholesky factor (diagonal inverted: the layout nwt_solve_wave reads)
+// of every free output's block.  One workgroup per problem; an entry sums over the breakpoints in whose block both coefficients lie
+// (nwt_lo / nwt_hi), reading the problem's channel rows.  err[0] = 3: a free output's cost model is not positive definite.
+__global__ void __launch_bounds__(128)
+grid_nwt_kernel(NtgDims D, int batch, NtgGridNwt A)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+	const int b = blockIdx.x, tid = threadIdx.x, P = D.P, k = D.cls_k[0];
+	if (b >= batch) return;
+	const double *rv = A.rowv + (size_t)b * D.row_total, *bps = A.bps + (size_t)b * P;
+	double *k0 = A.k0 + (size_t)b * A.k0_sz, *lf = A.lf + (size_t)b * A.lf_sz;
+	const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, ld = hb + 1, go = D.nwt_go, clo = D.nwt_clo;
+	const bool tw = D.nwt_tw != 0;
+	const int brows = 16 * D.nwt_jb + 48, ngt = tw ? ng - 16 * D.nwt_jb : ng;
+	auto wgt = [&](int i) { double w = 0.0; if (i > 0) w += (bps[i] - bps[i - 1]) / 2; if (i < P - 1) w += (bps[i + 1] - bps[i]) / 2; return w; };
+	// sum over the breakpoints and cost variables of output o for the local coefficients cl1 >= cl2
+	auto entry = [&](int o, int cl1, int cl2) {
+		const int i0 = max((int)A.lo[cl1], (int)A.lo[cl2]), i1 = min((int)A.hi[cl1], (int)A.hi[cl2]);
+		double v = 0.0;
+		for (int i = i0; i < i1; i++) {
+			const int q1 = cl1 - A.plan_off[i], q2 = cl2 - A.plan_off[i];
+			if (q1 < 0 || q1 >= k || q2 < 0 || q2 >= k) continue;
+			const double w = wgt(i);
+			for (int r = 0; r < D.d[o] && r < NTG_MAX_ORDER; r++) {
+				const int ch = D.ch_row0[r];
+				if (ch < 0) continue;
+				const double pr = rv[ch + q1 * P + i] * rv[ch + q2 * P + i];
+				const int fl = D.iz[o] + r;
+				if (D.nucf && ((D.tcost_mask >> fl) & 1ull)) v += 2.0 * w * pr;
+				if (D.nicf && i == 0 && ((D.icost_mask >> fl) & 1ull)) v += 2.0 * pr;
+				if (D.nfcf && i == P - 1 && ((D.fcost_mask >> fl) & 1ull)) v += 2.0 * pr;
+			}
+		}
+		return v;
+	};
+	for (int e = tid; e < A.k0_sz; e += 128) k0[e] = 0.0;
+	__syncthreads();
+	for (int idx = tid; idx < ngp * ng * ld; idx += 128) {
+		const int g = idx / (ng * ld), rem = idx - g * ng * ld, p1 = rem / ld, e = rem - p1 * ld, p2 = p1 - hb + e;
+		if (p2 < 0) continue;
+		const int ov1 = p1 % go, ov2 = p2 % go;
+		if (ov1 != ov2) continue;
+		const double v = entry(g * go + ov1, clo + p1 / go, clo + p2 / go);
+		if (tw && p1 >= ngt) k0[(size_t)ngp * ng * ld + ((size_t)g * brows + (ng - 1 - p2)) * ld + e] = v;   // entry (i, j) -> row n - 1 - j of the reversed array, same band offset
+		else k0[idx] = v;
+	}
+	// free outputs: band of half width k - 1 in LDS, factored by one thread each (a few thousand operations), stored with the diagonal inverted
+	const int nfo = D.nwt_nfo, ngf = D.nwt_ngf, hbf = D.nwt_hbf, ldf = hbf + 1;
+	double *kf = (double *)smem_raw;
+	for (int idx = tid; idx < nfo * ngf * ldf; idx += 128) {
+		const int f = idx / (ngf * ldf), rem = idx - f * ngf * ldf, p1 = rem / ldf, e = rem - p1 * ldf, p2 = p1 - hbf + e;
+		kf[idx] = p2 >= 0 ? entry(ngp * go + f, clo + p1, clo + p2) : 0.0;
+	}
+	__syncthreads();
+	if (tid < nfo) {
+		double *a = kf + (size_t)tid * ngf * ldf;
+		auto L = [&](int i, int j) -> double & { return a[(size_t)i * ldf + (j - i + hbf)]; };
+		bool ok = true;
+		for (int j = 0; j < ngf && ok; j++) {
+			double dd = L(j, j);
+			for (int t = max(0, j - hbf); t < j; t++) dd -= L(j, t) * L(j, t);
+			if (!(dd > 0.0)) { ok = false; break; }
+			dd = sqrt(dd); L(j, j) = dd;
+			for (int i = j + 1; i <= min(ngf - 1, j + hbf); i++) {
+				double sv = L(i, j);
+				for (int t = max(0, i - hbf); t < j; t++) sv -= L(i, t) * L(j, t);
+				L(i, j) = sv / dd;
+			}
+		}
+		if (!ok) { if (atomicCAS(&A.err[0], 0, 3) == 0) A.err[1] = b; }
+		for (int i = 0; i < ngf; i++) for (int e = 0; e <= hbf; e++) { const int j = i - hbf + e; lf[((size_t)tid * ngf + i) * ldf + e] = j < 0 ? 0.0 : (j == i ? 1.0 / L(i, i) : L(i, j)); }
+	}
+}
+
+hipError_t ntg_launch_grid_nwt(const NtgDims &D, int batch, const NtgGridNwt &g, hipStream_t st)
+{
+	const size_t lds = (size_t)std::max(1, D.nwt_nfo * D.nwt_ngf * (D.nwt_hbf + 1)) * 8;
+	if (lds > 64 * 1024) return hipErrorInvalidValue;
+	hipLaunchKernelGGL(grid_nwt_kernel, dim3(batch), dim3(128), lds, st, D, batch, g);
 	return hipGetLastError();
 }

@@ -95,6 +95,7 @@ struct NtgTables {
 	// (strides in elements; all 0 = one shared grid).
 	long long pp_rowv, pp_bps, pp_lin, pp_sinv, pp_q, pp_n0b;
 	long long pp_blk;   // ... and blk + b pp_blk (the full basis blocks: the receding-horizon shift evaluates the whole flag)
+	long long pp_k0, pp_lf;   // ... nwt_k0 + b pp_k0, nwt_lf + b pp_lf: the structured Newton mode's cost model and free-output factors of every grid (grids.hip, grid_nwt_kernel)
 	// linear rows: erow[mE] = original row of equality e; rowmap[nclin] = e, or -(j+1) for inequality j; linflag[slot]
 	// = 1 for slots declared as inequalities; inequality rows as CSR (by row) and CSC (by coefficient)
 	const int *erow, *rowmap, *linflag, *irow;

@@ -886,7 +886,7 @@ static int resolve_params(const ntg_plan *p, const ntg_solve_opts *o, SolveParam
 	// for hessian = 2 -- no quasi-Newton history -- would let the quasi-Newton mode write its history past the end of the workspace).
 	if (sp->hessian < 0 || sp->hessian > 3) sp->hessian = 0;
 	// the QP-based SQP step (hessian = 3) rides on the structured Newton mode's band model: where that does not apply it does not either
-	if (sp->hessian >= 2 && (!D.nwt_on || p->grid_batch)) sp->hessian = 1;
+	if (sp->hessian >= 2 && (!D.nwt_on || (p->grid_batch && !p->T.pp_k0))) sp->hessian = 1;
 	sp->stamps = getenv("NTG_AMD_STAMPS") ? std::max(1, atoi(getenv("NTG_AMD_STAMPS"))) : 0;
 	const double r = o->opttol > 0 ? o->opttol : std::pow(DBL_EPSILON, 0.8);
 	sp->sr = std::sqrt(r);
@@ -1280,8 +1280,8 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 	const NtgDims &D = p->D;
 	if (D.family == NTG_FAM_HOST) return fail(NTG_E_UNSUPPORTED, "host-callback plans have one grid");
 	if (D.nclass != 1) return fail(NTG_E_UNSUPPORTED, "per-problem grids need one basis class (every output on the same knots / order / multiplicity)");
-	// Nonlinear rows are fine: their evaluation reads the same per-problem tables, and the solve takes the quasi-Newton augmented-Lagrangian
-	// mode (the structured Newton step's cost model and maps are built for the plan's grid: hessian = 2 runs as hessian = 1, ntg_batch_solve).
+	// Nonlinear rows are fine: their evaluation reads the same per-problem tables, and the structured Newton mode / the QP-based SQP step get
+	// the cost model and the free-output factors of every grid (step 4b, grids.hip grid_nwt_kernel).
 	if (D.nI > 0) return fail(NTG_E_UNSUPPORTED, "per-problem grids: plans without linear inequality rows so far");
 	HIPCHK(hipSetDevice(p->device));
 	ntg_plan_clear_grids(p);
@@ -1416,10 +1416,30 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 		if (err.load()) return fail_free(NTG_E_UNSUPPORTED, "per-problem grid: preconditioner block not positive definite");
 		if (hipMemcpy(d_n0b, n0bv.data(), n0bv.size() * 8, hipMemcpyHostToDevice) != hipSuccess) return fail_free(NTG_E_HIP, "uploading the preconditioner blocks failed");
 	}
+	// 4b. the structured Newton mode's cost model and free-output factors of every grid (hessian = 2 / 3 then run on per-problem grids like on
+	//     the plan's own; the QP-based SQP step's plan tables belong to the plan's grid and stay unused there)
+	double *d_k0pp = nullptr, *d_lfpp = nullptr;
+	const size_t k0_sz = D.nwt_on ? (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0) : 0;
+	const size_t lf_sz = D.nwt_on ? std::max<size_t>((size_t)D.nwt_nfo * D.nwt_ngf * (D.nwt_hbf + 1), 1) : 0;
+	if (D.nwt_on) {
+		if (hipMalloc((void **)&d_k0pp, (size_t)batch * k0_sz * 8) != hipSuccess || hipMalloc((void **)&d_lfpp, (size_t)batch * lf_sz * 8) != hipSuccess) {
+			if (d_k0pp) hipFree(d_k0pp);
+			return fail_free(NTG_E_HIP, "hipMalloc (per-problem cost models)");
+		}
+		NtgGridNwt gn{d_rowv, d_bpsc, p->d_planoff, p->T.nwt_lo, p->T.nwt_hi, d_k0pp, d_lfpp, d_err, (int)k0_sz, (int)lf_sz};
+		hipError_t e4 = hipMemsetAsync(d_err, 0, 16, st);
+		if (e4 == hipSuccess) e4 = ntg_launch_grid_nwt(D, batch, gn, st);
+		if (e4 == hipSuccess) e4 = hipMemcpyAsync(herr, d_err, 12, hipMemcpyDeviceToHost, st);
+		if (e4 == hipSuccess) e4 = hipStreamSynchronize(st);
+		if (e4 != hipSuccess || herr[0] == 3) {
+			hipFree(d_k0pp); hipFree(d_lfpp);
+			return e4 != hipSuccess ? fail_free(NTG_E_HIP, hipGetErrorString(e4)) : fail_free(NTG_E_UNSUPPORTED, "per-problem grid: the cost model of a free output is not positive definite (problem " + std::to_string(herr[1]) + ")");
+		}
+	}
 	hipFree(d_off); hipFree(d_err);   // (d_blk is kept: the receding-horizon shift evaluates the whole flag at a breakpoint)
 	// 5. the kernels add b * stride to the value pointers (NtgTables::pp_*)
 	p->T_shared = p->T;
-	for (void *q : {(void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b, (void *)d_knc, (void *)d_blk}) if (q) p->grid_owned.push_back(q);
+	for (void *q : {(void *)d_rowv, (void *)d_bpsc, (void *)d_csr, (void *)d_csc, (void *)d_sinv, (void *)d_q, (void *)d_n0b, (void *)d_knc, (void *)d_blk, (void *)d_k0pp, (void *)d_lfpp}) if (q) p->grid_owned.push_back(q);
 	p->d_grid_knots = d_knc;
 	NtgTables &T = p->T;
 	T.rowv = d_rowv; T.pp_rowv = row_total;
@@ -1428,6 +1448,7 @@ extern "C" int ntg_plan_set_grids(ntg_plan *p, int batch, const double *d_knots,
 	if (m > 0) { T.csr_val = d_csr; T.csc_val = d_csc; T.pp_lin = lin_nnz; T.sinv_val = d_sinv; T.pp_sinv = sinv_nnz; }
 	if (D.q_use) { T.q_val = d_q; T.pp_q = qn; }
 	if (with_precond) { T.n0b = d_n0b; T.pp_n0b = (long long)n0b_sz; T.n0 = nullptr; T.n0c = nullptr; }
+	if (D.nwt_on) { T.nwt_k0 = d_k0pp; T.pp_k0 = (long long)k0_sz; T.nwt_lf = d_lfpp; T.pp_lf = (long long)lf_sz; }
 	p->grid_batch = batch;
 	return 0;
 }

@@ -78,5 +78,9 @@ hipError_t ntg_launch_grid_lin(const NtgDims &D, int batch, const NtgGridLin &g,
 // preconditioner blocks of every grid on the device (grids.hip, grid_prec_kernel)
 struct NtgGridPrec { const double *blk, *bps; const int *plan_off, *fidx, *binfo; double *n0b; int *err; int nblk, nb, spad, n0b_sz, nrmax; };
 hipError_t ntg_launch_grid_prec(const NtgDims &D, int batch, const NtgGridPrec &g, hipStream_t st);
+// structured Newton mode on per-problem grids: cost model (band, every coupling group; two-sided layout where the plan uses it) and the free
+// outputs' band factors of every grid, from the per-problem channel rows and breakpoints
+struct NtgGridNwt { const double *rowv, *bps; const int *plan_off; const short *lo, *hi; double *k0, *lf; int *err; int k0_sz, lf_sz; };
+hipError_t ntg_launch_grid_nwt(const NtgDims &D, int batch, const NtgGridNwt &g, hipStream_t st);
 hipError_t ntg_launch_mpc_shift(const NtgDims &D, const NtgTables &T, int batch, int sbp, int sknot, const double *lic,
                                 double *x, double *lower, double *upper, hipStream_t st);

@@ -1602,6 +1602,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	stage_tables<NT>(D, T, S, smem_raw, L, b);
 	NtgTables Tw = T;   // the preconditioner blocks of this problem (per-problem grids) or the shared ones (stride 0)
 	if (HESS && T.n0b) Tw.n0b = T.n0b + (size_t)b * T.pp_n0b;
+	if (NWT && T.nwt_k0) { Tw.nwt_k0 = T.nwt_k0 + (size_t)b * T.pp_k0; Tw.nwt_lf = T.nwt_lf + (size_t)b * T.pp_lf; }   // ... and the Newton mode's cost model / free-output factors
 	for (int i = tid; i < n; i += NT) sx[i] = xio[(size_t)b * n + i];
 	lds_sync();
 	CoefMap<EPT> cm;
@@ -1685,7 +1686,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			NTG_STAMP(6);
 			if (tid == 0) nwt_flag[0] = 0;
-			nwt_assemble<NT, FamN::CG>(D, T, S.rowv, S.chrow, S.off, blocks ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), NTG_CLOCK_TK(sp.stamps == 4));   // ends with a full barrier
+			nwt_assemble<NT, FamN::CG>(D, Tw, S.rowv, S.chrow, S.off, blocks ? nwt_B : nullptr, nwt_K, (double *)(smem_raw + L.nwt_y), NTG_CLOCK_TK(sp.stamps == 4));   // ends with a full barrier
 			NTG_STAMP(3);
 			if (D.nwt_tw) {   // two waves per group (wave uniform: every wave takes this branch)
 				const int f = nwt_factor_pairs(nwt_K, nwt_K + (size_t)ngp * ng * (hb + 1), ngp, nwt_q, panel, curv ? 1 : 0, nwt_flag);
@@ -1737,7 +1738,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			yvf[i] = pp < ngf ? v[T.nwt_map[ngp * ng + f * ngf + pp]] : 0.0;
 		}
 		auto free_solves = [&] {
-			if (wave >= wfree && wave < wfree + nfo) nwt_solve_wave((nwt_glb_cdp)(T.nwt_lf + (size_t)(wave - wfree) * ngf * (hbf + 1)), ngf, hbf, (nwt_lds_dp)(yvf + (size_t)(wave - wfree) * ylenf));
+			if (wave >= wfree && wave < wfree + nfo) nwt_solve_wave((nwt_glb_cdp)(Tw.nwt_lf + (size_t)(wave - wfree) * ngf * (hbf + 1)), ngf, hbf, (nwt_lds_dp)(yvf + (size_t)(wave - wfree) * ylenf));
 		};
 		if (tw) {
 			__syncthreads();
@@ -1858,7 +1859,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	auto qp_column = [&]() __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, go = D.nwt_go, kk = K > 0 ? K : D.order[0];
 		__syncthreads();
-		if (D.nwt_tab && !nwt_curv) {   // (the current factor is the cost model's: K0)
+		if (D.nwt_tab && !nwt_curv && !T.pp_k0) {   // (the current factor is the cost model's: K0 -- of the plan's grid, whose tables these are)
 			// The model is the cost model K0 (no constraint curvature any more in this solve): W M_i' per breakpoint and M_k W M_i' per pair
 			// of breakpoints are the plan's tables (NtgTables::nwt_tu, nwt_g) -- the column and its J U are short combinations of table
 			// rows, no band solve, no breakpoint pass.
