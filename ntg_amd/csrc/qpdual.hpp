@@ -25,20 +25,20 @@
 #define NTG_QP_TRI (NTG_QP_MAXA * (NTG_QP_MAXA + 1) / 2)
 #define NTG_QP_MAXCG 6                 // constraint flag entries per group (Family::CG)
 // doubles of LDS per coupling group: S and its factor (packed lower triangles), six vectors, the slots' derivative rows, the integer state
-#define NTG_QP_DOUBLES (2 * NTG_QP_TRI + 6 * NTG_QP_MAXA + NTG_QP_MAXA * NTG_QP_MAXCG + 2 * NTG_QP_MAXA + 8)
+#define NTG_QP_DOUBLES (2 * NTG_QP_TRI + 6 * NTG_QP_MAXA + NTG_QP_MAXA * NTG_QP_MAXCG + 2 * NTG_QP_MAXA + 8 + NTG_QP_MAXA / 2)
 #define NTG_QP_RED 128                 // doubles of the entering-row search's scratch: [waves <= 8][row functions <= 8][2]
 
 // view of one group's slots (Q: address-space qualified double pointer on the device, plain on the host)
 template <class DP, class IP>
 struct QpSlotsT {
 	DP S, H, nu, nu0, z, jwg, rr, sd, ar;
-	IP ns, row, sgn, inP, flag;
+	IP ns, row, sgn, inP, flag, tab;   // tab[a] = 1: the slot's column comes from the plan's tables (not stored)
 	NTG_HD QpSlotsT(DP base)
 	{
 		S = base; H = S + NTG_QP_TRI; nu = H + NTG_QP_TRI; nu0 = nu + NTG_QP_MAXA; z = nu0 + NTG_QP_MAXA; jwg = z + NTG_QP_MAXA;
 		rr = jwg + NTG_QP_MAXA; sd = rr + NTG_QP_MAXA; ar = sd + NTG_QP_MAXA;
 		IP ib = (IP)(ar + NTG_QP_MAXA * NTG_QP_MAXCG);
-		ns = ib; flag = ib + 1; row = ib + 4; sgn = row + NTG_QP_MAXA; inP = sgn + NTG_QP_MAXA;   // 4 + 3 * 16 ints = 26 doubles
+		ns = ib; flag = ib + 1; row = ib + 4; sgn = row + NTG_QP_MAXA; inP = sgn + NTG_QP_MAXA; tab = inP + NTG_QP_MAXA;   // 4 + 4 * 16 ints = 34 doubles
 	}
 };
 #define NTG_QP_TR(a, b) ((a) * ((a) + 1) / 2 + (b))   // a >= b

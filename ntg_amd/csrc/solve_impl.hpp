@@ -1863,21 +1863,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			// The model is the cost model K0 (no constraint curvature any more in this solve): W M_i' per breakpoint and M_k W M_i' per pair
 			// of breakpoints are the plan's tables (NtgTables::nwt_tu, nwt_g) -- the column and its J U are short combinations of table
 			// rows, no band solve, no breakpoint pass.
+			// (the column itself is not stored: the step's p = -W g - sum_a lam_a U_a combines the table rows of the slots with a multiplier, once)
 			constexpr int CGc = FamN::CG, NTc2 = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
-			for (int c = tid; c < n; c += NT) {
-				const int pos = T.nwt_pos[c];
-				if (pos >= 0 && pos < ngp * ng) {
-					const int g = pos / ng, pp = pos - g * ng;
-					QpSlots q(qpbase + g * NTG_QP_DOUBLES);
-					const int a = q.flag[0];
-					if (a < 0) continue;
-					const int i = q.row[a] % P;
-					double uv = 0.0;
-#pragma unroll
-					for (int u = 0; u < CGc; u++) uv += q.ar[a * NTG_QP_MAXCG + u] * T.nwt_tu[((size_t)i * CGc + u) * ng + pp];
-					qp_U[(size_t)a * npad + c] = uv;
-				}
-			}
+			if (tid < ngp) { QpSlots q(qpbase + tid * NTG_QP_DOUBLES); const int a = q.flag[0]; if (a >= 0) q.tab[a] = 1; }
 			for (int i2 = tid; i2 < P; i2 += NT) {
 #pragma unroll
 				for (int j = 0; j < NTc2; j++) {
@@ -1935,6 +1923,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				if (a >= 0) qp_U[(size_t)a * npad + c] = sxt[c];
 			}
 		}
+		if (tid < ngp) { QpSlots q(qpbase + tid * NTG_QP_DOUBLES); const int a = q.flag[0]; if (a >= 0) q.tab[a] = 0; }
 		qp_rows_pass(1);
 		__syncthreads();
 		for (int e = tid; e < ngp * QA; e += NT) {
@@ -2095,8 +2084,12 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 					const double nua = q.nu[a];
 					if (nua == 0.0) continue;
 					const double la = q.sgn[a] < 0 ? -nua : nua;
-					pc -= la * qp_U[(size_t)a * npad + c];
 					const int i = q.row[a] % P, qq = cl - S.off[i];
+					if (q.tab[a]) {   // the slot's column from the plan's table: U = sum_u a_u K0^-1 M_i' e_u
+						double uv = 0.0;
+						for (int u = 0; u < FamN::CG; u++) uv += q.ar[a * NTG_QP_MAXCG + u] * T.nwt_tu[((size_t)i * FamN::CG + u) * ng + pp];
+						pc -= la * uv;
+					} else pc -= la * qp_U[(size_t)a * npad + c];
 					if (qq >= 0 && qq < kk2)
 						for (int u = 0; u < FamN::CG; u++)
 							if ((int)((D.nwt_upack >> (8 * u + 4)) & 15u) == ov) gl += la * q.ar[a * NTG_QP_MAXCG + u] * S.rowv[S.chrow[(int)((D.nwt_upack >> (8 * u)) & 15u)] + qq * P + i];
