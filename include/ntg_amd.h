@@ -89,8 +89,8 @@ typedef struct {
 	                     *   quadrotor, manipulator; acts as 1 where it does not apply, e.g. more coupling groups than a
 	                     *   workgroup has wavefronts) -- the robust mode for BASELINE's configs D and E,
 	                     * 3 QP-based SQP step on the same band model: per major iteration the inequality QP on the linearised rows (what NPSOL does with the
-	                     *   Jacobian ntg() hands it, ntg.c:217-220,250-253), solved through its dual by an active-set method on at most 16 rows per
-	                     *   coupling group, l1 merit function; a problem whose working set does not fit continues in mode 2 by itself.  Config E:
+	                     *   Jacobian ntg() hands it, ntg.c:217-220,250-253), solved through its dual by an active-set method on at most 16 (32: single-group plans
+	                     *   on large workgroups) rows per coupling group, l1 merit function; a problem whose working set does not fit continues in mode 2 by itself.  Config E:
 	                     *   17 majors instead of 60, 2.9 x mode 2's rate.  With warm_start the QP's first working set is the rows the carried-over
 	                     *   multipliers name (no pass on the objective alone).  Acts as 1 where the band model does not apply. */
 	int fixed_iters;    /* 1: exactly itlim majors, no convergence exit */

@@ -383,7 +383,7 @@ SmemLayout ntg_make_layout(const NtgDims &D, int nthreads, int nvec, int with_x,
 		L.tav_rows = nvec > 0 ? D.ntav : D.ntav_cost;
 		int dfz_bytes = (L.dfz_rows * (D.P + 1) + ntg_dfz_tail(D)) * 8;
 		if (D.nwt_on && nvec > 0) dfz_bytes = std::max(dfz_bytes,   // (solve layouts only: the evaluation kernels never factor anything)
-		                                   std::max(D.nwt_ngrp * ((D.nwt_tw ? 16 * (D.nwt_ja + 3) + 48 + 16 * (D.nwt_jb + 3) + 48 : 16 * ((D.nwt_ng + 15) / 16) + 48) + (D.nwt_tw ? 2 : 1) * 416 /* NWT_PANEL */) * 8 + D.nwt_nfo * (16 * ((D.nwt_ngf + 15) / 16) + 48) * 8 + (qp ? (D.nwt_ngrp * NTG_QP_DOUBLES + NTG_QP_RED) * 8 : 0) /* QP-based SQP step: the groups' slots, scratch of the entering-row search */, (nthreads / 64) * 216 * 8 + D.nwt_ngrp * ((D.P + 63) / 64) * 8));   // solve vectors + panels | the assembly's staging buffers + the block flags
+		                                   std::max(D.nwt_ngrp * ((D.nwt_tw ? 16 * (D.nwt_ja + 3) + 48 + 16 * (D.nwt_jb + 3) + 48 : 16 * ((D.nwt_ng + 15) / 16) + 48) + (D.nwt_tw ? 2 : 1) * 416 /* NWT_PANEL */) * 8 + D.nwt_nfo * (16 * ((D.nwt_ngf + 15) / 16) + 48) * 8 + (qp ? (D.nwt_ngrp * ntg_qp_doubles(ntg_qp_maxa(D.nwt_ngrp, nthreads)) + NTG_QP_RED) * 8 : 0) /* QP-based SQP step: the groups' slots, scratch of the entering-row search */, (nthreads / 64) * 216 * 8 + D.nwt_ngrp * ((D.P + 63) / 64) * 8));   // solve vectors + panels | the assembly's staging buffers + the block flags
 		L.dfz = p; L.nwt_y = p; p = align16(p + dfz_bytes);
 	}
 	L.fvals = p; p = align16(p + D.P * 8);

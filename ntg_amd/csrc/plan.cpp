@@ -929,12 +929,12 @@ static size_t hist_doubles(const NtgDims &D, int batch, const SolveParams &sp)
 }
 static size_t al_doubles(const NtgDims &D, int batch) { return (size_t)batch * 2 * (D.ncnln + D.nI); }
 // structured Newton mode: band matrix / factor of every group + the per-breakpoint blocks, per problem
-static size_t nwt_doubles(const NtgDims &D, int batch, const SolveParams &sp)
+static size_t nwt_doubles(const NtgDims &D, int batch, const SolveParams &sp, int nt)
 {
 	if (sp.hessian < 2 || !D.nwt_on) return 0;
 	const size_t rev = D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0;   // the reversed arrays of the two-sided factorisation
 	// QP-based SQP step: the slots' columns W J' and the QP's multipliers (sqp_kernel, qp_pp)
-	const size_t qp = sp.hessian == 3 ? (size_t)NTG_QP_MAXA * ((D.nC + 1) & ~1) + (size_t)((D.ncnln + 1) & ~1) * (3 + D.nwt_cg + NTG_QP_MAXA) : 0;
+	const size_t qp = sp.hessian == 3 ? (size_t)ntg_qp_maxa(D.nwt_ngrp, nt) * ((D.nC + 1) & ~1) + (size_t)((D.ncnln + 1) & ~1) * (3 + D.nwt_cg + ntg_qp_maxa(D.nwt_ngrp, nt)) : 0;
 	return (size_t)batch * ((size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + rev + (size_t)D.nwt_ngrp * D.P * D.nwt_cg * D.nwt_cg + qp);
 }
 
@@ -976,7 +976,7 @@ extern "C" long long ntg_batch_workspace_bytes(const ntg_plan *p, int batch, con
 	SmemLayout L; int big;
 	solve_layout(p->D, nt, &L, &big, &sp);
 	const size_t npad = (size_t)((p->D.nC + 1) & ~1);
-	size_t dbl = hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0) + nwt_doubles(p->D, batch, sp);
+	size_t dbl = hist_doubles(p->D, batch, sp) + al_doubles(p->D, batch) + (big ? (size_t)batch * 5 * npad : 0) + nwt_doubles(p->D, batch, sp, nt);
 	// the wave kernel's HBM tier of the direction chains (per resident wave, not per problem); sized for both of its instances
 	for (int h = 0; h < 2; h++) {
 		SolveParams s2 = sp; s2.hessian = h;

@@ -21,24 +21,27 @@
 #endif
 #endif
 
-#define NTG_QP_MAXA 16                 // slots (rows in the working set of one major iteration) per coupling group
-#define NTG_QP_TRI (NTG_QP_MAXA * (NTG_QP_MAXA + 1) / 2)
+#define NTG_QP_MAXA 32                 // largest number of slots (rows in the working set of one major iteration) of a coupling group
 #define NTG_QP_MAXCG 6                 // constraint flag entries per group (Family::CG)
-// doubles of LDS per coupling group: S and its factor (packed lower triangles), six vectors, the slots' derivative rows, the integer state
-#define NTG_QP_DOUBLES (2 * NTG_QP_TRI + 6 * NTG_QP_MAXA + NTG_QP_MAXA * NTG_QP_MAXCG + 2 * NTG_QP_MAXA + 8 + NTG_QP_MAXA / 2)
 #define NTG_QP_RED 128                 // doubles of the entering-row search's scratch: [waves <= 8][row functions <= 8][2]
+// slots per coupling group of a plan: 32 where one group has the LDS of a large workgroup to itself (quadrotor: rows stay active along arcs of the
+// trajectory), 16 for several groups (manipulator: a couple of rows per arm) and for the small workgroups that share a CU (obstacle class)
+NTG_HD int ntg_qp_maxa(int ngrp, int nthreads) { return (ngrp == 1 && nthreads >= 256) ? 32 : 16; }
+// doubles of LDS per coupling group: S and its factor (packed lower triangles), six vectors, the slots' derivative rows, the integer state
+NTG_HD int ntg_qp_doubles(int maxa) { return 2 * (maxa * (maxa + 1) / 2) + 6 * maxa + maxa * NTG_QP_MAXCG + 2 + 2 * maxa + 2; }
 
-// view of one group's slots (Q: address-space qualified double pointer on the device, plain on the host)
+// view of one group's slots (DP / IP: address-space qualified pointers on the device, plain on the host)
 template <class DP, class IP>
 struct QpSlotsT {
 	DP S, H, nu, nu0, z, jwg, rr, sd, ar;
 	IP ns, row, sgn, inP, flag, tab;   // tab[a] = 1: the slot's column comes from the plan's tables (not stored)
-	NTG_HD QpSlotsT(DP base)
+	NTG_HD QpSlotsT(DP base, int maxa)
 	{
-		S = base; H = S + NTG_QP_TRI; nu = H + NTG_QP_TRI; nu0 = nu + NTG_QP_MAXA; z = nu0 + NTG_QP_MAXA; jwg = z + NTG_QP_MAXA;
-		rr = jwg + NTG_QP_MAXA; sd = rr + NTG_QP_MAXA; ar = sd + NTG_QP_MAXA;
-		IP ib = (IP)(ar + NTG_QP_MAXA * NTG_QP_MAXCG);
-		ns = ib; flag = ib + 1; row = ib + 4; sgn = row + NTG_QP_MAXA; inP = sgn + NTG_QP_MAXA; tab = inP + NTG_QP_MAXA;   // 4 + 4 * 16 ints = 34 doubles
+		const int tri = maxa * (maxa + 1) / 2;
+		S = base; H = S + tri; nu = H + tri; nu0 = nu + maxa; z = nu0 + maxa; jwg = z + maxa;
+		rr = jwg + maxa; sd = rr + maxa; ar = sd + maxa;
+		IP ib = (IP)(ar + maxa * NTG_QP_MAXCG);
+		ns = ib; flag = ib + 1; row = ib + 4; sgn = row + maxa; inP = sgn + maxa; tab = inP + maxa;   // 4 + 4 maxa ints = 2 + 2 maxa doubles
 	}
 };
 #define NTG_QP_TR(a, b) ((a) * ((a) + 1) / 2 + (b))   // a >= b

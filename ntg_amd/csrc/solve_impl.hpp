@@ -1638,10 +1638,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	const size_t nwt_ksz = (size_t)D.nwt_ngrp * D.nwt_ng * (D.nwt_hb + 1) + (D.nwt_tw ? (size_t)D.nwt_ngrp * (16 * D.nwt_jb + 48) * (D.nwt_hb + 1) : 0);
 	// (QP-based SQP step: + the slots' columns U = W J' [NTG_QP_MAXA][npad] and the QP's multipliers of the previous major iteration [ncnln])
 	const size_t ncq = (size_t)((D.ncnln + 1) & ~1);   // rows of the QP's per-row arrays: multipliers, c, J W g, derivative rows [CG], J U [NTG_QP_MAXA]
-	const size_t qp_pp = QPM ? (size_t)NTG_QP_MAXA * npad + ncq * (3 + NWT_CG2S + NTG_QP_MAXA) : 0;
+	const size_t qp_pp = QPM ? (size_t)ntg_qp_maxa(D.nwt_ngrp, NT) * npad + ncq * (3 + NWT_CG2S + ntg_qp_maxa(D.nwt_ngrp, NT)) : 0;
 	double *nwt_K = NWT ? nwt_all + (size_t)b * (nwt_ksz + (size_t)D.nwt_ngrp * D.P * NWT_CG2 + qp_pp) : nullptr;
 	double *nwt_B = NWT ? nwt_K + nwt_ksz : nullptr;
-	double *qp_U = NWT ? nwt_B + (size_t)D.nwt_ngrp * D.P * NWT_CG2 : nullptr, *qp_lamq = NWT ? qp_U + (size_t)NTG_QP_MAXA * npad : nullptr;
+	double *qp_U = NWT ? nwt_B + (size_t)D.nwt_ngrp * D.P * NWT_CG2 : nullptr, *qp_lamq = NWT ? qp_U + (size_t)ntg_qp_maxa(D.nwt_ngrp, NT) * npad : nullptr;
 	const NwtPair nwt_q{D.nwt_ng, D.nwt_hb, D.nwt_ja, D.nwt_jb};
 	const int nwt_lena = 16 * (D.nwt_ja + 3) + 48, nwt_lenb = 16 * (D.nwt_jb + 3) + 48;
 	// LDS of the mode (the area at L.nwt_y): the groups' solve vectors, the factorisation panels (one per factoring wave), the free outputs' vectors
@@ -1774,11 +1774,14 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	//   p = -W g - sum_a lam_a U_a.
 	// The line search backtracks on the l1 merit function, which the one evaluation site returns in this mode (ALState::qp).
 	// =====================================================================================================================
-	constexpr int QA = NTG_QP_MAXA;
-	typedef QpSlotsT<double *, int *> QpSlots;
+	const int QA = ntg_qp_maxa(D.nwt_ngrp, NT), QPD = ntg_qp_doubles(QA);   // slots per coupling group, LDS doubles of a group's slot state
+	// (the slots are addressed through LDS-typed pointers: ds_read / ds_write instead of FLAT accesses, which would also count in vmcnt and wait
+	// for whatever the wave has in flight to HBM)
+	typedef __attribute__((address_space(3))) int *lds_ip;
+	typedef QpSlotsT<lds_dp, lds_ip> QpSlots;
 	const int qp_ylenf = 16 * ((D.nwt_ngf + 15) >> 4) + 48;
-	double *qpbase = (double *)(smem_raw + L.nwt_y) + nwt_yall + nwt_npan * NWT_PANEL + D.nwt_nfo * qp_ylenf;
-	double *qpred = qpbase + D.nwt_ngrp * NTG_QP_DOUBLES;   // [waves][rows per breakpoint][2] scratch of the entering-row search
+	lds_dp qpbase = (lds_dp)((double *)(smem_raw + L.nwt_y) + nwt_yall + nwt_npan * NWT_PANEL + D.nwt_nfo * qp_ylenf);
+	lds_dp qpred = qpbase + D.nwt_ngrp * QPD;   // [waves][rows per breakpoint][2] scratch of the entering-row search
 	double qp_rho = 1.0, qp_phi0 = 0.0, qp_D = 0.0, qp_alpha = 1.0, qp_viol1 = 0.0, qp_pn = 0.0, qp_xn = 0.0, qp_lmax = 0.0, qp_gl = 0.0;
 	int qp_k = 0, qp_over = 0, qp_nsolve = 0, qp_ncol = 0, qp_nocurv = 0, qp_fell = 0, qp_ntab = 0;
 	bool qp_first = true, qp_full = false, qp_last = false;   // qp_last: the final pass evaluates at the point the last step led to   // qp_full: a group's working set did not hold every row the last QP wanted
@@ -1826,7 +1829,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				for (int j = 0; j < NTc; j++) {
 					if (j >= D.nnltc) continue;
 					const int g = FamN::row_group(j), row = j * P + i;
-					QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+					QpSlots q(qpbase + g * QPD, QA);
 					const int acol = q.flag[0];
 					if (acol < 0) continue;
 					double ju = 0.0;
@@ -1847,7 +1850,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		const int ngp = D.nwt_ngrp, b0 = D.nlic + D.nltc + D.nlfc + D.nnlic;
 		for (int e = tid; e < ngp * QA; e += NT) {
 			const int g = e / QA, a = e - g * QA;
-			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			QpSlots q(qpbase + g * QPD, QA);
 			if (a >= *q.ns || (only_new && a != q.flag[0])) continue;
 			const int row = q.row[a], j = row / P;
 			for (int u = 0; u < FamN::CG; u++) q.ar[a * NTG_QP_MAXCG + u] = qp_a[(size_t)row * FamN::CG + u];
@@ -1865,13 +1868,13 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			// rows, no band solve, no breakpoint pass.
 			// (the column itself is not stored: the step's p = -W g - sum_a lam_a U_a combines the table rows of the slots with a multiplier, once)
 			constexpr int CGc = FamN::CG, NTc2 = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
-			if (tid < ngp) { QpSlots q(qpbase + tid * NTG_QP_DOUBLES); const int a = q.flag[0]; if (a >= 0) q.tab[a] = 1; }
+			if (tid < ngp) { QpSlots q(qpbase + tid * QPD, QA); const int a = q.flag[0]; if (a >= 0) q.tab[a] = 1; }
 			for (int i2 = tid; i2 < P; i2 += NT) {
 #pragma unroll
 				for (int j = 0; j < NTc2; j++) {
 					if (j >= D.nnltc) continue;
 					const int g = FamN::row_group(j), row = j * P + i2;
-					QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+					QpSlots q(qpbase + g * QPD, QA);
 					const int a = q.flag[0];
 					if (a < 0) continue;
 					const int i = q.row[a] % P;
@@ -1890,7 +1893,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			__syncthreads();
 			for (int e = tid; e < ngp * QA; e += NT) {
 				const int g = e / QA, a2 = e - g * QA;
-				QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+				QpSlots q(qpbase + g * QPD, QA);
 				const int bcol = q.flag[0];
 				if (bcol < 0 || a2 >= *q.ns) continue;
 				q.S[a2 <= bcol ? NTG_QP_TR(bcol, a2) : NTG_QP_TR(a2, bcol)] = qp_JU[(size_t)bcol * ncq + q.row[a2]];
@@ -1903,7 +1906,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		__syncthreads();
 		for (int e = tid; e < ngp * go * kk; e += NT) {
 			const int g = e / (go * kk), r = e - g * go * kk, ov = r / kk, qq = r - ov * kk;
-			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			QpSlots q(qpbase + g * QPD, QA);
 			const int a = q.flag[0];
 			if (a < 0) continue;
 			const int i = q.row[a] % P;
@@ -1918,17 +1921,17 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		for (int c = tid; c < n; c += NT) {
 			const int pos = T.nwt_pos[c];
 			if (pos >= 0 && pos < ngp * ng) {
-				QpSlots q(qpbase + (pos / ng) * NTG_QP_DOUBLES);
+				QpSlots q(qpbase + (pos / ng) * QPD, QA);
 				const int a = q.flag[0];
 				if (a >= 0) qp_U[(size_t)a * npad + c] = sxt[c];
 			}
 		}
-		if (tid < ngp) { QpSlots q(qpbase + tid * NTG_QP_DOUBLES); const int a = q.flag[0]; if (a >= 0) q.tab[a] = 0; }
+		if (tid < ngp) { QpSlots q(qpbase + tid * QPD, QA); const int a = q.flag[0]; if (a >= 0) q.tab[a] = 0; }
 		qp_rows_pass(1);
 		__syncthreads();
 		for (int e = tid; e < ngp * QA; e += NT) {
 			const int g = e / QA, a2 = e - g * QA;
-			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			QpSlots q(qpbase + g * QPD, QA);
 			const int bcol = q.flag[0];
 			if (bcol < 0 || a2 >= *q.ns) continue;   // (the whole row and column of the slot: a reused slot sits in the middle)
 			q.S[a2 <= bcol ? NTG_QP_TR(bcol, a2) : NTG_QP_TR(a2, bcol)] = qp_JU[(size_t)bcol * ncq + q.row[a2]];
@@ -1953,7 +1956,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		qp_rows_pass(0);
 		// slots of the previous major's working set, in row order (a wave per group: ballot + prefix count)
 		if (wave < ngp) {
-			QpSlots q(qpbase + wave * NTG_QP_DOUBLES);
+			QpSlots q(qpbase + wave * QPD, QA);
 			int cnt = 0;
 			for (int j = 0; j < D.nnltc; j++) {
 				if (FamN::row_group(j) != wave) continue;
@@ -1973,15 +1976,15 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		qp_slot_rows(false);
 		__syncthreads();
 		int nswarm = 0;   // the first iterations form the columns of the slots carried over (one band solve per slot index, all groups at once)
-		for (int g = 0; g < ngp; g++) { QpSlots q(qpbase + g * NTG_QP_DOUBLES); nswarm = max(nswarm, *q.ns); }
+		for (int g = 0; g < ngp; g++) { QpSlots q(qpbase + g * QPD, QA); nswarm = max(nswarm, *q.ns); }
 		for (int it = 0; it < 5 * QA + 8; it++) {
 			__syncthreads();
 			bool docol = false;
 			if (it < nswarm) {
-				if (tid < ngp) { QpSlots q(qpbase + tid * NTG_QP_DOUBLES); q.flag[0] = it < *q.ns ? it : -1; }
+				if (tid < ngp) { QpSlots q(qpbase + tid * QPD, QA); q.flag[0] = it < *q.ns ? it : -1; }
 				docol = true;
 			} else {
-			if (wave < ngp && lane == 0) { QpSlots q(qpbase + wave * NTG_QP_DOUBLES); qp_nsolve += qp_passive_solve(q); }
+			if (wave < ngp && lane == 0) { QpSlots q(qpbase + wave * QPD, QA); qp_nsolve += qp_passive_solve(q); }
 			__syncthreads();
 			// most violated linearised bound of every trajectory row function among the rows outside the passive set:
 			// c + J p = c - J W g - sum_a lam_a (J U_a)
@@ -1993,7 +1996,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				for (int j = 0; j < NTc; j++) {
 					if (j >= D.nnltc) continue;
 					const int row = j * P + i;
-					QpSlots q(qpbase + FamN::row_group(j) * NTG_QP_DOUBLES);
+					QpSlots q(qpbase + FamN::row_group(j) * QPD, QA);
 					const int ns = *q.ns;
 					double lin = qp_c[row] - qp_jwg[row];
 					int pas = 0;   // bit 0 / 1: the row's upper / lower side is passive
@@ -2022,7 +2025,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			__syncthreads();
 			if (wave < ngp && lane == 0) {
-				QpSlots q(qpbase + wave * NTG_QP_DOUBLES);
+				QpSlots q(qpbase + wave * QPD, QA);
 				double w = 0.0; int key = 0x7fffffff;
 				for (int wv = 0; wv < NT / 64; wv++)
 					for (int j = 0; j < D.nnltc; j++) {
@@ -2049,7 +2052,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			}
 			__syncthreads();
 			bool anycol = false, any = false;
-			for (int g = 0; g < ngp; g++) { QpSlots q(qpbase + g * NTG_QP_DOUBLES); anycol = anycol || q.flag[0] >= 0; any = any || q.flag[1] != 0; }
+			for (int g = 0; g < ngp; g++) { QpSlots q(qpbase + g * QPD, QA); anycol = anycol || q.flag[0] >= 0; any = any || q.flag[1] != 0; }
 			if (!any) break;
 			if (anycol) { qp_slot_rows(true); docol = true; }
 			}
@@ -2063,7 +2066,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		__syncthreads();
 		double lm = 0.0;
 		for (int g = 0; g < ngp; g++) {
-			QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+			QpSlots q(qpbase + g * QPD, QA);
 			const int ns = *q.ns;
 			for (int a = 0; a < ns; a++) { const double nua = q.nu[a]; lm = fmax(lm, fabs(nua)); if (tid == 0 && nua != 0.0) qp_lamq[D.nnlic + q.row[a]] = q.sgn[a] < 0 ? -nua : nua; }
 			if (q.flag[2]) { qp_over++; qp_full = true; }
@@ -2078,7 +2081,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			double pc = -sd[c], gl = sg[c];
 			if (pos >= 0 && pos < ngp * ng) {
 				const int g = pos / ng, pp = pos - g * ng, ov = pp % go2, cl = D.nwt_clo + pp / go2;
-				QpSlots q(qpbase + g * NTG_QP_DOUBLES);
+				QpSlots q(qpbase + g * QPD, QA);
 				const int ns = *q.ns;
 				for (int a = 0; a < ns; a++) {
 					const double nua = q.nu[a];

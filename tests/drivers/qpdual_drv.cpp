@@ -18,10 +18,10 @@ int main(int argc, char **argv)
 		std::mt19937_64 rng(seed);
 		std::normal_distribution<double> N(0.0, 1.0);
 		const int m = 2 + seed % (NTG_QP_MAXA - 1), n = 24;
-		std::vector<double> J((size_t)m * n), base(NTG_QP_DOUBLES, 0.0);
+		std::vector<double> J((size_t)m * n), base(ntg_qp_doubles(NTG_QP_MAXA), 0.0);
 		for (auto &v : J) v = N(rng);
 		if (seed % 3 == 0) for (int a = 1; a < m; a += 2) for (int c = 0; c < n; c++) J[(size_t)a * n + c] = J[(size_t)(a - 1) * n + c] + 1e-6 * N(rng);   // adjacent breakpoints
-		QpSlotsT<double *, int *> s(base.data());
+		QpSlotsT<double *, int *> s(base.data(), NTG_QP_MAXA);
 		*s.ns = m;
 		for (int a = 0; a < m; a++) {
 			for (int b = 0; b <= a; b++) { double v = 0.0; for (int c = 0; c < n; c++) v += J[(size_t)a * n + c] * J[(size_t)b * n + c]; s.S[NTG_QP_TR(a, b)] = v; }

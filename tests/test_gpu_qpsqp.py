@@ -66,11 +66,11 @@ def test_qp_sqp_full_size_against_golden_solutions(name):
     assert np.median(stat) <= 5e-8
 
 
-@pytest.mark.parametrize("name,batch,maj_mean,maj_max,fell_max", [("E", 1024, 20, 100, 0.01), ("O", 2048, 8, 40, 0.01), ("D", 512, 8, 50, 0.15)])
+@pytest.mark.parametrize("name,batch,maj_mean,maj_max,fell_max", [("E", 1024, 20, 100, 0.01), ("O", 2048, 8, 40, 0.01), ("D", 512, 8, 50, 0.05)])
 def test_qp_sqp_bench_batches(name, batch, maj_mean, maj_max, fell_max):
     """the batches bench.py runs: inform 0 for >= 99 % (config E: every problem), nothing but 0 / 1; KKT conditions of a sample with the reported
     multipliers; the share of problems that left the mode for the augmented-Lagrangian passes (working set full / no acceptable step) is
-    small -- config D's rows stay active along arcs of the trajectory: up to 15 % there"""
+    small -- config D has 32 slots per group for its rows, which stay active along arcs of the trajectory"""
     spec, bounds = _case(name)
     lo, up = bounds(batch)
     p, x, out = _solve(spec, lo, up, want_lambda=True)
@@ -95,8 +95,9 @@ def test_qp_sqp_bench_batches(name, batch, maj_mean, maj_max, fell_max):
 
 
 def test_full_working_set_continues_in_the_newton_mode():
-    """a problem whose rows stay active along an arc (more rows than a group's NTG_QP_MAXA slots) must not stall: it continues with the
-    augmented-Lagrangian passes from where it is and ends at the same optimum as the Newton mode alone"""
+    """a problem the QP step cannot finish (a working set larger than the group's slots, or -- config D's case now that it has 32 slots -- a step the
+    l1 merit function does not accept in 25 halvings) must not stall or end at inform 6: it continues with the augmented-Lagrangian passes from
+    where it is and ends at the same optimum as the Newton mode alone"""
     spec, bounds = _case("D")
     lo, up = bounds(512)
     p, x, out = _solve(spec, lo, up)
