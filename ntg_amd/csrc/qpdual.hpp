@@ -28,20 +28,20 @@
 // trajectory), 16 for several groups (manipulator: a couple of rows per arm) and for the small workgroups that share a CU (obstacle class)
 NTG_HD int ntg_qp_maxa(int ngrp, int nthreads) { return (ngrp == 1 && nthreads >= 256) ? 32 : 16; }
 // doubles of LDS per coupling group: S and its factor (packed lower triangles), six vectors, the slots' derivative rows, the integer state
-NTG_HD int ntg_qp_doubles(int maxa) { return 2 * (maxa * (maxa + 1) / 2) + 6 * maxa + maxa * NTG_QP_MAXCG + 2 + 2 * maxa + 2; }
+NTG_HD int ntg_qp_doubles(int maxa) { return 2 * (maxa * (maxa + 1) / 2) + 6 * maxa + maxa * NTG_QP_MAXCG + 2 + (5 * maxa + 1) / 2 + 2; }
 
 // view of one group's slots (DP / IP: address-space qualified pointers on the device, plain on the host)
 template <class DP, class IP>
 struct QpSlotsT {
 	DP S, H, nu, nu0, z, jwg, rr, sd, ar;
-	IP ns, row, sgn, inP, flag, tab;   // tab[a] = 1: the slot's column comes from the plan's tables (not stored)
+	IP ns, row, sgn, inP, flag, tab, pl;   // tab[a] = 1: the slot's column comes from the plan's tables (not stored); pl: the passive slots in order (device solve)
 	NTG_HD QpSlotsT(DP base, int maxa)
 	{
 		const int tri = maxa * (maxa + 1) / 2;
 		S = base; H = S + tri; nu = H + tri; nu0 = nu + maxa; z = nu0 + maxa; jwg = z + maxa;
 		rr = jwg + maxa; sd = rr + maxa; ar = sd + maxa;
 		IP ib = (IP)(ar + maxa * NTG_QP_MAXCG);
-		ns = ib; flag = ib + 1; row = ib + 4; sgn = row + maxa; inP = sgn + maxa; tab = inP + maxa;   // 4 + 4 maxa ints = 2 + 2 maxa doubles
+		ns = ib; flag = ib + 1; row = ib + 4; sgn = row + maxa; inP = sgn + maxa; tab = inP + maxa; pl = tab + maxa;   // 4 + 5 maxa ints
 	}
 };
 #define NTG_QP_TR(a, b) ((a) * ((a) + 1) / 2 + (b))   // a >= b

@@ -1788,6 +1788,81 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	(void)qp_over; (void)qp_nsolve; (void)qp_ncol; (void)qp_fell; (void)qp_ntab;
 	// flag entry (index into z) of variable u of group g
 	auto qp_flag = [&](int g, int u) __attribute__((always_inline)) { return FamN::DM * (g * D.nwt_go + (int)((D.nwt_upack >> (8 * u + 4)) & 15u)) + (int)((D.nwt_upack >> (8 * u)) & 15u); };
+	// The passive-set solve of qpdual.hpp (qp_passive_solve: same matrices, same ratio test, same drop rule) by ALL lanes of the group's wave:
+	// lane i owns row i of the passive matrix in LDS -- right-looking Cholesky with one rank-one update per pivot, substitutions with the
+	// pivot's unknown broadcast by __shfl.  The scalar routine's O(np^3) dependent LDS accesses were the tail of config D (working sets of
+	// 20 - 30 rows: a millisecond per solve); this is O(np^2) per lane.
+	auto qp_passive_solve_wave = [&](QpSlots &q, int lane) __attribute__((always_inline)) -> int {
+		int solves = 0;
+		for (;;) {
+			const int ns = *q.ns;
+			int np = 0;
+			for (int a = 0; a < ns; a++) if (q.inP[a]) { if (lane == 0) q.pl[np] = a; np++; }   // (uniform count; lane 0 writes the list)
+			nwt_wave_sync();
+			if (np == 0) break;
+			const int mya = lane < np ? q.pl[lane] : 0;
+			const double mys = q.sgn[mya] < 0 ? -1.0 : 1.0;
+			bool ok = false;
+			for (int attempt = 0; attempt < 2 && !ok; attempt++) {
+				const double shift = attempt ? 1e4 : 1.0;
+				if (lane < np)
+					for (int l = 0; l <= lane; l++) {
+						const int b2 = q.pl[l]; const double sb = q.sgn[b2] < 0 ? -1.0 : 1.0;
+						double h = mys * sb * q.S[mya >= b2 ? NTG_QP_TR(mya, b2) : NTG_QP_TR(b2, mya)];
+						if (l == lane) h += shift * 1e-10 * q.S[NTG_QP_TR(mya, mya)];
+						q.H[NTG_QP_TR(lane, l)] = h;
+					}
+				nwt_wave_sync();
+				ok = true;
+				for (int k = 0; k < np; k++) {
+					const double dkk = q.H[NTG_QP_TR(k, k)];
+					if (!(dkk > 0.0)) { ok = false; break; }   // (uniform: every lane reads the same word)
+					const double r = sqrt(dkk);
+					double lik = 0.0;
+					if (lane > k && lane < np) { lik = q.H[NTG_QP_TR(lane, k)] / r; q.H[NTG_QP_TR(lane, k)] = lik; }
+					nwt_wave_sync();
+					if (lane == k) q.H[NTG_QP_TR(k, k)] = r;
+					if (lane > k && lane < np) for (int j = k + 1; j <= lane; j++) q.H[NTG_QP_TR(lane, j)] -= lik * q.H[NTG_QP_TR(j, k)];
+					nwt_wave_sync();
+				}
+			}
+			if (!ok) {   // not factorable even with the larger shift: the working set is given up
+				if (lane < np) { q.nu[mya] = 0.0; q.inP[mya] = 0; }
+				nwt_wave_sync();
+				break;
+			}
+			// L z = -q, L' x = z
+			double zi = lane < np ? -(mys * (q.jwg[mya] + q.rr[mya]) - 1e-10 * q.S[NTG_QP_TR(mya, mya)] * q.nu0[mya]) : 0.0;
+			for (int k = 0; k < np; k++) {
+				const double lkk = q.H[NTG_QP_TR(k, k)];
+				if (lane == k) zi /= lkk;
+				const double zk = __shfl(zi, k);
+				if (lane > k && lane < np) zi -= q.H[NTG_QP_TR(lane, k)] * zk;
+			}
+			for (int k = np - 1; k >= 0; k--) {
+				const double lkk = q.H[NTG_QP_TR(k, k)];
+				if (lane == k) zi /= lkk;
+				const double xk = __shfl(zi, k);
+				if (lane < k) zi -= q.H[NTG_QP_TR(k, lane)] * xk;
+			}
+			solves++;
+			// ratio test: back to the first sign change
+			const double nua = lane < np ? q.nu[mya] : 0.0;
+			const bool bad = lane < np && q.sgn[mya] != 0 && !(zi > 0.0);
+			double al = bad ? nua / (nua - zi) : 1.0;
+#pragma unroll
+			for (int sh = 1; sh < 64; sh <<= 1) al = fmin(al, __shfl_xor(al, sh));
+			if (__ballot(bad) == 0ull) { if (lane < np) q.nu[mya] = zi; nwt_wave_sync(); break; }
+			if (!(al >= 0.0)) al = 0.0;
+			if (lane < np) {
+				const double nn = nua + al * (zi - nua);
+				if (q.sgn[mya] != 0 && !(nn > 1e-14 * (1.0 + fabs(zi)))) { q.nu[mya] = 0.0; q.inP[mya] = 0; }
+				else q.nu[mya] = nn;
+			}
+			nwt_wave_sync();
+		}
+		return solves;
+	};
 	// Row caches of one major iteration (HBM, per problem): for every trajectory row (constraint-major, like c) its value c, J W g, its
 	// derivative row on the group's CG flag entries, and -- per slot index -- J U (the row times the slot's column): the entering-row
 	// search, the entries of S and the right-hand sides are then reads and short sums, no evaluation-shaped pass per QP iteration.
@@ -1984,7 +2059,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 				if (tid < ngp) { QpSlots q(qpbase + tid * QPD, QA); q.flag[0] = it < *q.ns ? it : -1; }
 				docol = true;
 			} else {
-			if (wave < ngp && lane == 0) { QpSlots q(qpbase + wave * QPD, QA); qp_nsolve += qp_passive_solve(q); }
+			if (wave < ngp) { QpSlots q(qpbase + wave * QPD, QA); qp_nsolve += qp_passive_solve_wave(q, lane); }
 			__syncthreads();
 			// most violated linearised bound of every trajectory row function among the rows outside the passive set:
 			// c + J p = c - J W g - sum_a lam_a (J U_a)
