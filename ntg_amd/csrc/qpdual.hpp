@@ -54,7 +54,7 @@ NTG_HD int qp_passive_solve(Q &s)
 	const int ns = *s.ns;
 	int P[NTG_QP_MAXA], np = 0, solves = 0;
 	for (int a = 0; a < ns; a++) if (s.inP[a]) P[np++] = a;
-	while (np > 0) {
+	for (int round = 0; np > 0 && round < 3 * NTG_QP_MAXA + 8; round++) {   // (bounded: see the device routine)
 		// H_PP = D S D + diag(del), right-hand side -q_P
 		int ok = 0;
 		for (int attempt = 0; attempt < 2 && !ok; attempt++) {

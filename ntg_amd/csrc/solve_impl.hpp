@@ -1794,7 +1794,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	// 20 - 30 rows: a millisecond per solve); this is O(np^2) per lane.
 	auto qp_passive_solve_wave = [&](QpSlots &q, int lane) __attribute__((always_inline)) -> int {
 		int solves = 0;
-		for (;;) {
+		// (every round that does not end the loop removes at least one slot in exact arithmetic; the count is bounded all the same -- a wave
+		// that never leaves this loop would take the GPU with it)
+		for (int round = 0; round < 3 * QA + 8; round++) {
 			const int ns = *q.ns;
 			int np = 0;
 			for (int a = 0; a < ns; a++) if (q.inP[a]) { if (lane == 0) q.pl[np] = a; np++; }   // (uniform count; lane 0 writes the list)
