@@ -127,3 +127,18 @@ def test_qp_mode_falls_back_where_the_band_model_does_not_apply():
     xa = torch.ones((8, spec.nC), dtype=torch.float64, device="cuda:0"); xb = xa.clone()
     oa = p.solve(dev(lo), dev(up), xa, api.default_opts(hessian=3)); ob = p.solve(dev(lo), dev(up), xb, api.default_opts(hessian=1))
     assert torch.equal(xa, xb) and torch.equal(oa["iters"], ob["iters"])
+
+
+@pytest.mark.parametrize("name,nb", [("O", 40), ("E2", 12)])
+def test_qp_sqp_result_does_not_depend_on_the_batch(name, nb):
+    """one workgroup per problem, nothing shared but the plan's tables: a problem's result is bit-identical whether it is solved alone, in
+    a batch, or in a permuted batch (slots, row caches and columns are per problem; the working set is rebuilt in row order)"""
+    spec, bounds = _case(name)
+    lo, up = bounds(nb)
+    p, x, out = _solve(spec, lo, up)
+    perm = np.random.default_rng(11).permutation(nb)
+    _, xp, outp = _solve(spec, lo[perm], up[perm])
+    assert torch.equal(xp, x[torch.as_tensor(perm, device=x.device)])
+    assert torch.equal(outp["iters"], out["iters"][torch.as_tensor(perm, device=x.device)])
+    _, x1, out1 = _solve(spec, lo[3:4], up[3:4])
+    assert torch.equal(x1[0], x[3]) and int(out1["iters"][0]) == int(out["iters"][3])
