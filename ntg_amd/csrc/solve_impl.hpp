@@ -1878,7 +1878,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			compute_z<NOUT, K, DM>(D, S, what == 0 ? sd : sxt, i, D.tcon_mask, zv);
 			if (what == 0) {
 				double z[NZ], c[NTc], tape[FamN::TAPE];
-				compute_z<NOUT, K, DM>(D, S, sx, i, D.tcon_mask, z);
+				compute_z<NOUT, K, DM>(D, S, sxt, i, D.tcon_mask, z);   // (the trial-point buffer holds x here -- in LDS also for the BIG layouts, whose x lives in HBM)
 				FamN::template nltc_val<NZ>(NOUT > 0 ? NOUT : D.nout, i, z, c, tape);
 #pragma unroll
 				for (int j = 0; j < NTc; j++) {
@@ -2022,6 +2022,9 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	auto qp_major = [&]() __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, wave = tid >> 6, lane = tid & 63, b0 = D.nlic + D.nltc + D.nlfc + D.nnlic;
 		constexpr int NTc = FamN::NNLTC > 0 ? FamN::NNLTC : 1;
+		double qp_bl[NTc], qp_bu[NTc];   // the rows' bounds (one pair per row function), read once per major
+#pragma unroll
+		for (int j = 0; j < NTc; j++) { qp_bl[j] = j < D.nnltc ? al.lo[b0 + j] : 0.0; qp_bu[j] = j < D.nnltc ? al.up[b0 + j] : 0.0; }
 		__syncthreads();   // the multipliers crossed lanes through HBM
 		// After the model with the constraint curvature was not positive definite at two major iterations in a row the curvature is not tried
 		// again in this solve: the model is then the cost model, the same matrix at every later major -- its factor is kept (no block pass, no
@@ -2052,6 +2055,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		__syncthreads();
 		qp_slot_rows(false);
 		__syncthreads();
+		NTG_STAMP(5);   // (variant builds: row caches + slots of the carried-over working set)
 		int nswarm = 0;   // the first iterations form the columns of the slots carried over (one band solve per slot index, all groups at once)
 		for (int g = 0; g < ngp; g++) { QpSlots q(qpbase + g * QPD, QA); nswarm = max(nswarm, *q.ns); }
 		for (int it = 0; it < 5 * QA + 8; it++) {
@@ -2082,7 +2086,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 						if (nua != 0.0) lin -= (q.sgn[a] < 0 ? -nua : nua) * qp_JU[(size_t)a * ncq + row];
 						if (q.inP[a] && q.row[a] == row) pas |= q.sgn[a] < 0 ? 2 : 1;
 					}
-					const double bl = al.lo[b0 + j], bu = al.up[b0 + j];
+					const double bl = qp_bl[j], bu = qp_bu[j];
 					const double wu = (bu < 1e19 && !(pas & 1)) ? lin - bu : -1.0, wl = (bl > -1e19 && !(pas & 2)) ? bl - lin : -1.0;
 					const bool up = wu >= wl;
 					const double w = up ? wu : wl, bound = up ? bu : bl;
@@ -2139,6 +2143,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		__syncthreads();
 		// the QP's multipliers (signed: > 0 at an upper bound), the step p = -W g - sum_a lam_a U_a, the scalars of the exit test and of the
 		// merit function
+		NTG_STAMP(2);
 		for (int j = tid; j < D.ncnln; j += NT) qp_lamq[j] = 0.0;
 		__syncthreads();
 		double lm = 0.0;
@@ -2182,7 +2187,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 		block_sum<NT, 4>(r3, S);
 		qp_pn = sqrt(r3[0]); qp_xn = sqrt(r3[1]); qp_gp = r3[2]; qp_gl = sqrt(r3[3]);
 		nwt_restore();
-		NTG_STAMP(2);
+		NTG_STAMP(3);   // (variant builds: the step and its scalars -- shares the slot with the model assembly, which the QP step seldom runs)
 		__syncthreads();
 	};
 	const LinIneq lin{nI, T.irow, T.icsr_ptr, T.icsr_col, T.icsc_ptr, T.icsc_row, T.icsr_val, T.icsc_val, (double *)(smem_raw + L.tI)};
