@@ -1647,6 +1647,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	// LDS of the mode (the area at L.nwt_y): the groups' solve vectors, the factorisation panels (one per factoring wave), the free outputs' vectors
 	const int nwt_yall = D.nwt_ngrp * (D.nwt_tw ? nwt_lena + nwt_lenb : 16 * ((D.nwt_ng + 15) >> 4) + 48), nwt_npan = (D.nwt_tw ? 2 : 1) * D.nwt_ngrp;
 	bool nwt_curv = false;        // the current factor includes the constraint curvature
+	bool nwt_k0_only = false;     // the current factor is the cost model's alone (nwt_refresh_ex without blocks)
 	int nwt_bad = 0;              // diagnostic: non-positive pivots replaced in Gauss-Newton factorisations (wave 0's count)
 	int nwt_nfact = 0, nwt_nfail = 0, nwt_napply = 0;   // diagnostic (sp.stamps == 3): factorisations, of which not positive definite, solves
 	bool phase0 = NWT && alprob && !sp.warm;  // the pass on the objective alone is still running (a warm start goes straight to the multipliers it was given)
@@ -1658,6 +1659,10 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 	auto nwt_refresh_ex = [&](const double *xs, bool allow_curv, const double *tsrc, double mu_gn, bool blocks) __attribute__((always_inline)) {
 		const int ngp = D.nwt_ngrp, ng = D.nwt_ng, hb = D.nwt_hb, P2 = D.P;
 		const int wave = tid >> 6;
+		// Without blocks the matrix is the cost model K0 -- a constant of the problem: while the factor in nwt_K is K0's (the majors of the pass
+		// on the objective alone, the QP step's no-curvature regime) there is nothing to assemble or factor again.  Same matrix, same factor:
+		// the iterates are bit for bit those of refactoring every time.
+		if (!blocks && nwt_k0_only) return;
 		unsigned long long *nwt_act = (unsigned long long *)((double *)(smem_raw + L.nwt_y) + (NT / 64) * 216);   // after the assembly's staging buffers
 		double *panel = (double *)(smem_raw + L.nwt_y) + nwt_yall;
 		for (int attempt = (allow_curv && blocks) ? 0 : 1; attempt < 2; attempt++) {
@@ -1703,6 +1708,7 @@ sqp_kernel(NtgDims D, NtgTables T, SmemLayout L, SolveParams sp, int batch,
 			if (nwt_flag[0] == 0) break;
 			nwt_nfail++;
 		}
+		nwt_k0_only = !blocks;
 	};
 	auto nwt_refresh = [&](const double *xs, bool allow_curv) __attribute__((always_inline)) { nwt_refresh_ex(xs, allow_curv, al_t, al.mu, al.mu > 0.0); };
 	// restore = false: the caller keeps using the borrowed area (the QP-based SQP step's slots live behind the solve vectors) and puts
